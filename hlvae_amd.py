@@ -1,0 +1,12 @@
+"""Import shim: the package directory is ``hl-vae_amd/`` (not a valid Python identifier),
+so ``import hlvae_amd`` loads it from there and registers it under this name."""
+import importlib.util as _u
+import os as _os
+import sys as _sys
+
+_dir = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "hl-vae_amd")
+_spec = _u.spec_from_file_location("hlvae_amd", _os.path.join(_dir, "__init__.py"),
+                                   submodule_search_locations=[_dir])
+_mod = _u.module_from_spec(_spec)
+_sys.modules["hlvae_amd"] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,282 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the HL-VAE ELBO hot path.
+
+This file is a float64 CPU restatement (PyTorch tensors, autograd for the gradients)
+of the reference's algorithm for SURVEY.md section 8(a) rows P, A-J and T.  It is the
+checker for the HIP path: only tests/, __graft_entry__.smoke() and bench.py's
+``cpu_baseline`` leg may import it.  The product package never does.
+
+Pinning: tests/golden/make_golden.py imports the reference's own modules
+(/root/reference/HLVAE.py, HL_VAE/*.py) in the build container, loads identical weights
+through ``load_state_dict`` and stores the reference's outputs as fixtures;
+tests/test_oracle_golden.py checks this restatement against them to 1e-12.
+
+Every function cites the reference lines it follows (paths relative to /root/reference).
+The restatement is functional: parameters are a dict keyed by the reference's
+``state_dict`` names, the reparameterisation noise ``eps`` is an explicit argument
+(the reference draws it from torch's global RNG, HLVAE.py:361).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+DT = torch.float64
+
+
+def block_indices(types_info):
+    """Integer index tensors per type block (the reference compares float index
+    vectors with ``== i`` every step: HL_VAE/utils.py:95-96, HLVAE.py:389,405-410)."""
+    dti = np.asarray(types_info["data_types_indexes"])
+    eti = np.asarray(types_info["exp_types_indexes"])
+    pti = np.asarray(types_info["param_indexes"])
+    out = []
+    for i, tpl in enumerate(types_info["set_of_types"]):
+        out.append(dict(type=tpl[0], K=int(tpl[1]),
+                        var=torch.as_tensor(np.nonzero(dti == i)[0]),
+                        exp=torch.as_tensor(np.nonzero(eti == i)[0]),
+                        par=torch.as_tensor(np.nonzero(pti == i)[0])))
+    return out
+
+
+def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.05, dtype=DT) -> Dict[str, torch.Tensor]:
+    """Deterministic parameter set with the reference's shapes, key names and init
+    distributions (row P: HLVAE.py:109-281 -- N(0, 0.05^2) everywhere, thresholds = 1,
+    _log_vy = log(vy_init - e^-8), _disp_param = 1).  Uses its own generator, so the same
+    state can be loaded into the reference with load_state_dict."""
+    x_dim, h_e, z_dim, h_d, y_dim = dims
+    h_d = list(reversed(h_d))                                            # HLVAE.py:113
+    g = torch.Generator().manual_seed(seed)
+
+    def nrm(*shape):
+        return (torch.randn(*shape, generator=g, dtype=torch.float64) * std).to(dtype)
+
+    st: Dict[str, torch.Tensor] = {}
+    real_dim = sum(1 for t in types_info["types_dict"] if t["type"] == "real")
+    pos_dim = sum(1 for t in types_info["types_dict"] if t["type"] == "pos")
+    min_log_vy = torch.tensor([-8.0])                                    # float32 as in HLVAE.py:206-209
+    st["_log_vy_real"] = torch.log(vy_init[0] - torch.exp(min_log_vy)).to(dtype).repeat(real_dim)
+    st["_log_vy_pos"] = torch.log(vy_init[1] - torch.exp(min_log_vy)).to(dtype).repeat(pos_dim)
+    st["_disp_param"] = torch.ones(1, dtype=dtype)
+    n_in = x_dim
+    for li, n_out in enumerate(h_e):                                     # HLVAE.py:128-135
+        st[f"VAE_encoder_common_layers.{2 * li}.weight"] = nrm(n_out, n_in)
+        st[f"VAE_encoder_common_layers.{2 * li}.bias"] = nrm(n_out)
+        n_in = n_out
+    st["mean_layer.0.weight"], st["mean_layer.0.bias"] = nrm(z_dim, n_in), nrm(z_dim)
+    st["log_var_layer.0.weight"], st["log_var_layer.0.bias"] = nrm(z_dim, n_in), nrm(z_dim)
+    n_in = z_dim
+    for li, n_out in enumerate(h_d):                                     # HLVAE.py:233-242 (d_layers aliased by hidden)
+        w, b = nrm(n_out, n_in), nrm(n_out)
+        st[f"d_layers.{2 * li}.weight"], st[f"d_layers.{2 * li}.bias"] = w, b
+        st[f"hidden.{2 * li}.weight"], st[f"hidden.{2 * li}.bias"] = w, b
+        n_in = n_out
+    st["y_layer.0.weight"], st["y_layer.0.bias"] = nrm(y_dim * n_variables, n_in), nrm(y_dim * n_variables)
+    dti = np.asarray(types_info["data_types_indexes"])
+    for i, tpl in enumerate(types_info["set_of_types"]):                 # HLVAE.py:261-281
+        n = int(np.sum(dti == i))
+        K = int(tpl[1])
+        if tpl[0] == "count":
+            st[f"obs_layer.{i}.weight"], st[f"obs_layer.{i}.bias"] = nrm(n, y_dim, 1), nrm(n, 1)
+        elif tpl[0] in ("real", "pos"):
+            st[f"obs_layer.{i}.weight_mean"], st[f"obs_layer.{i}.bias_mean"] = nrm(n, y_dim, 1), nrm(n, 1)
+        elif tpl[0] == "cat":
+            st[f"obs_layer.{i}.weight"], st[f"obs_layer.{i}.bias"] = nrm(n, y_dim, K - 1), nrm(n, K - 1)
+        elif tpl[0] == "ordinal":
+            st[f"obs_layer.{i}.weight_region"], st[f"obs_layer.{i}.bias_region"] = nrm(n, y_dim, 1), nrm(n, 1)
+            st[f"obs_layer.{i}.weight_thresholds"] = torch.ones(n, K - 1, dtype=dtype)
+        else:
+            raise ValueError(tpl)
+    return st
+
+
+def batch_normalization(data, mask, blocks, conv=False):
+    """Row A.  HL_VAE/utils.py:88-143 (MLP path: types_info['conv'] False)."""
+    out = torch.zeros_like(data)
+    norm = [[], []]
+    for b in blocks:
+        m = mask[:, b["var"]]
+        d = data[:, b["exp"]]
+        if b["type"] == "real":
+            obs = d * m                                                   # utils.py:98
+            if conv:
+                out[:, b["exp"]] = obs / 255                              # utils.py:99-102
+                continue
+            mean = (obs * m).sum(0) / m.sum(0)                            # :105
+            var = torch.sum(((obs - mean) * m) ** 2, 0) / m.sum(0)        # :106
+            out[:, b["exp"]] = (obs - mean[None, :]) / torch.sqrt(var + 1e-5) * m   # :107
+            norm[0] = [mean, var]
+        elif b["type"] == "count":
+            obs = d * m
+            aux = torch.log(obs)                                          # :118
+            aux = torch.where(m == 0, torch.zeros_like(aux), aux)         # :120
+            out[:, b["exp"]] = aux
+        elif b["type"] == "pos":
+            lg = torch.log(1.0 + d * m)                                   # :124-125
+            mean = (lg * m).sum(0) / m.sum(0)                             # :126
+            var = torch.sum(((lg - mean) * m) ** 2, 0) / m.sum(0)         # :127
+            var = torch.clamp(var, 1e-6, 1e20)                            # :128
+            out[:, b["exp"]] = (lg - mean[None, :]) / torch.sqrt(var + 1e-5) * m    # :129
+            norm[1] = [mean, var]
+        else:                                                             # cat / ordinal :133-139
+            out[:, b["exp"]] = d * m.repeat_interleave(b["K"], dim=1)
+    return out, norm
+
+
+def heads(y_grouped, blocks, st, Theta):
+    """Row E value: theta = head(y) for EVERY entry (HLVAE.py:416-453; heads :11-89)."""
+    B = y_grouped.shape[0]
+    theta = torch.zeros(B, Theta, dtype=y_grouped.dtype)
+    for i, b in enumerate(blocks):
+        yb = y_grouped[:, b["var"], :]
+        if b["type"] == "count":
+            t = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight"]) + st[f"obs_layer.{i}.bias"]
+        elif b["type"] in ("real", "pos"):
+            t = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight_mean"]) + st[f"obs_layer.{i}.bias_mean"]
+        elif b["type"] == "cat":
+            t = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight"]) + st[f"obs_layer.{i}.bias"]
+            t = torch.cat([torch.zeros(B, t.shape[1], 1, dtype=t.dtype), t], -1)        # HLVAE.py:66-67
+        elif b["type"] == "ordinal":
+            thr = st[f"obs_layer.{i}.weight_thresholds"].repeat(B, 1, 1)               # :85
+            reg = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight_region"]) + st[f"obs_layer.{i}.bias_region"]
+            t = torch.cat([thr, reg], -1)                                               # :87-88
+        theta[:, b["par"]] = t.reshape(B, -1)                                           # :448
+    return theta
+
+
+def loglik_blocks(theta, data, mask, blocks, st, norm, noise=None):
+    """Rows F-I + scatter of row J.  HL_VAE/loglik.py; HLVAE.py:381-414."""
+    B, D = mask.shape
+    log_p_x = torch.zeros(B, D, dtype=theta.dtype)
+    log_p_x_missing = torch.zeros(B, D, dtype=theta.dtype)
+    params: List = []
+    for i, b in enumerate(blocks):
+        th = theta[:, b["par"]]
+        x = data[:, b["exp"]]
+        m = mask[:, b["var"]]
+        K = b["K"]
+        if b["type"] == "real":                                           # loglik.py:27-70
+            mean_d, var_d = norm[0]
+            var_d = torch.clamp(var_d, 3e-4, np.inf)                      # :38
+            log_vy = -8.0 + F.softplus(st["_log_vy_real"] + 8.0)          # :51
+            est_var = var_d * torch.exp(log_vy)                           # :52,56
+            est_mean = torch.sqrt(var_d) * th + mean_d                    # :55
+            lp = -0.5 * (x - est_mean) ** 2 / est_var - 0.5 * math.log(2 * math.pi) - 0.5 * torch.log(est_var)  # :58
+            params.append(est_mean)                                       # :64-67 (mean only)
+        elif b["type"] == "pos":                                          # loglik.py:73-121
+            mean_d, var_d = norm[1]
+            var_d = torch.clamp(var_d, 1e-3, np.inf)                      # :80
+            lx = torch.log(1.0 + x)                                       # :84
+            est_mean = torch.sqrt(var_d) * th + mean_d                    # :96
+            est_var = var_d * torch.exp(st["_log_vy_pos"])                # :100
+            lp = -0.5 * (lx - est_mean) ** 2 / est_var - 0.5 * torch.log(2 * math.pi * est_var) - lx     # :102
+            params.append(est_mean)
+        elif b["type"] == "count":                                        # loglik.py:191-213
+            lam = torch.clamp(F.softplus(th), 1e-6, 1e20)                 # :203
+            lp = x * torch.log(lam) - lam - torch.lgamma(x + 1)           # Poisson.log_prob :205-206
+            params.append(lam)
+        elif b["type"] == "cat":                                          # loglik.py:124-146
+            log_pi = th.reshape(B, -1, K)
+            log_pi = log_pi - torch.logsumexp(log_pi, 2, keepdim=True)    # :134
+            lp = torch.sum(x.reshape(B, -1, K) * F.log_softmax(log_pi, 2), -1)   # :135
+            params.append(log_pi)
+        elif b["type"] == "ordinal":                                      # loglik.py:149-188
+            t3 = th.reshape(B, -1, K)
+            part, mean_param = t3[:, :, :-1], t3[:, :, -1]                # :162
+            mean_value = F.softplus(mean_param[:, :, None])               # :163
+            theta_values = torch.cumsum(torch.clamp(F.softplus(part), 1e-6, 1e20), 2)   # :164
+            sg = torch.sigmoid(theta_values - mean_value)                 # :165
+            one = torch.ones(B, sg.shape[1], 1, dtype=sg.dtype)
+            probs = torch.cat([sg, one], 2) - torch.cat([one * 0, sg], 2) # :166-167
+            probs = torch.clamp(probs, 1e-6, 1.0)                         # :169
+            vals = torch.sum(x.reshape(B, -1, K).detach().int(), 2)       # :172
+            vals = torch.where(m == 0, torch.ones_like(vals), vals)       # :173
+            true = F.one_hot((vals - 1).long(), K).to(sg.dtype)           # :174
+            probs = probs / probs.sum(2, keepdim=True)                    # :178
+            lp = torch.sum(true * F.log_softmax(torch.log(probs), -1), -1)    # :179
+            params.append(probs)
+        log_p_x[:, b["var"]] = lp * m                                     # loglik.py:62 etc.; HLVAE.py:409
+        log_p_x_missing[:, b["var"]] = lp * (1.0 - m)                     # :63; HLVAE.py:410
+    return log_p_x, log_p_x_missing, params
+
+
+class OracleHLVAE:
+    """Functional float64 restatement of reference HLVAE (conv=False, logvar_network=False)."""
+
+    def __init__(self, dims, types_info, n_variables, state: Dict[str, torch.Tensor]):
+        self.dims = dims
+        self.x_dim, self.h_e, self.z_dim, h_d, self.y_dim = dims
+        self.h_d = list(reversed(h_d))
+        self.types_info = types_info
+        self.D = n_variables
+        self.blocks = block_indices(types_info)
+        self.Theta = len(types_info["param_indexes"])
+        self.st = state
+
+    # ---- row B: HLVAE.py:311-324 (trunk evaluated once; the reference's two evaluations are identical)
+    def encode_params(self, X_list):
+        t = X_list
+        for li in range(len(self.h_e)):
+            t = F.relu(F.linear(t, self.st[f"VAE_encoder_common_layers.{2 * li}.weight"],
+                                self.st[f"VAE_encoder_common_layers.{2 * li}.bias"]))
+        mu = F.linear(t, self.st["mean_layer.0.weight"], self.st["mean_layer.0.bias"])
+        lv = F.linear(t, self.st["log_var_layer.0.weight"], self.st["log_var_layer.0.bias"])
+        return mu, torch.clamp(lv, -15.0, 15.0)                           # :319
+
+    # ---- rows D, E, F-J: HLVAE.py:326-349
+    def decode(self, z, data, mask, norm):
+        u = z
+        for li in range(len(self.h_d)):
+            u = F.relu(F.linear(u, self.st[f"hidden.{2 * li}.weight"], self.st[f"hidden.{2 * li}.bias"]))
+        y = F.linear(u, self.st["y_layer.0.weight"], self.st["y_layer.0.bias"])
+        y_grouped = y.reshape(y.shape[0], self.D, -1)                     # :343
+        theta = heads(y_grouped, self.blocks, self.st, self.Theta)
+        # stop-gradient through missing entries (HLVAE.py:435-452): same value, gradient only where observed
+        pm = torch.zeros_like(theta)
+        for b in self.blocks:
+            pm[:, b["par"]] = mask[:, b["var"]].repeat_interleave(b["K"], dim=1)
+        theta = pm * theta + (1.0 - pm) * theta.detach()
+        log_p_x, log_p_x_missing, params = loglik_blocks(theta, data, mask, self.blocks, self.st, norm)
+        return log_p_x, log_p_x_missing, params, theta
+
+    def forward(self, data, mask, eps):
+        """HLVAE.forward (HLVAE.py:364-375) with explicit noise.  Returns a dict."""
+        X_list, norm = batch_normalization(data, mask, self.blocks, conv=False)
+        mu, lv = self.encode_params(X_list)
+        z = mu + eps * torch.exp(0.5 * lv)                                # row C: HLVAE.py:360-362
+        log_p_x, log_p_x_missing, params, theta = self.decode(z, data, mask, norm)
+        return dict(X_list=X_list, norm=norm, mu=mu, log_var=lv, z=z, log_p_x=log_p_x,
+                    log_p_x_missing=log_p_x_missing, p_params=params, theta=theta)
+
+    def test_samples(self, data, mask):
+        """Row T: get_test_samples (HLVAE.py:455-475): deterministic encode -> decode(mu)."""
+        with torch.no_grad():
+            X_list, norm = batch_normalization(data, mask, self.blocks, conv=False)
+            mu, lv = self.encode_params(X_list)
+            log_p_x, log_p_x_missing, params, theta = self.decode(mu, data, mask, norm)
+        return dict(mu=mu, log_var=lv, log_p_x=log_p_x, log_p_x_missing=log_p_x_missing, p_params=params)
+
+    @staticmethod
+    def loss_function(log_px):                                            # HLVAE.py:377-379
+        return -torch.sum(log_px, 1)
+
+
+def standard_normal_kl(mu, lv):
+    """NOT in the reference: closed-form KL(q(z|x) || N(0, I)) used by the
+    GP-free configurations; parity for it is pinned analytically, not by the reference."""
+    return -0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
+
+
+def adam_step(params: List[torch.Tensor], grads: List[torch.Tensor], m: List[torch.Tensor], v: List[torch.Tensor],
+              step: int, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam defaults (HLVAE_main.py:277-278), written out."""
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    with torch.no_grad():
+        for p, g, mi, vi in zip(params, grads, m, v):
+            mi.mul_(b1).add_(g, alpha=1 - b1)
+            vi.mul_(b2).addcmul_(g, g, value=1 - b2)
+            p.addcdiv_(mi, (vi.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)

@@ -1,0 +1,114 @@
+"""The CPU oracle (oracle/) against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  Tolerance: 1e-12 relative -- both are float64 evaluations of the
+same formulas; only summation order differs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hlvae_oracle as orc
+import gp_oracle as gpo
+import metrics_oracle as mo
+from hlvae_amd import synthetic
+from tests_common import MIX_SPEC, load_mix_case, rel_err
+
+T64 = torch.float64
+TOL = 1e-11
+
+
+@pytest.mark.parametrize("name", ["mix_init", "mix_trained"])
+def test_forward_backward_mix(golden_dir, name):
+    g, src, dims, state = load_mix_case(golden_dir, name)
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    # the reference registers the decoder trunk twice (hidden / d_layers share tensors, HLVAE.py:232-242)
+    for k in list(st):
+        if k.startswith("hidden."):
+            st[k] = st["d_layers." + k[len("hidden."):]]
+    model = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st)
+    data, mask = torch.tensor(g["data"]), torch.tensor(g["mask"])
+    out = model.forward(data, mask, torch.tensor(g["eps"]))
+    for k in ("mu", "log_var", "z", "log_p_x", "log_p_x_missing"):
+        assert rel_err(out[k].detach().numpy(), g[k]) < TOL, k
+    for i, p in enumerate(out["p_params"]):
+        assert rel_err(p.detach().numpy().reshape(g[f"p_params_{i}"].shape), g[f"p_params_{i}"]) < TOL
+    nll = model.loss_function(out["log_p_x"])
+    loss = float(g["nll_scale"][0]) * nll.sum() + orc.standard_normal_kl(out["mu"], out["log_var"])
+    assert rel_err(loss.detach().numpy(), g["loss"][0]) < TOL
+    loss.backward()
+    checked = 0
+    for k in g.files:
+        if k.startswith("grad__"):
+            name_ = k[len("grad__"):]
+            assert rel_err(st[name_].grad.numpy(), g[k]) < 1e-9, name_
+            checked += 1
+    assert checked >= 15
+    # row T
+    ts = model.test_samples(data, mask)
+    assert rel_err(ts["mu"].numpy(), g["test_mu"]) < TOL
+    assert rel_err(ts["log_p_x"].numpy(), g["test_log_p_x"]) < TOL
+    assert rel_err(ts["log_p_x_missing"].numpy(), g["test_log_p_x_missing"]) < TOL
+    # row M
+    xh, e_obs, e_mis, e_all = mo.step_metrics([p.detach() for p in out["p_params"]], data, mask, src.types_info,
+                                              st["_log_vy_pos"].detach())
+    assert rel_err(xh.numpy(), g["x_hat_mean"]) < TOL
+    assert rel_err(e_obs.numpy(), g["err_observed"]) < TOL
+    assert rel_err(e_mis.numpy(), g["err_missing"]) < TOL
+
+
+def test_d4_small(golden_dir):
+    g = np.load(os.path.join(golden_dir, "d4_small.npz"))
+    src = synthetic.make_d4(n_subjects=2, T=4, seed=5)
+    d = src.data[:8]
+    assert np.allclose([d.sum(), (d * np.arange(d.shape[1])).sum()], g["data_argsum"]), "generator drifted"
+    dims = [src.cov_dim_ext, [32], 8, [32], 5]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=3, std=0.05)
+    chk = float(sum(v.double().abs().sum() for v in state.values()))
+    assert abs(chk - g["state_checksum"][0]) < 1e-9 * chk, "weight generator drifted"
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    for k in list(st):
+        if k.startswith("hidden."):
+            st[k] = st["d_layers." + k[len("hidden."):]]
+    model = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st)
+    out = model.forward(torch.tensor(d), torch.tensor(g["mask"]), torch.tensor(g["eps"]))
+    for k in ("mu", "log_var", "log_p_x", "log_p_x_missing"):
+        assert rel_err(out[k].detach().numpy(), g[k]) < TOL, k
+    loss = float(g["nll_scale"][0]) * model.loss_function(out["log_p_x"]).sum() + \
+        orc.standard_normal_kl(out["mu"], out["log_var"])
+    assert rel_err(loss.detach().numpy(), g["loss"][0]) < TOL
+    loss.backward()
+    for k in g.files:
+        if k.startswith("grad__"):
+            assert rel_err(st[k[6:]].grad.numpy(), g[k]) < 1e-9, k
+    assert rel_err(st["y_layer.0.weight"].grad[:40].numpy(), g["grad_slice__y_layer.0.weight"]) < 1e-9
+    assert rel_err(st["VAE_encoder_common_layers.0.weight"].grad[:, :64].numpy(),
+                   g["grad_slice__VAE_encoder_common_layers.0.weight"]) < 1e-9
+
+
+def test_gp_kl(golden_dir):
+    g = np.load(os.path.join(golden_dir, "gp_kl.npz"))
+    P, P_b, N, eps, idc, lr = g["scalars"]
+    L = g["mu"].shape[1]
+    spec = gpo.spec_from_config([2], [], [0], [{"cont_covariate": 0, "cat_covariate": 2},
+                                               {"cont_covariate": 0, "cat_covariate": 3},
+                                               {"cont_covariate": 1, "cat_covariate": 4}], [], int(idc))
+    prm = {k[4:]: torch.tensor(g[k]).requires_grad_(True) for k in g.files if k.startswith("kp__")}
+    assert set(prm) == set(gpo.init_kernel_params(spec, L))
+    mu = torch.tensor(g["mu"]).requires_grad_(True)
+    lv = torch.tensor(g["log_v"]).requires_grad_(True)
+    z = torch.tensor(g["z"]).requires_grad_(True)
+    m, H = torch.tensor(g["m"]), torch.tensor(g["H"])
+    kld, gm, gH = gpo.minibatch_kld_upper_bound_iter(spec, prm, torch.tensor(g["noise"]), L, m, H, torch.tensor(g["x"]),
+                                                     mu, lv, z, P, P_b, N, True, int(idc), float(eps))
+    assert rel_err(kld.detach().numpy(), g["kld"]) < TOL
+    assert rel_err(gm.detach().numpy(), g["grad_m"]) < 1e-9
+    assert rel_err(gH.detach().numpy(), g["grad_H"]) < 1e-9
+    kld.sum().backward()
+    assert rel_err(mu.grad.numpy(), g["d_mu"]) < 1e-9
+    assert rel_err(lv.grad.numpy(), g["d_log_v"]) < 1e-9
+    assert rel_err(z.grad.numpy(), g["d_z"]) < 1e-8
+    for k, p in prm.items():
+        assert rel_err(p.grad.numpy(), g["kg__" + k]) < 1e-8, k
+    m_new, H_new = gpo.natural_gradient_update(m, H, gm.detach(), gH.detach(), float(lr))
+    assert rel_err(m_new.numpy(), g["m_new"]) < 1e-9
+    assert rel_err(H_new.numpy(), g["H_new"]) < 1e-9

@@ -1,0 +1,30 @@
+"""Shared helpers for the test-suite (fixture loading, error norms)."""
+import os
+
+import numpy as np
+import torch
+
+from hlvae_amd import synthetic
+
+MIX_SPEC = [("real", 1), ("cat", 3), ("pos", 1), ("ordinal", 4), ("count", 1), ("cat", 5), ("real", 1),
+            ("ordinal", 5), ("pos", 1), ("cat", 5), ("count", 1), ("cat", 3), ("real", 1), ("ordinal", 4)]
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+
+
+def max_abs_err(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+def load_mix_case(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    src = synthetic.make_tabular(n_rows=24, T=6, seed=7, spec=MIX_SPEC)
+    assert np.array_equal(src.data, g["data"]), "synthetic generator drifted from the fixture inputs"
+    d = [int(v) for v in g["dims"]]
+    dims = [d[0], [d[1]], d[2], [d[3]], d[4]]
+    state = {k[len("state__"):]: torch.tensor(g[k]) for k in g.files if k.startswith("state__")}
+    return g, src, dims, state
