@@ -1,0 +1,528 @@
+"""Drop-in ``HLVAE`` for MI355X: same constructor, attributes, ``state_dict`` keys and return
+tuples as the reference class (reference HLVAE.py:104-475), MLP path (``conv=False``), with the
+whole forward/backward running in hand-written HIP kernels behind the C ABI of
+include/hlvae_hip.h.  There is NO CPU fallback: calling the model with CPU tensors raises.
+
+Call surface mirrored:
+    HLVAE(dims, types_info, n_variables, vy_init, vy_fixed, logvar_network, conv)   HLVAE.py:109
+    forward(data, mask, param_mask, types_info, do_test=False) -> 8-tuple           HLVAE.py:364-375
+    encode / decode / sample_latent / loss_function / get_test_samples              HLVAE.py:284-379, 455-475
+    attributes types_info, conv, logvar_network, _log_vy_real, _log_vy_pos, z_dim, num_dim, y_dim
+
+Memory layout (MI355X-first, not the reference's): every parameter is a view into ONE flat fp32
+arena (gradients and Adam moments likewise), so the optimiser is a single HBM-streaming kernel and
+the data-parallel gradient all-reduce is one contiguous RCCL call; dense weights have padded bf16
+shadow copies (plus transposes) that the MFMA kernels read.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .layout import (KIND_CAT, KIND_COUNT, KIND_ORDINAL, KIND_POS, KIND_REAL, ColumnPlan, compile_plan)
+
+
+def _ru(v, m):
+    return (v + m - 1) // m * m
+
+
+# --- head modules: parameter containers with the reference's names and shapes ----------------------
+class Observation_Count(nn.Module):                      # reference HLVAE.py:11-22
+    def __init__(self, n, y_dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, y_dim, 1))
+        self.bias = nn.Parameter(torch.empty(n, 1))
+
+
+class Observation_Real_Pos_Beta(nn.Module):              # reference HLVAE.py:25-51 (logvar_network=False)
+    def __init__(self, n, y_dim):
+        super().__init__()
+        self.weight_mean = nn.Parameter(torch.empty(n, y_dim, 1))
+        self.bias_mean = nn.Parameter(torch.empty(n, 1))
+
+
+class Observation_Cat(nn.Module):                        # reference HLVAE.py:54-68
+    def __init__(self, n, y_dim, nclass):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, y_dim, nclass - 1))
+        self.bias = nn.Parameter(torch.empty(n, nclass - 1))
+
+
+class Observation_Ordinal(nn.Module):                    # reference HLVAE.py:70-89
+    def __init__(self, n, y_dim, nclass):
+        super().__init__()
+        self.weight_region = nn.Parameter(torch.empty(n, y_dim, 1))
+        self.bias_region = nn.Parameter(torch.empty(n, 1))
+        self.weight_thresholds = nn.Parameter(torch.empty(n, nclass - 1))
+
+
+class _Anchor(torch.autograd.Function):
+    """Connects the HIP forward/backward to autograd.  The only differentiable input is a dummy
+    anchor; backward() runs the HIP backward and assigns ``p.grad`` views of the gradient arena."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, data, mask, eps, B):
+        ctx.model, ctx.B = model, B
+        ctx.data, ctx.mask, ctx.eps = data, mask, eps
+        ctx.token = model._run_forward(data, mask, eps, B, want_params=True)
+        mu, lv, z, lpx, lpm = model._clone_outputs(B)
+        ctx.mark_non_differentiable(lpm)
+        return mu, lv, z, lpx, lpm
+
+    @staticmethod
+    def backward(ctx, g_mu, g_lv, g_z, g_lpx, g_lpm):
+        model, B = ctx.model, ctx.B
+        if g_z is not None and bool((g_z != 0).any()):
+            raise NotImplementedError("gradient through the latent sample z itself is not on the hot path")
+        if model._fwd_token != ctx.token:     # another forward overwrote the workspace: recompute
+            model._run_forward(ctx.data, ctx.mask, ctx.eps, B, want_params=False)
+        f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        model._run_backward(ctx.eps, f32(g_lpx), f32(g_mu), f32(g_lv), B)
+        model._assign_grads()
+        return None, None, None, None, None, None
+
+
+class HLVAE(nn.Module):
+    """Heterogeneous longitudinal VAE, MLP encoder/decoder, HIP hot path (see module docstring)."""
+
+    def __init__(self, dims, types_info, n_variables, vy_init=[1., .5], vy_fixed=False, logvar_network=False,
+                 conv=True, max_batch=512, materialize_samples=True):
+        super().__init__()
+        [x_dim, h_dim_e, z_dim, h_dim_d, y_dim] = dims
+        if conv:
+            raise NotImplementedError("conv=True (convolutional front/back end, reference HLVAE.py:139-152) is outside "
+                                      "the MLP hot path built here; construct with conv=False")
+        if logvar_network:
+            raise NotImplementedError("logvar_network=True is outside the hot path (SURVEY.md section 8)")
+        if not (isinstance(h_dim_e, (list, tuple)) and len(h_dim_e) == 1 and isinstance(h_dim_d, (list, tuple))
+                and len(h_dim_d) == 1):
+            raise NotImplementedError("exactly one hidden layer per side is implemented (reference config: [500])")
+        h_dim_d = [i for i in reversed(h_dim_d)]                                    # HLVAE.py:113
+        self.z_dim, self.num_dim, self.y_dim = z_dim, n_variables, y_dim
+        self.logvar_network, self.conv = logvar_network, conv
+        self.tau = 1e-3
+        self.types_info = types_info
+        self.materialize_samples = materialize_samples
+        self.plan: ColumnPlan = compile_plan(types_info, y_dim)
+        if self.plan.X != x_dim or self.plan.D != n_variables:
+            raise ValueError(f"dims[0]={x_dim}/n_variables={n_variables} do not match types_info "
+                             f"(X={self.plan.X}, D={self.plan.D})")
+        self.h_e, self.h_d = int(h_dim_e[0]), int(h_dim_d[0])
+        pl = self.plan
+        # bookkeeping attributes the reference exposes (HLVAE.py:180-201)
+        self.real_dim, self.pos_dim = pl.n_real, pl.n_pos
+
+        # ---- modules with the reference's names (state_dict keys) ------------------------------
+        self.VAE_encoder_common_layers = nn.Sequential(nn.Linear(x_dim, self.h_e), nn.ReLU())
+        self.mean_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
+        self.log_var_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
+        self._log_vy_real = nn.Parameter(torch.empty(pl.n_real))
+        self._log_vy_pos = nn.Parameter(torch.empty(pl.n_pos))
+        self._disp_param = nn.Parameter(torch.ones(1))
+        self.d_layers = nn.ModuleList([nn.Linear(z_dim, self.h_d), nn.ReLU()])
+        self.hidden = nn.Sequential(*self.d_layers)                                  # alias, HLVAE.py:242
+        self.y_layer = nn.Sequential(nn.Linear(self.h_d, y_dim * n_variables))
+        self.obs_layer = nn.ModuleList()
+        for b in pl.blocks:
+            n, K = b["n_vars"], b["nclass"]
+            if b["type"] == "count":
+                self.obs_layer.append(Observation_Count(n, y_dim))
+            elif b["type"] in ("real", "pos"):
+                self.obs_layer.append(Observation_Real_Pos_Beta(n, y_dim))
+            elif b["type"] == "cat":
+                self.obs_layer.append(Observation_Cat(n, y_dim, K))
+            else:
+                self.obs_layer.append(Observation_Ordinal(n, y_dim, K))
+
+        # ---- flat arena: [atomically accumulated grads | dense weights] -------------------------
+        order: List[nn.Parameter] = [self._log_vy_real, self._log_vy_pos, self._disp_param]
+        for m in self.obs_layer:
+            order += list(m.parameters())
+        order += [self.y_layer[0].bias, self.d_layers[0].bias, self.mean_layer[0].bias, self.log_var_layer[0].bias,
+                  self.VAE_encoder_common_layers[0].bias]
+        n_small = len(order)
+        order += [self.y_layer[0].weight, self.d_layers[0].weight, self.mean_layer[0].weight,
+                  self.log_var_layer[0].weight, self.VAE_encoder_common_layers[0].weight]
+        self._order = order
+        offs, o = [], 0
+        for i, p in enumerate(order):
+            if i == n_small:
+                self._atomic_region = o
+            offs.append(o)
+            o = _ru(o + p.numel(), 32)
+        self._offsets = offs
+        self._arena_size = _ru(o, 64)
+        arena = torch.zeros(self._arena_size, dtype=torch.float32)
+        self._bind_arena(arena)
+        self._init_parameters(vy_init)
+        if vy_fixed:
+            self._log_vy_real.requires_grad_(False)
+            self._log_vy_pos.requires_grad_(False)
+        self._anchor = torch.zeros((), requires_grad=True)
+        self._plan_handle = None
+        self._ws = None
+        self._ws_t = {}
+        self._max_batch = max_batch
+        self._shadow_versions = None
+        self._fwd_token = 0
+        self._block_cols = None
+
+    # ------------------------------------------------------------------ arena / parameters
+    def _bind_arena(self, arena: torch.Tensor):
+        self._arena = arena
+        self._grad_arena = None
+        for p, o in zip(self._order, self._offsets):
+            p.data = arena[o:o + p.numel()].view(p.shape)
+            p.grad = None
+
+    def _init_parameters(self, vy_init):
+        """Row P: N(0, 0.05^2) everywhere, thresholds 1, _log_vy = log(vy - e^-8) (HLVAE.py:132-133,
+        169-176, 205-216, 237-250; heads :17-18, 39-40, 60-61, 79-82)."""
+        with torch.no_grad():
+            for p in self._order:
+                p.normal_(0.0, 0.05)
+            for m in self.obs_layer:
+                if isinstance(m, Observation_Ordinal):
+                    m.weight_thresholds.fill_(1.0)
+            min_log_vy = torch.tensor([-8.0])
+            self._log_vy_real.fill_(float(torch.log(vy_init[0] - torch.exp(min_log_vy))))
+            self._log_vy_pos.fill_(float(torch.log(vy_init[1] - torch.exp(min_log_vy))))
+            self._disp_param.fill_(1.0)
+
+    def _apply(self, fn, *a, **k):
+        """``.to(device)`` / ``.cuda()`` move the arena as ONE tensor and re-bind the parameter views;
+        dtype casts (``.double()``, ``.to(torch.float64)`` as in reference HLVAE_main.py:156-158) are
+        accepted and ignored: masters stay fp32, compute is bf16 MFMA with fp32 accumulation."""
+        probe = fn(torch.empty(0, dtype=torch.float32, device=self._arena.device))
+        if probe.device != self._arena.device:
+            req = [p.requires_grad for p in self._order]
+            self._release_device_state()
+            self._bind_arena(self._arena.to(probe.device))
+            for p, r in zip(self._order, req):
+                p.requires_grad_(r)
+            self._anchor = torch.zeros((), requires_grad=True, device=probe.device)
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        sd = {k: v.to(torch.float32) for k, v in state_dict.items()}
+        out = super().load_state_dict(sd, strict=strict, assign=False)
+        self._shadow_versions = None
+        return out
+
+    def _release_device_state(self):
+        if self._plan_handle is not None:
+            _lib.load().hlvae_plan_destroy(self._plan_handle)
+        self._plan_handle, self._ws, self._ws_t, self._shadow_versions = None, None, {}, None
+        self._grad_arena = None
+        self._block_cols = None
+
+    def __del__(self):
+        try:
+            self._release_device_state()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plan + workspace
+    @property
+    def device(self):
+        return self._arena.device
+
+    def arena_offset(self, p: nn.Parameter) -> int:
+        for q, o in zip(self._order, self._offsets):
+            if q is p:
+                return o
+        raise KeyError("parameter not in arena")
+
+    def _build_dims(self) -> _lib.HlvaeDims:
+        pl = self.plan
+        d = _lib.HlvaeDims()
+        d.D, d.X, d.y_dim, d.h_e, d.h_d, d.L = pl.D, pl.X, self.y_dim, self.h_e, self.h_d, self.z_dim
+        d.n_real, d.n_pos = pl.n_real, pl.n_pos
+        ao = self.arena_offset
+        d.o_w1, d.o_b1 = ao(self.VAE_encoder_common_layers[0].weight), ao(self.VAE_encoder_common_layers[0].bias)
+        d.o_wmu, d.o_bmu = ao(self.mean_layer[0].weight), ao(self.mean_layer[0].bias)
+        d.o_wlv, d.o_blv = ao(self.log_var_layer[0].weight), ao(self.log_var_layer[0].bias)
+        d.o_wd, d.o_bd = ao(self.d_layers[0].weight), ao(self.d_layers[0].bias)
+        d.o_wy, d.o_by = ao(self.y_layer[0].weight), ao(self.y_layer[0].bias)
+        d.arena_size, d.atomic_region = self._arena_size, self._atomic_region
+        _lib.load().hlvae_dims_fill(C.byref(d))
+        return d
+
+    def _build_vars(self):
+        pl = self.plan
+        arr = (_lib.HlvaeVar * pl.D)()
+        ao = self.arena_offset
+        o_real, o_pos = ao(self._log_vy_real), ao(self._log_vy_pos)
+        for d in range(pl.D):
+            v = arr[d]
+            kind, K, bi = int(pl.kind[d]), int(pl.ncls[d]), int(pl.bidx[d])
+            m = self.obs_layer[int(pl.blk[d])]
+            v.kind, v.ncls, v.xoff, v.sidx, v.e_off, v.pad = kind, K, int(pl.xoff[d]), -1, -1, 0
+            if kind in (KIND_REAL, KIND_POS):
+                v.w_off, v.b_off = ao(m.weight_mean) + bi * self.y_dim, ao(m.bias_mean) + bi
+                si = int(pl.sidx[d])
+                v.sidx = si if kind == KIND_REAL else pl.n_real + si      # reals first, then pos
+                v.e_off = (o_real if kind == KIND_REAL else o_pos) + si
+            elif kind == KIND_COUNT:
+                v.w_off, v.b_off = ao(m.weight) + bi * self.y_dim, ao(m.bias) + bi
+            elif kind == KIND_CAT:
+                v.w_off, v.b_off = ao(m.weight) + bi * self.y_dim * (K - 1), ao(m.bias) + bi * (K - 1)
+            else:
+                v.w_off, v.b_off = ao(m.weight_region) + bi * self.y_dim, ao(m.bias_region) + bi
+                v.e_off = ao(m.weight_thresholds) + bi * (K - 1)
+        return arr
+
+    def _ensure_device_state(self, B: int):
+        if self.device.type != "cuda":
+            raise RuntimeError("hlvae_amd.HLVAE runs on MI355X through its HIP library only; move the model and the "
+                               "inputs to the GPU (model.to('cuda')).  There is no CPU fallback.")
+        lib = _lib.load()
+        if self._plan_handle is None:
+            self._dims = self._build_dims()
+            h = C.c_void_p()
+            _lib.check(lib.hlvae_plan_create(C.byref(h), C.byref(self._dims), self._build_vars()), "hlvae_plan_create")
+            self._plan_handle = h
+        Bp = _ru(max(B, 1), 128)
+        if self._ws is None or Bp > self._ws.Bp_max:
+            self._alloc_workspace(max(Bp, _ru(self._max_batch, 128)))
+        self._sync_shadows()
+
+    def _alloc_workspace(self, Bp: int):
+        d, dev = self._dims, self.device
+        bf, f32 = torch.bfloat16, torch.float32
+        z = lambda *s, dt=bf: torch.zeros(*s, dtype=dt, device=dev)
+        ksteps_e, ksteps_d = d.Xp // 64, d.NYp // 64
+        # split-K so that (Bp/64)*(h/64)*S is about 2-3 waves of the 256 CUs, with no empty split
+        def pick(ksteps, tiles):
+            S = max(1, min(ksteps, (640 + tiles - 1) // tiles))
+            per = (ksteps + S - 1) // S
+            return (ksteps + per - 1) // per
+        S_e = pick(ksteps_e, (Bp // 64) * (d.hep // 64))
+        S_d = pick(ksteps_d, (Bp // 64) * (d.hdp // 64))
+        NT = (d.D + 15) // 16
+        t = dict(
+            G=z(self._arena_size, dt=f32),
+            w1s=z(d.hep, d.Xp), wmls=z(2 * d.Lp, d.hep), wmlTs=z(d.hep, 2 * d.Lp), wds=z(d.hdp, d.Lp),
+            wdTs=z(d.Lp, d.hdp), wys=z(d.NY, d.hdp), wyTs=z(d.hdp, d.NYp),
+            sums=z(3, max(d.n_stat, 1), dt=torch.float64), norm=z(2, max(d.n_stat, 1), dt=f32),
+            xn=z(Bp, d.Xp), xnT=z(d.Xp, Bp), xt=z(Bp, d.D, dt=f32), m8=z(Bp, d.D, dt=torch.uint8),
+            slab=z(max(S_e, S_d), Bp, max(d.hep, d.hdp), dt=f32),
+            t=z(Bp, d.hep), tT=z(d.hep, Bp), mu=z(Bp, d.L, dt=f32), lv=z(Bp, d.L, dt=f32), z=z(Bp, d.L, dt=f32),
+            zb=z(Bp, d.Lp), zbT=z(d.Lp, Bp), u=z(Bp, d.hdp), uT=z(d.hdp, Bp), dy=z(Bp, d.NYp), dyT=z(d.NY, Bp),
+            log_p_x=z(Bp, d.D, dt=f32), log_p_x_missing=z(Bp, d.D, dt=f32), rowpart=z(NT, Bp, dt=f32),
+            nll=z(Bp, dt=f32), scal=z(8, dt=torch.float64), pfull=z(Bp, d.X, dt=f32), xhat=z(Bp, d.D, dt=f32),
+            du=z(Bp, d.hdp), duT=z(d.hdp, Bp), dz=z(Bp, d.Lp, dt=f32), dml=z(Bp, 2 * d.Lp), dmlT=z(2 * d.Lp, Bp),
+            dt=z(Bp, d.hep), dtT=z(d.hep, Bp))
+        t["P"] = self._arena
+        ws = _lib.HlvaeWs()
+        ws.Bp_max, ws.splitk_enc, ws.splitk_dec = Bp, S_e, S_d
+        for name in _lib.WS_POINTERS:
+            setattr(ws, name, t[name].data_ptr())
+        self._ws, self._ws_t = ws, t
+        self._grad_arena = t["G"]
+        self._shadow_versions = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _sync_shadows(self, force=False):
+        """bf16 shadows follow the fp32 masters: refreshed when any parameter tensor was modified in
+        place (optimizer step, load_state_dict) since the last refresh."""
+        ver = tuple(p._version for p in self._order)
+        if force or ver != self._shadow_versions:
+            _lib.check(_lib.load().hlvae_refresh_shadows(self._plan_handle, C.byref(self._ws), self._stream()),
+                       "hlvae_refresh_shadows")
+            self._shadow_versions = ver
+
+    def mark_shadows_fresh(self):
+        """called by the fused optimiser (which rewrites the shadows itself)"""
+        self._shadow_versions = tuple(p._version for p in self._order)
+
+    # ------------------------------------------------------------------ raw stage drivers
+    def _prep_inputs(self, data, mask):
+        if data.device.type != "cuda" or mask.device.type != "cuda":
+            raise RuntimeError("hlvae_amd.HLVAE: inputs must live on the GPU (no CPU fallback)")
+        if data.dim() != 2 or data.shape[1] != self.plan.X or mask.shape != (data.shape[0], self.plan.D):
+            raise ValueError(f"expected data [B,{self.plan.X}] and mask [B,{self.plan.D}], got {tuple(data.shape)} "
+                             f"and {tuple(mask.shape)}")
+        return data.to(torch.float64).contiguous(), mask.to(torch.float64).contiguous()
+
+    def _run_normalize(self, data, mask, B, stats_hook=None):
+        lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
+        _lib.check(lib.hlvae_normalize_stats(self._plan_handle, ws, _lib.ptr(data), _lib.ptr(mask), B, s), "normalize_stats")
+        if stats_hook is not None:
+            stats_hook(self._ws_t["sums"])          # data-parallel: all-reduce the masked column sums
+        _lib.check(lib.hlvae_normalize_pack(self._plan_handle, ws, _lib.ptr(data), _lib.ptr(mask), B, s), "normalize_pack")
+
+    def _run_forward(self, data, mask, eps, B, want_params=True, g_scale=1.0, want_grad=False, stats_hook=None):
+        lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
+        self._run_normalize(data, mask, B, stats_hook)
+        _lib.check(lib.hlvae_encoder_fwd(self._plan_handle, ws, _lib.ptr(eps), B, s), "encoder_fwd")
+        if want_grad:
+            _lib.check(lib.hlvae_zero_grad(self._plan_handle, ws, s), "zero_grad")
+        _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, None, C.c_float(g_scale), int(want_grad), int(want_params),
+                                         B, s), "decoder_fwd")
+        self._fwd_token += 1
+        return self._fwd_token
+
+    def _run_decoder_only(self, B, want_params=True):
+        lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
+        _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, None, C.c_float(1.0), 0, int(want_params), B, s), "decoder_fwd")
+        self._fwd_token += 1
+
+    def _run_backward(self, eps, g_lpx, g_mu, g_lv, B):
+        """recompute the head kernel with the real upstream gradient, then the dense backward"""
+        lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
+        _lib.check(lib.hlvae_zero_grad(self._plan_handle, ws, s), "zero_grad")
+        _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, _lib.ptr(g_lpx), C.c_float(0.0 if g_lpx is None else 1.0),
+                                         1, 0, B, s), "decoder_fwd(grad)")
+        _lib.check(lib.hlvae_backward(self._plan_handle, ws, _lib.ptr(eps), _lib.ptr(g_mu), _lib.ptr(g_lv), B, s), "backward")
+
+    def _assign_grads(self):
+        G = self._grad_arena
+        for p, o in zip(self._order, self._offsets):
+            if p.requires_grad and p is not self._disp_param:
+                p.grad = G[o:o + p.numel()].view(p.shape)
+
+    def _clone_outputs(self, B):
+        t = self._ws_t
+        return (t["mu"][:B].clone(), t["lv"][:B].clone(), t["z"][:B].clone(), t["log_p_x"][:B].clone(),
+                t["log_p_x_missing"][:B].clone())
+
+    # ------------------------------------------------------------------ p_params / p_samples
+    def _block_columns(self):
+        if self._block_cols is None:
+            pti = np.asarray(self.types_info["param_indexes"])
+            self._block_cols = [torch.as_tensor(np.nonzero(pti == i)[0], device=self.device)
+                                for i in range(len(self.plan.blocks))]
+        return self._block_cols
+
+    def _p_params(self, B):
+        """per-type parameter tensors in ``set_of_types`` order with the reference's shapes
+        (cat/ordinal [B,n,K], real/pos/count [B,n]; HLVAE.py:411-412, loglik.py 'params')."""
+        pf = self._ws_t["pfull"][:B]
+        out = []
+        for b, cols in zip(self.plan.blocks, self._block_columns()):
+            p = pf.index_select(1, cols)
+            out.append(p.reshape(B, b["n_vars"], b["nclass"]) if b["type"] in ("cat", "ordinal") else p)
+        return out
+
+    def _norm_params(self):
+        """[[mean, var]_real, [mean, var]_pos] as batch_normalization returns them (HL_VAE/utils.py:108,132)."""
+        nm, pl = self._ws_t["norm"], self.plan
+        real = [nm[0, :pl.n_real].clone(), nm[1, :pl.n_real].clone()] if pl.n_real else []
+        pos = [nm[0, pl.n_real:pl.n_real + pl.n_pos].clone(), nm[1, pl.n_real:pl.n_real + pl.n_pos].clone()] if pl.n_pos else []
+        return [real, pos]
+
+    def _p_samples(self, p_params, B):
+        """Samples from the fitted likelihoods with the reference's semantics, including its quirks
+        (loglik.py:59,68; 118-119; 141-142 softmax over the VARIABLE axis; 184-186; 211).  Plain torch
+        ops on the GPU: sampling is not on the training hot path."""
+        import torch.distributions as td
+        nm, pl = self._ws_t["norm"], self.plan
+        out = []
+        for b, p in zip(pl.blocks, p_params):
+            K = b["nclass"]
+            if b["type"] == "real":
+                var_d = torch.clamp(nm[1, :pl.n_real], min=3e-4)
+                lvy = -8.0 + torch.nn.functional.softplus(self._log_vy_real.detach() + 8.0)
+                out.append(p + torch.sqrt(var_d * torch.exp(lvy)) * torch.randn_like(p))
+            elif b["type"] == "pos":
+                var_d = torch.clamp(nm[1, pl.n_real:pl.n_real + pl.n_pos], min=1e-3)
+                sd = torch.sqrt(var_d * torch.exp(self._log_vy_pos.detach()))
+                out.append(torch.clamp(torch.exp(p + sd * torch.randn_like(p)) - 1.0, 0, 1e20))
+            elif b["type"] == "count":
+                out.append(torch.poisson(p))
+            elif b["type"] == "cat":
+                idx = td.Categorical(probs=torch.softmax(p, dim=1)).sample()
+                out.append(torch.nn.functional.one_hot(idx, K).to(torch.float64))
+            else:
+                idx = td.Categorical(logits=torch.log(torch.clamp(p, 1e-6, 1e20))).sample()
+                out.append((torch.arange(1, K + 1, device=p.device)[None, None, :] <= (1 + idx)[:, :, None]).to(torch.float64))
+        return out
+
+    # ------------------------------------------------------------------ reference call surface
+    def sample_latent(self, mu, log_var):                                            # HLVAE.py:351-362
+        std = torch.exp(0.5 * log_var)
+        return mu + torch.randn_like(std) * std
+
+    def loss_function(self, log_px):                                                 # HLVAE.py:377-379
+        return -torch.sum(log_px, 1)
+
+    def forward(self, data, mask, param_mask, types_info, do_test=False, eps=None):
+        """HLVAE.forward (HLVAE.py:364-375).  ``param_mask`` is implied by ``mask`` (each variable's bit
+        repeated over its parameter slots, read_functions.py:173-176) and is not read.
+        ``eps`` (optional, [B, L]) fixes the reparameterisation noise; default: torch's CUDA RNG."""
+        data, mask = self._prep_inputs(data, mask)
+        B = data.shape[0]
+        self._ensure_device_state(B)
+        if eps is None:
+            eps = torch.randn(B, self.z_dim, device=self.device, dtype=torch.float32)
+        eps = eps.to(device=self.device, dtype=torch.float32).contiguous()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._order)
+        if need_grad:
+            mu, lv, z, lpx, lpm = _Anchor.apply(self._anchor, self, data, mask, eps, B)
+        else:
+            self._run_forward(data, mask, eps, B, want_params=True)
+            mu, lv, z, lpx, lpm = self._clone_outputs(B)
+        p_params = {"x": self._p_params(B)}
+        p_samples = {"x": self._p_samples(p_params["x"], B) if self.materialize_samples else None}
+        q_samples = {"s": None, "z": z}
+        q_params = {"s": None, "z": [mu, lv]}
+        return p_samples, mu, lv, lpx, lpm, p_params, q_samples, q_params
+
+    def encode(self, data, mask, param_mask, types_info, norm_params=None, X_list=None):
+        """HLVAE.encode (HLVAE.py:284-324), inference only (the reference calls it under no_grad:
+        training.py:176, HLVAE_main.py:194).  Batch statistics are always recomputed on device."""
+        data, mask = self._prep_inputs(data, mask)
+        B = data.shape[0]
+        self._ensure_device_state(B)
+        lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
+        eps = torch.randn(B, self.z_dim, device=self.device, dtype=torch.float32) if self.training else None
+        self._run_normalize(data, mask, B)
+        _lib.check(lib.hlvae_encoder_fwd(self._plan_handle, ws, _lib.ptr(eps), B, s), "encoder_fwd")
+        self._fwd_token += 1
+        t = self._ws_t
+        mu, lv, z = t["mu"][:B].clone(), t["lv"][:B].clone(), t["z"][:B].clone()
+        return {"s": None, "z": z}, {"s": None, "z": [mu, lv]}
+
+    def _set_latent(self, z, B):
+        t, L = self._ws_t, self.z_dim
+        zf = z.detach().to(device=self.device, dtype=torch.float32)
+        t["z"][:B].copy_(zf)
+        t["zb"].zero_()
+        t["zb"][:B, :L].copy_(zf)
+        Bp = _ru(B, 128)
+        zbT = t["zbT"].view(-1)[: self._dims.Lp * Bp].view(self._dims.Lp, Bp)
+        zbT.zero_()
+        zbT[:L, :B].copy_(zf.t())
+
+    def decode(self, z, batch_x, miss_list, param_mask, norm_params=None):
+        """HLVAE.decode (HLVAE.py:326-349), inference only -> (log_p_x, log_p_x_missing, p_samples, p_params)."""
+        data, mask = self._prep_inputs(batch_x, miss_list)
+        B = data.shape[0]
+        self._ensure_device_state(B)
+        self._run_normalize(data, mask, B)
+        self._set_latent(z, B)
+        self._run_decoder_only(B, want_params=True)
+        t = self._ws_t
+        p_params = {"x": self._p_params(B)}
+        p_samples = {"x": self._p_samples(p_params["x"], B) if self.materialize_samples else None}
+        return t["log_p_x"][:B].clone(), t["log_p_x_missing"][:B].clone(), p_samples, p_params
+
+    def get_test_samples(self, data, miss_list, param_mask, data_list=None, X_list=None, norm_params=None, s=None):
+        """HLVAE.get_test_samples (HLVAE.py:455-475): deterministic encode, decode(mean_qz)."""
+        with torch.no_grad():
+            data, mask = self._prep_inputs(data, miss_list)
+            B = data.shape[0]
+            self._ensure_device_state(B)
+            self._run_forward(data, mask, None, B, want_params=True)      # eps = None -> z = mu
+            mu, lv, z, lpx, lpm = self._clone_outputs(B)
+            p_params = {"x": self._p_params(B)}
+            p_samples = {"x": self._p_samples(p_params["x"], B) if self.materialize_samples else None}
+        return {"s": None, "z": z}, {"s": None, "z": [mu, lv]}, p_samples, p_params, lpx, lpm

@@ -1,0 +1,100 @@
+"""ctypes binding of libhlvae_hip.so (C ABI declared in include/hlvae_hip.h).
+
+There is no CPU fallback: if the shared library is missing the first use raises, and every
+non-zero return code of the library becomes a Python exception (the reference's errors are
+Python exceptions too)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
+ABI_VERSION = 1
+
+_vp = C.c_void_p
+
+
+class HlvaeVar(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "ncls", "xoff", "sidx", "w_off", "b_off", "e_off", "pad")]
+
+
+class HlvaeDims(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("D", "X", "y_dim", "h_e", "h_d", "L", "n_real", "n_pos",
+                                            "Xp", "hep", "hdp", "Lp", "NY", "NYp", "n_stat")]
+                + [(n, C.c_int64) for n in ("o_w1", "o_b1", "o_wmu", "o_bmu", "o_wlv", "o_blv", "o_wd", "o_bd",
+                                            "o_wy", "o_by", "arena_size", "atomic_region")])
+
+
+WS_POINTERS = ("P", "G", "w1s", "wmls", "wmlTs", "wds", "wdTs", "wys", "wyTs", "sums", "norm", "xn", "xnT", "xt", "m8",
+               "slab", "t", "tT", "mu", "lv", "z", "zb", "zbT", "u", "uT", "dy", "dyT", "log_p_x", "log_p_x_missing",
+               "rowpart", "nll", "scal", "pfull", "xhat", "du", "duT", "dz", "dml", "dmlT", "dt", "dtT")
+
+
+class HlvaeWs(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("Bp_max", "splitk_enc", "splitk_dec")] + [(n, _vp) for n in WS_POINTERS])
+
+
+class HlvaeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "hlvae_abi_version": (C.c_int, []),
+    "hlvae_last_error": (C.c_char_p, []),
+    "hlvae_struct_sizes": (None, [C.POINTER(C.c_int32)] * 3),
+    "hlvae_dims_fill": (None, [C.POINTER(HlvaeDims)]),
+    "hlvae_plan_create": (C.c_int, [C.POINTER(_vp), C.POINTER(HlvaeDims), C.POINTER(HlvaeVar)]),
+    "hlvae_plan_destroy": (None, [_vp]),
+    "hlvae_refresh_shadows": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp]),
+    "hlvae_normalize_stats": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_int, _vp]),
+    "hlvae_normalize_pack": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_int, _vp]),
+    "hlvae_encoder_fwd": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, _vp]),
+    "hlvae_decoder_fwd": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_float, C.c_int, C.c_int, C.c_int, _vp]),
+    "hlvae_scale_dy": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, _vp]),
+    "hlvae_backward": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_int, _vp]),
+    "hlvae_zero_grad": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp]),
+    "hlvae_kl_std_normal": (C.c_int, [C.POINTER(HlvaeWs), C.c_int, C.c_int, C.c_float, _vp, _vp, _vp]),
+    "hlvae_adam_step": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, _vp]),
+    "hlvae_gemm_nt_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def load():
+    """dlopen the in-tree library once; verify ABI version and struct layout."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HlvaeError(f"{LIB_PATH} not found: build it with `make -C hl-vae_amd/csrc` "
+                         "(or __graft_entry__.build()); there is no CPU fallback for the HIP path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hlvae_abi_version() != ABI_VERSION:
+        raise HlvaeError(f"ABI version mismatch: library {lib.hlvae_abi_version()} vs binding {ABI_VERSION}")
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    lib.hlvae_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
+    if (a.value, b.value, c.value) != (C.sizeof(HlvaeDims), C.sizeof(HlvaeVar), C.sizeof(HlvaeWs)):
+        raise HlvaeError("struct layout mismatch between include/hlvae_hip.h and hl-vae_amd/_lib.py: "
+                         f"{(a.value, b.value, c.value)} vs {(C.sizeof(HlvaeDims), C.sizeof(HlvaeVar), C.sizeof(HlvaeWs))}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().hlvae_last_error()
+        raise HlvaeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    return None if t is None else _vp(t.data_ptr())

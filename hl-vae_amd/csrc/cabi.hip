@@ -1,0 +1,217 @@
+// extern "C" boundary of libhlvae_hip.so (include/hlvae_hip.h): argument validation against what the
+// kernels' grids assume, then stream-ordered launches.  No allocation of caller memory, no device sync.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "common.h"
+
+// launchers implemented next to their kernels
+int hl_launch_gemm_f32(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, int, float*, hipStream_t);
+int hl_launch_gemm_splitk(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, hipStream_t);
+int hl_launch_reduce_act(int, const float*, int, int, int, const float*, int, const bf16_t*, bf16_t*, bf16_t*, int, int,
+                         float*, hipStream_t);
+int hl_launch_gemm_act(int, const bf16_t*, int, const bf16_t*, int, int, int, int, const float*, int, const bf16_t*,
+                       bf16_t*, int, bf16_t*, int, int, float*, hipStream_t);
+int hl_launch_mid_fwd(int, const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, float*,
+                      float*, float*, bf16_t*, bf16_t*, int, int, int, hipStream_t);
+int hl_launch_mid_bwd(int, const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*,
+                      const float*, float*, bf16_t*, bf16_t*, int, int, int, float*, float*, hipStream_t);
+int hl_launch_y_heads(const hlvae_plan*, const hlvae_ws*, const float*, float, int, int, int, int, hipStream_t);
+int hl_launch_scale_dy(const hlvae_plan*, const hlvae_ws*, const float*, int, int, hipStream_t);
+int hl_launch_stats(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, hipStream_t);
+int hl_launch_pack(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, int, hipStream_t);
+int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
+int hl_adam(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t);
+int hl_launch_kl_std(const hlvae_ws*, int, int, float, float*, float*, hipStream_t);
+
+static thread_local char g_err[512] = "";
+void hl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int padded_batch(int B) { return ru(B, 128); }
+
+extern "C" {
+
+int hlvae_abi_version(void) { return HLVAE_ABI_VERSION; }
+const char* hlvae_last_error(void) { return g_err; }
+void hlvae_struct_sizes(int32_t* dims_bytes, int32_t* var_bytes, int32_t* ws_bytes) {
+    if (dims_bytes) *dims_bytes = (int32_t)sizeof(hlvae_dims);
+    if (var_bytes) *var_bytes = (int32_t)sizeof(hlvae_var);
+    if (ws_bytes) *ws_bytes = (int32_t)sizeof(hlvae_ws);
+}
+
+void hlvae_dims_fill(hlvae_dims* d) {
+    d->Xp = ru(d->X, 64);
+    d->hep = ru(d->h_e, 64);
+    d->hdp = ru(d->h_d, 64);
+    d->Lp = ru(d->L, 32);
+    d->NY = d->D * d->y_dim;
+    d->NYp = ru(d->NY, 64);
+    d->n_stat = d->n_real + d->n_pos;
+}
+
+int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var* vars) {
+    HL_REQUIRE(out && dims && vars, HLVAE_EINVAL, "plan_create: null argument");
+    hlvae_dims d = *dims;
+    hlvae_dims_fill(&d);
+    HL_REQUIRE(d.D > 0 && d.X >= d.D && d.h_e > 0 && d.h_d > 0 && d.L > 0, HLVAE_EINVAL, "plan_create: bad dims");
+    HL_REQUIRE(d.y_dim == 5, HLVAE_EINVAL, "plan_create: y_dim=%d, only 5 is instantiated", d.y_dim);
+    HL_REQUIRE(d.Lp <= 64, HLVAE_EINVAL, "plan_create: latent_dim=%d > 64 unsupported", d.L);
+    HL_REQUIRE(d.arena_size % 4 == 0, HLVAE_EINVAL, "plan_create: arena_size must be a multiple of 4 floats");
+    std::vector<int32_t> col2var(d.Xp, -1), stat_var(d.n_stat > 0 ? d.n_stat : 1, 0);
+    int x = 0, nstat_seen = 0;
+    for (int i = 0; i < d.D; ++i) {
+        const hlvae_var& v = vars[i];
+        HL_REQUIRE(v.kind >= HLVAE_REAL && v.kind <= HLVAE_ORDINAL, HLVAE_EINVAL, "variable %d: kind %d", i, v.kind);
+        const bool disc = v.kind == HLVAE_CAT || v.kind == HLVAE_ORDINAL;
+        HL_REQUIRE(disc ? (v.ncls >= 2 && v.ncls <= 8) : v.ncls == 1, HLVAE_EINVAL,
+                   "variable %d: nclass %d unsupported (cat/ordinal: 2..8)", i, v.ncls);
+        HL_REQUIRE(v.xoff == x, HLVAE_EINVAL, "variable %d: xoff %d, expected %d", i, v.xoff, x);
+        HL_REQUIRE(v.w_off >= 0 && v.b_off >= 0 && v.w_off < d.atomic_region && v.b_off < d.atomic_region,
+                   HLVAE_EINVAL, "variable %d: head offsets outside the atomic gradient region", i);
+        if (v.kind == HLVAE_REAL || v.kind == HLVAE_POS) {
+            HL_REQUIRE(v.sidx >= 0 && v.sidx < d.n_stat && v.e_off >= 0, HLVAE_EINVAL, "variable %d: sidx/e_off", i);
+            stat_var[v.sidx] = i;
+            ++nstat_seen;
+        }
+        if (v.kind == HLVAE_ORDINAL) HL_REQUIRE(v.e_off >= 0, HLVAE_EINVAL, "variable %d: thresholds offset", i);
+        for (int k = 0; k < v.ncls; ++k) col2var[x + k] = i;
+        x += v.ncls;
+    }
+    HL_REQUIRE(x == d.X, HLVAE_EINVAL, "plan_create: variables cover %d columns, X=%d", x, d.X);
+    HL_REQUIRE(nstat_seen == d.n_stat, HLVAE_EINVAL, "plan_create: %d statistic rows, n_stat=%d", nstat_seen, d.n_stat);
+    hlvae_plan* p = new hlvae_plan();
+    p->d = d;
+    p->vars_dev = nullptr; p->col2var_dev = nullptr; p->stat_var_dev = nullptr;
+    hipError_t e = hipMalloc(&p->vars_dev, sizeof(hlvae_var) * d.D);
+    if (e == hipSuccess) e = hipMalloc(&p->col2var_dev, sizeof(int32_t) * d.Xp);
+    if (e == hipSuccess) e = hipMalloc(&p->stat_var_dev, sizeof(int32_t) * stat_var.size());
+    if (e == hipSuccess) e = hipMemcpy(p->vars_dev, vars, sizeof(hlvae_var) * d.D, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->col2var_dev, col2var.data(), sizeof(int32_t) * d.Xp, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->stat_var_dev, stat_var.data(), sizeof(int32_t) * stat_var.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hl_set_error("plan_create: %s", hipGetErrorString(e));
+        hlvae_plan_destroy(p);
+        return (int)e;
+    }
+    *out = p;
+    return 0;
+}
+
+void hlvae_plan_destroy(hlvae_plan* p) {
+    if (!p) return;
+    if (p->vars_dev) (void)hipFree(p->vars_dev);
+    if (p->col2var_dev) (void)hipFree(p->col2var_dev);
+    if (p->stat_var_dev) (void)hipFree(p->stat_var_dev);
+    delete p;
+}
+
+#define CHECK_B()                                                                                         \
+    HL_REQUIRE(p && ws, HLVAE_EINVAL, "null plan/workspace");                                              \
+    HL_REQUIRE(B > 0 && padded_batch(B) <= ws->Bp_max, HLVAE_ESHAPE, "batch %d exceeds workspace (Bp_max=%d)", B, ws->Bp_max); \
+    const int Bp = padded_batch(B);                                                                       \
+    const hlvae_dims& d = p->d;                                                                            \
+    hipStream_t st = (hipStream_t)s;                                                                       \
+    (void)d; (void)Bp; (void)st
+
+int hlvae_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s) {
+    HL_REQUIRE(p && ws, HLVAE_EINVAL, "null plan/workspace");
+    return hl_refresh_shadows(p, ws, (hipStream_t)s);
+}
+
+int hlvae_normalize_stats(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask, int B,
+                          hlvae_stream s) {
+    CHECK_B();
+    return hl_launch_stats(p, ws, data, mask, B, st);
+}
+
+int hlvae_normalize_pack(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask, int B,
+                         hlvae_stream s) {
+    CHECK_B();
+    return hl_launch_pack(p, ws, data, mask, B, Bp, st);
+}
+
+int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int B, hlvae_stream s) {
+    CHECK_B();
+    int rc;
+    HL_REQUIRE(ws->splitk_enc >= 1, HLVAE_EINVAL, "splitk_enc");
+    // trunk: T = relu(Xn W1^T + b1)   (HLVAE.py:316-317, evaluated once)
+    if ((rc = hl_launch_gemm_splitk(ws->xn, d.Xp, ws->w1s, d.Xp, ws->slab, d.hep, Bp, d.hep, d.Xp, ws->splitk_enc, st))) return rc;
+    if ((rc = hl_launch_reduce_act(0, ws->slab, ws->splitk_enc, Bp, d.hep, ws->P + d.o_b1, d.h_e, nullptr, ws->t, ws->tT,
+                                   Bp, B, nullptr, st))) return rc;
+    // mean / log-var heads + clamp + reparameterisation
+    return hl_launch_mid_fwd(d.Lp, ws->t, d.hep, ws->wmls, d.hep, ws->P + d.o_bmu, ws->P + d.o_blv, eps, ws->mu, ws->lv,
+                             ws->z, ws->zb, ws->zbT, Bp, B, d.L, st);
+}
+
+int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, float g_scale, int want_grad,
+                      int want_params, int B, hlvae_stream s) {
+    CHECK_B();
+    int rc;
+    // U = relu(z Wd^T + bd)   (HLVAE.py:336)
+    if ((rc = hl_launch_gemm_act(0, ws->zb, d.Lp, ws->wds, d.Lp, Bp, d.hdp, d.Lp, ws->P + d.o_bd, d.h_d, nullptr, ws->u,
+                                 d.hdp, ws->uT, Bp, B, nullptr, st))) return rc;
+    return hl_launch_y_heads(p, ws, g_logpx, g_scale, want_grad, want_params, B, Bp, st);
+}
+
+int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, int B, hlvae_stream s) {
+    CHECK_B();
+    HL_REQUIRE(g_logpx, HLVAE_EINVAL, "scale_dy: null gradient");
+    return hl_launch_scale_dy(p, ws, g_logpx, B, Bp, st);
+}
+
+int hlvae_zero_grad(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s) {
+    HL_REQUIRE(p && ws, HLVAE_EINVAL, "null plan/workspace");
+    HL_CHECK(hipMemsetAsync(ws->G, 0, sizeof(float) * p->d.atomic_region, (hipStream_t)s));
+    return 0;
+}
+
+int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, const float* g_mu, const float* g_lv,
+                   int B, hlvae_stream s) {
+    CHECK_B();
+    int rc;
+    HL_REQUIRE(ws->splitk_dec >= 1, HLVAE_EINVAL, "splitk_dec");
+    // d Wy = dY^T U                                  [NY][h_d]
+    if ((rc = hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, st))) return rc;
+    // d U = (dY Wy) * relu'(U); d bd
+    if ((rc = hl_launch_gemm_splitk(ws->dy, d.NYp, ws->wyTs, d.NYp, ws->slab, d.hdp, Bp, d.hdp, d.NYp, ws->splitk_dec, st))) return rc;
+    if ((rc = hl_launch_reduce_act(1, ws->slab, ws->splitk_dec, Bp, d.hdp, nullptr, d.h_d, ws->u, ws->du, ws->duT, Bp, B,
+                                   ws->G + d.o_bd, st))) return rc;
+    // d Wd = dU^T z                                  [h_d][L]
+    if ((rc = hl_launch_gemm_f32(ws->duT, Bp, ws->zbT, Bp, ws->G + d.o_wd, d.L, d.h_d, d.L, Bp, 0, 0, nullptr, st))) return rc;
+    // d z -> d mu, d log_var (clamp + reparameterisation backward); d bmu, d blv
+    if ((rc = hl_launch_mid_bwd(d.Lp, ws->du, d.hdp, ws->wdTs, d.hdp, eps, ws->lv, g_mu, g_lv, ws->dz, ws->dml, ws->dmlT,
+                                Bp, B, d.L, ws->G + d.o_bmu, ws->G + d.o_blv, st))) return rc;
+    // d [Wmu; Wlv] = dml^T T                         2 x [L][h_e]
+    if ((rc = hl_launch_gemm_f32(ws->dmlT, Bp, ws->tT, Bp, ws->G + d.o_wmu, d.h_e, 2 * d.Lp, d.h_e, Bp, d.Lp, d.L,
+                                 ws->G + d.o_wlv, st))) return rc;
+    // d T = (dml [Wmu; Wlv]) * relu'(T); d b1
+    if ((rc = hl_launch_gemm_act(1, ws->dml, 2 * d.Lp, ws->wmlTs, 2 * d.Lp, Bp, d.hep, 2 * d.Lp, nullptr, d.h_e, ws->t,
+                                 ws->dt, d.hep, ws->dtT, Bp, B, ws->G + d.o_b1, st))) return rc;
+    // d W1 = dT^T Xn                                 [h_e][X]   (no input gradient for layer 1)
+    return hl_launch_gemm_f32(ws->dtT, Bp, ws->xnT, Bp, ws->G + d.o_w1, d.X, d.h_e, d.X, Bp, 0, 0, nullptr, st);
+}
+
+int hlvae_kl_std_normal(const hlvae_ws* ws, int B, int L, float weight, float* g_mu, float* g_lv, hlvae_stream s) {
+    HL_REQUIRE(ws && B > 0 && L > 0, HLVAE_EINVAL, "kl_std_normal: bad arguments");
+    return hl_launch_kl_std(ws, B, L, weight, g_mu, g_lv, (hipStream_t)s);
+}
+
+int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr,
+                    float beta1, float beta2, float eps, float grad_scale, hlvae_stream s) {
+    HL_REQUIRE(p && ws && m1 && m2 && step_count, HLVAE_EINVAL, "adam_step: null argument");
+    return hl_adam(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, (hipStream_t)s);
+}
+
+int hlvae_gemm_nt_f32(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc, int M, int N, int K,
+                      hlvae_stream s) {
+    HL_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, HLVAE_EINVAL, "gemm: bad arguments");
+    return hl_launch_gemm_f32(A, lda, B, ldb, C, ldc, M, N, K, 0, 0, nullptr, (hipStream_t)s);
+}
+
+}  // extern "C"

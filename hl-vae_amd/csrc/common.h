@@ -1,0 +1,57 @@
+// Shared device helpers for the gfx950 HL-VAE kernels (wave = 64 lanes, hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hlvae_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // one 16x16 accumulator fragment
+typedef uint16_t bf16_t;                                        // storage type of bf16 buffers
+
+#define HL_THREADS 256
+#define HL_WAVE 64
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 h = (__bf16)f;   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// torch.nn.functional.softplus (beta = 1, threshold = 20)
+__device__ __forceinline__ float softplus_f(float t) { return t > 20.f ? t : log1pf(__expf(t)); }
+__device__ __forceinline__ float sigmoid_f(float t) { return 1.f / (1.f + __expf(-t)); }
+
+static inline int ru(int v, int m) { return (v + m - 1) / m * m; }
+
+struct hlvae_plan {
+    hlvae_dims d;
+    hlvae_var* vars_dev;      // [D]
+    int32_t* col2var_dev;     // [Xp]  variable of an expanded column, -1 in the padding
+    int32_t* stat_var_dev;    // [n_stat] variable index of each statistics row
+};
+
+void hl_set_error(const char* fmt, ...);
+#define HL_CHECK(expr)                                                            \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            hl_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (int)_e;                                                       \
+        }                                                                         \
+    } while (0)
+#define HL_LAUNCH_CHECK() HL_CHECK(hipGetLastError())
+#define HL_REQUIRE(cond, code, ...)                                               \
+    do {                                                                          \
+        if (!(cond)) { hl_set_error(__VA_ARGS__); return (code); }                \
+    } while (0)

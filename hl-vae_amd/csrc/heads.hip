@@ -1,0 +1,588 @@
+// y_layer GEMM fused with the per-type heads, the five log-likelihoods, the ELBO row sums and the
+// backward of all of them (SURVEY.md section 8(a) rows D tail, E, F, G, H, I-cat, I-ord, J, M).
+//
+// Tile = BM batch rows x 16 variables (= 16*YD columns of Y = U * Wy^T + by, column d*YD + k is
+// feature k of variable d: the reshape of HLVAE.py:343).  The fp32 accumulator tile is staged in
+// LDS; thread (v = tid & 15, rg = tid >> 4) then owns variable v of the tile for rows rg, rg+16, ...
+// so the type of a variable is a per-thread constant, its head weights live in registers, and
+// mixed-type columns cost no gather/scatter (the reference walks boolean masks per type block,
+// HLVAE.py:387-412, 422-452).  Y itself is never written to HBM: the tile is overwritten in LDS by
+// g * d log_p_x / d Y and leaves as bf16 in both layouts for the two backward GEMMs.
+//
+// Stop-gradient through missing entries (HLVAE.py:435-452): theta = head(y) everywhere, gradient
+// only where the mask is 1 -> dY and all head-parameter gradients are gated by the mask.
+#include "gemm_nt.h"
+
+#define HL_LOG2PI 1.8378770664093453f
+
+template <int YD, int KM>
+struct HeadAcc {
+    static constexpr int N = (YD + 1) * (KM - 1) > (YD + KM) ? (YD + 1) * (KM - 1) : (YD + KM);
+};
+
+struct RowIO {
+    const float* Cs;   // set per call
+};
+
+// ---- real / pos:  HL_VAE/loglik.py:27-70 and :73-121 -------------------------------------------
+template <int YD, int BM, int CLD, int NACC>
+__device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int rg, int m0, int B, int D, int d,
+                                             const hlvae_var& var, const float* __restrict__ P,
+                                             const float* __restrict__ norm, int n_stat, const float (&byv)[YD],
+                                             const float* __restrict__ xt, const uint8_t* __restrict__ m8,
+                                             const float* __restrict__ g_elem, float g_scale,
+                                             float* __restrict__ logpx, float* __restrict__ logpx_miss,
+                                             float* __restrict__ pfull, int X, float* __restrict__ xhat,
+                                             float (&acc)[NACC], float (&lpo)[BM / 16]) {
+    float w[YD];
+#pragma unroll
+    for (int k = 0; k < YD; ++k) w[k] = P[var.w_off + k];
+    const float b = P[var.b_off];
+    const float p = P[var.e_off];
+    const float mean_d = norm[var.sidx];
+    float vd = norm[n_stat + var.sidx];
+    float ev, dp_fac;
+    if (!is_pos) {
+        vd = fmaxf(vd, 3e-4f);                                   // loglik.py:38
+        const float lvy = -8.f + softplus_f(p + 8.f);            // :51
+        ev = vd * __expf(lvy);                                   // :52,56
+        dp_fac = sigmoid_f(p + 8.f);
+    } else {
+        vd = fmaxf(vd, 1e-3f);                                   // :80
+        ev = vd * __expf(p);                                     // :100
+        dp_fac = 1.f;
+    }
+    const float sd = sqrtf(vd);
+    const float inv_ev = 1.f / ev;
+    const float c0 = -0.5f * HL_LOG2PI - 0.5f * __logf(ev);
+    const float pos_var = is_pos ? __expf(p) : 0.f;              // read_functions.py:285
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+        const int r = rg + 16 * i, gr = m0 + r;
+        float* yrow = Cs + r * CLD + v * YD;
+        float th = b;
+        float y[YD];
+#pragma unroll
+        for (int k = 0; k < YD; ++k) {
+            y[k] = yrow[k] + byv[k];
+            th += w[k] * y[k];
+        }
+        float lp_obs = 0.f, dth = 0.f;
+        if (gr < B) {
+            const size_t o = (size_t)gr * D + d;
+            const float x = xt[o];                               // raw x (real) or log1p x (pos)
+            const bool ob = m8[o] != 0;
+            const float mean = sd * th + mean_d;                 // :55 / :96
+            const float rr = x - mean;
+            float lp = -0.5f * rr * rr * inv_ev + c0;            // :58 / :102
+            if (is_pos) lp -= x;
+            logpx[o] = ob ? lp : 0.f;
+            logpx_miss[o] = ob ? 0.f : lp;
+            if (ob) {
+                const float g = g_elem != nullptr ? g_elem[o] : g_scale;
+                lp_obs = lp;
+                dth = g * rr * inv_ev * sd;
+                acc[YD + 1] += g * (0.5f * rr * rr * inv_ev - 0.5f) * dp_fac;
+            }
+            if (pfull != nullptr) {
+                pfull[(size_t)gr * X + var.xoff] = mean;         // loglik.py:64-67 (mean only)
+                xhat[o] = is_pos ? __expf(mean + 0.5f * pos_var) - 1.f : mean;   // read_functions.py:277,288
+            }
+        }
+        lpo[i] = lp_obs;
+        acc[YD] += dth;
+#pragma unroll
+        for (int k = 0; k < YD; ++k) {
+            acc[k] += dth * y[k];
+            yrow[k] = dth * w[k];
+        }
+    }
+}
+
+// ---- count:  HL_VAE/loglik.py:191-213 ------------------------------------------------------------
+template <int YD, int BM, int CLD, int NACC>
+__device__ __forceinline__ void proc_count(float* Cs, int v, int rg, int m0, int B, int D, int d, const hlvae_var& var,
+                                           const float* __restrict__ P, const float (&byv)[YD],
+                                           const float* __restrict__ xt, const uint8_t* __restrict__ m8,
+                                           const float* __restrict__ g_elem, float g_scale, float* __restrict__ logpx,
+                                           float* __restrict__ logpx_miss, float* __restrict__ pfull, int X,
+                                           float* __restrict__ xhat, float (&acc)[NACC], float (&lpo)[BM / 16]) {
+    float w[YD];
+#pragma unroll
+    for (int k = 0; k < YD; ++k) w[k] = P[var.w_off + k];
+    const float b = P[var.b_off];
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+        const int r = rg + 16 * i, gr = m0 + r;
+        float* yrow = Cs + r * CLD + v * YD;
+        float th = b;
+        float y[YD];
+#pragma unroll
+        for (int k = 0; k < YD; ++k) {
+            y[k] = yrow[k] + byv[k];
+            th += w[k] * y[k];
+        }
+        float lp_obs = 0.f, dth = 0.f;
+        if (gr < B) {
+            const size_t o = (size_t)gr * D + d;
+            const float x = xt[o];
+            const bool ob = m8[o] != 0;
+            const float sp = softplus_f(th);
+            const float lam = fminf(fmaxf(sp, 1e-6f), 1e20f);    // :203
+            const float lp = x * __logf(lam) - lam - lgammaf(x + 1.f);   // Poisson.log_prob
+            logpx[o] = ob ? lp : 0.f;
+            logpx_miss[o] = ob ? 0.f : lp;
+            if (ob) {
+                const float g = g_elem != nullptr ? g_elem[o] : g_scale;
+                lp_obs = lp;
+                if (sp >= 1e-6f && sp <= 1e20f) dth = g * (x / lam - 1.f) * sigmoid_f(th);
+            }
+            if (pfull != nullptr) {
+                pfull[(size_t)gr * X + var.xoff] = lam;
+                xhat[o] = lam;                                   // read_functions.py:294
+            }
+        }
+        lpo[i] = lp_obs;
+        acc[YD] += dth;
+#pragma unroll
+        for (int k = 0; k < YD; ++k) {
+            acc[k] += dth * y[k];
+            yrow[k] = dth * w[k];
+        }
+    }
+}
+
+// ---- categorical:  Observation_Cat (HLVAE.py:54-68) + loglik_cat (loglik.py:124-146) -------------
+// theta_0 = 0, theta_j = b_j + sum_k W[k][j-1] y_k.  accumulators: gW at k*(KM-1)+(j-1), gb at YD*(KM-1)+(j-1)
+template <int YD, int BM, int CLD, int NACC, int KM>
+__device__ __forceinline__ void proc_cat(float* Cs, int v, int rg, int m0, int B, int D, int d, const hlvae_var& var,
+                                         const float* __restrict__ P, const float (&byv)[YD],
+                                         const float* __restrict__ xt, const uint8_t* __restrict__ m8,
+                                         const float* __restrict__ g_elem, float g_scale, float* __restrict__ logpx,
+                                         float* __restrict__ logpx_miss, float* __restrict__ pfull, int X,
+                                         float* __restrict__ xhat, float (&acc)[NACC], float (&lpo)[BM / 16]) {
+    const int K = var.ncls;
+    float W[YD][KM - 1], bb[KM - 1];
+#pragma unroll
+    for (int j = 0; j < KM - 1; ++j) {
+        bb[j] = j < K - 1 ? P[var.b_off + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < YD; ++k) W[k][j] = j < K - 1 ? P[var.w_off + k * (K - 1) + j] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+        const int r = rg + 16 * i, gr = m0 + r;
+        float* yrow = Cs + r * CLD + v * YD;
+        float y[YD], th[KM - 1];
+#pragma unroll
+        for (int k = 0; k < YD; ++k) y[k] = yrow[k] + byv[k];
+        float mx = 0.f;                                          // theta_0 = 0 (HLVAE.py:66-67)
+#pragma unroll
+        for (int j = 0; j < KM - 1; ++j) {
+            float t = bb[j];
+#pragma unroll
+            for (int k = 0; k < YD; ++k) t += W[k][j] * y[k];
+            th[j] = t;
+            if (j < K - 1) mx = fmaxf(mx, t);
+        }
+        float se = __expf(-mx);
+#pragma unroll
+        for (int j = 0; j < KM - 1; ++j)
+            if (j < K - 1) se += __expf(th[j] - mx);
+        const float lse = mx + __logf(se);                       // loglik.py:134
+        float dth[KM - 1];
+#pragma unroll
+        for (int j = 0; j < KM - 1; ++j) dth[j] = 0.f;
+        float lp_obs = 0.f;
+        if (gr < B) {
+            const size_t o = (size_t)gr * D + d;
+            const int cls = (int)xt[o];                          // -1: all-zero one-hot row
+            const bool ob = m8[o] != 0;
+            float lp = 0.f;
+            if (cls == 0) lp = -lse;
+#pragma unroll
+            for (int j = 0; j < KM - 1; ++j)
+                if (cls == j + 1) lp = th[j] - lse;              // :135 (one-hot data)
+            logpx[o] = ob ? lp : 0.f;
+            logpx_miss[o] = ob ? 0.f : lp;
+            if (ob && cls >= 0) {
+                const float g = g_elem != nullptr ? g_elem[o] : g_scale;
+                lp_obs = lp;
+#pragma unroll
+                for (int j = 0; j < KM - 1; ++j)
+                    if (j < K - 1) dth[j] = g * ((cls == j + 1 ? 1.f : 0.f) - __expf(th[j] - lse));
+            } else if (ob) {
+                lp_obs = lp;
+            }
+            if (pfull != nullptr) {
+                float* pf = pfull + (size_t)gr * X + var.xoff;
+                pf[0] = -lse;                                    // params = normalised log_pi (:139)
+                int am = 0;
+                float best = 0.f;
+#pragma unroll
+                for (int j = 0; j < KM - 1; ++j)
+                    if (j < K - 1) {
+                        pf[j + 1] = th[j] - lse;
+                        if (th[j] > best) { best = th[j]; am = j + 1; }
+                    }
+                xhat[o] = (float)am;                             // read_functions.py:297-299 (first max)
+            }
+        }
+        lpo[i] = lp_obs;
+        float dy[YD];
+#pragma unroll
+        for (int k = 0; k < YD; ++k) dy[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KM - 1; ++j) {
+            acc[YD * (KM - 1) + j] += dth[j];
+#pragma unroll
+            for (int k = 0; k < YD; ++k) {
+                acc[k * (KM - 1) + j] += dth[j] * y[k];
+                dy[k] += dth[j] * W[k][j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < YD; ++k) yrow[k] = dy[k];
+    }
+}
+
+// ---- ordinal:  Observation_Ordinal (HLVAE.py:70-89) + loglik_ordinal (loglik.py:149-188) ---------
+// accumulators: gw[k] at k, gb at YD, g_thresholds[j] at YD+1+j
+template <int YD, int BM, int CLD, int NACC, int KM>
+__device__ __forceinline__ void proc_ord(float* Cs, int v, int rg, int m0, int B, int D, int d, const hlvae_var& var,
+                                         const float* __restrict__ P, const float (&byv)[YD],
+                                         const float* __restrict__ xt, const uint8_t* __restrict__ m8,
+                                         const float* __restrict__ g_elem, float g_scale, float* __restrict__ logpx,
+                                         float* __restrict__ logpx_miss, float* __restrict__ pfull, int X,
+                                         float* __restrict__ xhat, float (&acc)[NACC], float (&lpo)[BM / 16]) {
+    const int K = var.ncls;
+    float w[YD];
+#pragma unroll
+    for (int k = 0; k < YD; ++k) w[k] = P[var.w_off + k];
+    const float b = P[var.b_off];
+    float thr[KM - 1], dthr_fac[KM - 1];                         // cumulative thresholds are row-independent
+    {
+        float cs = 0.f;
+#pragma unroll
+        for (int j = 0; j < KM - 1; ++j) {
+            float a = 0.f, f = 0.f;
+            if (j < K - 1) {
+                const float t = P[var.e_off + j];
+                const float sp = softplus_f(t);
+                a = fminf(fmaxf(sp, 1e-6f), 1e20f);              // loglik.py:164
+                f = (sp >= 1e-6f && sp <= 1e20f) ? sigmoid_f(t) : 0.f;
+            }
+            cs += a;
+            thr[j] = cs;
+            dthr_fac[j] = f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+        const int r = rg + 16 * i, gr = m0 + r;
+        float* yrow = Cs + r * CLD + v * YD;
+        float y[YD];
+        float reg = b;
+#pragma unroll
+        for (int k = 0; k < YD; ++k) {
+            y[k] = yrow[k] + byv[k];
+            reg += w[k] * y[k];
+        }
+        const float mv = softplus_f(reg);                        // :163
+        float sg[KM - 1];
+#pragma unroll
+        for (int j = 0; j < KM - 1; ++j) sg[j] = j < K - 1 ? sigmoid_f(thr[j] - mv) : 1.f;   // :165
+        float pc[KM];                                            // clamped class probabilities (:166-169)
+        bool pass[KM];
+        float S = 0.f;
+#pragma unroll
+        for (int c = 0; c < KM; ++c) {
+            float pr = 0.f;
+            if (c < K) {
+                const float hi = (c < K - 1) ? sg[c < KM - 1 ? c : KM - 2] : 1.f;
+                const float lo = (c > 0) ? sg[c - 1 >= 0 ? c - 1 : 0] : 0.f;
+                pr = hi - lo;
+            }
+            pass[c] = (c < K) && pr >= 1e-6f && pr <= 1.f;
+            pc[c] = c < K ? fminf(fmaxf(pr, 1e-6f), 1.f) : 0.f;
+            S += pc[c];
+        }
+        const float invS = 1.f / S;
+        float dreg = 0.f, lp_obs = 0.f;
+        float du[KM - 1];
+#pragma unroll
+        for (int j = 0; j < KM - 1; ++j) du[j] = 0.f;
+        if (gr < B) {
+            const size_t o = (size_t)gr * D + d;
+            const bool ob = m8[o] != 0;
+            int cls = ob ? (int)xt[o] : 0;                       // :172-174 (masked rows -> class 0)
+            cls = cls < 0 ? 0 : (cls > K - 1 ? K - 1 : cls);
+            float pcc = pc[0];
+#pragma unroll
+            for (int c = 1; c < KM; ++c)
+                if (cls == c) pcc = pc[c];
+            const float lp = __logf(pcc * invS);                 // :178-179
+            logpx[o] = ob ? lp : 0.f;
+            logpx_miss[o] = ob ? 0.f : lp;
+            if (ob) {
+                const float g = g_elem != nullptr ? g_elem[o] : g_scale;
+                lp_obs = lp;
+                float dp[KM];
+#pragma unroll
+                for (int c = 0; c < KM; ++c)
+                    dp[c] = pass[c] ? g * ((cls == c ? 1.f / pcc : 0.f) - invS) : 0.f;
+                float dmv = 0.f;
+#pragma unroll
+                for (int j = 0; j < KM - 1; ++j)
+                    if (j < K - 1) {
+                        const float ds = dp[j] - dp[j + 1];      // s_j enters p_j (+) and p_{j+1} (-)
+                        du[j] = ds * sg[j] * (1.f - sg[j]);
+                        dmv -= du[j];
+                    }
+                dreg = dmv * sigmoid_f(reg);
+            }
+            if (pfull != nullptr) {
+                float* pf = pfull + (size_t)gr * X + var.xoff;
+                int am = 0;
+                float best = pc[0];
+#pragma unroll
+                for (int c = 0; c < KM; ++c)
+                    if (c < K) {
+                        pf[c] = pc[c] * invS;                    // params = normalised mean_probs (:183)
+                        if (pc[c] > best) { best = pc[c]; am = c; }
+                    }
+                xhat[o] = (float)am;
+            }
+        }
+        lpo[i] = lp_obs;
+        // d thresholds: thr_j = sum_{i<=j} a_i  ->  d a_i = sum_{j>=i} du_j
+        float run = 0.f;
+#pragma unroll
+        for (int j = KM - 2; j >= 0; --j) {
+            run += du[j];
+            acc[YD + 1 + j] += run * dthr_fac[j];
+        }
+        acc[YD] += dreg;
+#pragma unroll
+        for (int k = 0; k < YD; ++k) {
+            acc[k] += dreg * y[k];
+            yrow[k] = dreg * w[k];
+        }
+    }
+}
+
+// arena offset of accumulator n of a variable (or -1)
+template <int YD>
+__device__ __forceinline__ int acc_dest(const hlvae_var& var, int n) {
+    const int K = var.ncls;
+    switch (var.kind) {
+        case HLVAE_REAL:
+        case HLVAE_POS:
+            return n < YD ? var.w_off + n : (n == YD ? var.b_off : (n == YD + 1 ? var.e_off : -1));
+        case HLVAE_COUNT:
+            return n < YD ? var.w_off + n : (n == YD ? var.b_off : -1);
+        case HLVAE_CAT: {
+            const int KM = K <= 3 ? 3 : (K <= 5 ? 5 : 8);
+            if (n < YD * (KM - 1)) {
+                const int k = n / (KM - 1), j = n % (KM - 1);
+                return j < K - 1 ? var.w_off + k * (K - 1) + j : -1;
+            }
+            const int j = n - YD * (KM - 1);
+            return j < K - 1 ? var.b_off + j : -1;
+        }
+        case HLVAE_ORDINAL:
+            if (n < YD) return var.w_off + n;
+            if (n == YD) return var.b_off;
+            return (n - YD - 1) < K - 1 ? var.e_off + (n - YD - 1) : -1;
+    }
+    return -1;
+}
+
+template <int YD, int BM>
+__global__ __launch_bounds__(HL_THREADS) void k_y_heads(
+    const bf16_t* __restrict__ U, int ldu, const bf16_t* __restrict__ Wy, int K, const hlvae_var* __restrict__ vars,
+    const float* __restrict__ P, float* __restrict__ G, long o_by, const float* __restrict__ norm, int n_stat,
+    const float* __restrict__ xt, const uint8_t* __restrict__ m8, int D, const float* __restrict__ g_elem, float g_scale,
+    bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dyT, int Bp, float* __restrict__ logpx,
+    float* __restrict__ logpx_miss, float* __restrict__ rowpart, float* __restrict__ pfull, int X,
+    float* __restrict__ xhat, int B, int want_grad) {
+    constexpr int BN = 16 * YD;
+    using Gm = GemmNT<BM, BN, 64, 4, 1>;
+    constexpr int CLD = Gm::CLD;
+    constexpr int NACC = HeadAcc<YD, 8>::N;
+    constexpr int RED_BYTES = 4 * 16 * NACC * 4;
+    __shared__ __attribute__((aligned(16))) char smem[Gm::SMEM_BYTES + RED_BYTES];
+    const int tn = blockIdx.x, m0 = blockIdx.y * BM, n0 = tn * BN;
+    const int NY = D * YD;
+    typename Gm::Acc accm;
+    Gm::zero(accm);
+    Gm::run(U, ldu, Wy, ldu, m0, n0, Bp, NY, 0, K, smem, accm);
+    Gm::to_lds(accm, smem);
+    float* Cs = reinterpret_cast<float*>(smem);
+    float* red = reinterpret_cast<float*>(smem + Gm::SMEM_BYTES);
+
+    const int tid = threadIdx.x, v = tid & 15, rg = tid >> 4;
+    const int d = tn * 16 + v;
+    float acc[NACC];
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) acc[n] = 0.f;
+    float lpo[BM / 16];
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) lpo[i] = 0.f;
+    hlvae_var var;
+    var.kind = -1;
+    if (d < D) {
+        var = vars[d];
+        float byv[YD];
+#pragma unroll
+        for (int k = 0; k < YD; ++k) byv[k] = P[o_by + (long)d * YD + k];
+        switch (var.kind) {
+            case HLVAE_REAL:
+                proc_realpos<YD, BM, CLD, NACC>(false, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
+                                                g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo);
+                break;
+            case HLVAE_POS:
+                proc_realpos<YD, BM, CLD, NACC>(true, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
+                                                g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo);
+                break;
+            case HLVAE_COUNT:
+                proc_count<YD, BM, CLD, NACC>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                              logpx_miss, pfull, X, xhat, acc, lpo);
+                break;
+            case HLVAE_CAT:
+                if (var.ncls <= 3)
+                    proc_cat<YD, BM, CLD, NACC, 3>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                else if (var.ncls <= 5)
+                    proc_cat<YD, BM, CLD, NACC, 5>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                else
+                    proc_cat<YD, BM, CLD, NACC, 8>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                break;
+            case HLVAE_ORDINAL:
+                if (var.ncls <= 5)
+                    proc_ord<YD, BM, CLD, NACC, 5>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                else
+                    proc_ord<YD, BM, CLD, NACC, 8>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                break;
+        }
+    } else {   // columns past the last variable: keep the tile clean
+#pragma unroll
+        for (int i = 0; i < BM / 16; ++i)
+#pragma unroll
+            for (int k = 0; k < YD; ++k) Cs[(rg + 16 * i) * CLD + v * YD + k] = 0.f;
+    }
+    // ELBO row sums over the 16 variables of the tile (wavefront shuffles inside the 16-lane group)
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+        float s = lpo[i];
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        const int gr = m0 + rg + 16 * i;
+        if (v == 0 && gr < Bp) rowpart[(size_t)tn * Bp + gr] = gr < B ? s : 0.f;
+    }
+    if (!want_grad) return;
+    // head-parameter gradients: 4 lane groups of a wave share v -> shuffle, then 4 waves through LDS
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+        float a = acc[n];
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        if ((tid & 63) < 16) red[(wave * 16 + v) * NACC + n] = a;
+    }
+    __syncthreads();   // also orders the dY tile writes above
+    for (int idx = tid; idx < 16 * NACC; idx += HL_THREADS) {
+        const int vv = idx / NACC, n = idx % NACC;
+        const int dd = tn * 16 + vv;
+        if (dd >= D) continue;
+        const hlvae_var vr = vars[dd];
+        const int dst = acc_dest<YD>(vr, n);
+        if (dst < 0) continue;
+        const float sum = red[(0 * 16 + vv) * NACC + n] + red[(1 * 16 + vv) * NACC + n] +
+                          red[(2 * 16 + vv) * NACC + n] + red[(3 * 16 + vv) * NACC + n];
+        atomicAdd(G + dst, sum);
+    }
+    // dY tile -> HBM (bf16, both layouts) and d by = column sums
+    for (int idx = tid; idx < BM * BN; idx += HL_THREADS) {
+        const int r = idx / BN, c = idx % BN;
+        if (n0 + c < NY) dy[(size_t)(m0 + r) * lddy + n0 + c] = f2bf(Cs[r * CLD + c]);
+    }
+    for (int idx = tid; idx < BM * BN; idx += HL_THREADS) {
+        const int c = idx / BM, r = idx % BM;
+        if (n0 + c < NY) dyT[(size_t)(n0 + c) * Bp + m0 + r] = f2bf(Cs[r * CLD + c]);
+    }
+    for (int c = tid; c < BN; c += HL_THREADS) {
+        if (n0 + c >= NY) continue;
+        float s = 0.f;
+        for (int r = 0; r < BM; ++r) s += Cs[r * CLD + c];
+        atomicAdd(G + o_by + n0 + c, s);
+    }
+}
+
+// nll[b] = -sum_tiles rowpart[t][b];  scal[0] = sum_b nll[b]   (HLVAE.py:377-379, training.py:104)
+__global__ void k_rowsum(const float* __restrict__ rowpart, int NT, int Bp, int B, float* __restrict__ nll,
+                         double* __restrict__ scal) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    if (b < B)
+        for (int t = 0; t < NT; ++t) s += rowpart[(size_t)t * Bp + b];
+    if (b < Bp) nll[b] = -s;
+    double tot = wave_sum_d((double)(-s));
+    if ((threadIdx.x & 63) == 0) atomicAdd(scal, tot);
+}
+
+// dY *= g[b][d] after the fact (autograd path with a non-uniform upstream gradient)
+__global__ void k_scale_dy(bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dyT, int Bp,
+                           const float* __restrict__ g, int B, int D, int YD) {
+    const int NY = D * YD;
+    const long n = (long)B * NY;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / NY), c = (int)(i % NY);
+        const float s = g[(size_t)b * D + c / YD];
+        const size_t o = (size_t)b * lddy + c;
+        const bf16_t r = f2bf(bf2f(dy[o]) * s);
+        dy[o] = r;
+        dyT[(size_t)c * Bp + b] = r;
+    }
+}
+
+int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_elem, float g_scale, int want_grad,
+                      int want_params, int B, int Bp, hipStream_t s) {
+    const hlvae_dims& d = p->d;
+    HL_REQUIRE(d.y_dim == 5, HLVAE_EINVAL, "y_dim=%d: only y_dim=5 (the reference configuration) is instantiated", d.y_dim);
+    const int NT = (d.D + 15) / 16;
+    float* pf = want_params ? ws->pfull : nullptr;
+    float* xh = want_params ? ws->xhat : nullptr;
+    HL_REQUIRE(!want_params || (ws->pfull && ws->xhat), HLVAE_EINVAL, "want_params without pfull/xhat buffers");
+    if ((long)(Bp / 128) * NT >= 512) {
+        dim3 grid(NT, Bp / 128);
+        k_y_heads<5, 128><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,
+                                                      ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy,
+                                                      d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing, ws->rowpart,
+                                                      pf, d.X, xh, B, want_grad);
+    } else {
+        dim3 grid(NT, Bp / 64);
+        k_y_heads<5, 64><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,
+                                                     ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy,
+                                                     d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing, ws->rowpart,
+                                                     pf, d.X, xh, B, want_grad);
+    }
+    HL_LAUNCH_CHECK();
+    HL_CHECK(hipMemsetAsync(ws->scal, 0, sizeof(double), s));
+    k_rowsum<<<(Bp + 255) / 256, 256, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hl_launch_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g, int B, int Bp, hipStream_t s) {
+    const hlvae_dims& d = p->d;
+    k_scale_dy<<<1024, 256, 0, s>>>(ws->dy, d.NYp, ws->dyT, Bp, g, B, d.D, d.y_dim);
+    HL_LAUNCH_CHECK();
+    return 0;
+}

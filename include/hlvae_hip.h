@@ -1,0 +1,174 @@
+/*
+ * hlvae_hip.h -- C ABI of libhlvae_hip.so: the MI355X (gfx950) HIP kernels of the HL-VAE ELBO
+ * training hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * The reference (MineOgre/HL-VAE) is 19 Python files with NO native/FFI boundary,
+ * so there is no existing FFI to bind.  Each entry point below replaces the Python-level stage of
+ * the reference that is cited next to it (paths relative to the reference repo); the host side
+ * that calls them mirrors the reference's class/function names (hl-vae_amd/HLVAE.py etc.).
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller; nothing here allocates or frees caller
+ *     memory.  The only library-owned device memory is the small per-plan tables.
+ *   - every call is asynchronous on the given hipStream_t (pass torch's current stream);
+ *     no call synchronises the device, so all of them can be captured into a hipGraph.
+ *   - return value 0 = success, otherwise a hipError_t (>0) or a negative HLVAE_E* code;
+ *     hlvae_last_error() returns a human-readable message for the calling thread.
+ *   - bf16 buffers are raw uint16_t.  "p" suffixed sizes are padded sizes, see hlvae_dims.
+ */
+#ifndef HLVAE_HIP_H
+#define HLVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HLVAE_ABI_VERSION 1
+
+#define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define HLVAE_ESHAPE (-2)   /* operand shapes do not match what the kernel grid assumes */
+
+/* variable kinds (column plan, hl-vae_amd/layout.py; reference HL_VAE/loglik.py function names) */
+enum { HLVAE_REAL = 0, HLVAE_POS = 1, HLVAE_COUNT = 2, HLVAE_CAT = 3, HLVAE_ORDINAL = 4 };
+
+/* one row per variable d (reference types_info, HL_VAE/read_functions.py:142-198) */
+typedef struct {
+    int32_t kind;    /* HLVAE_REAL ...                                              */
+    int32_t ncls;    /* K for cat / ordinal, 1 otherwise                             */
+    int32_t xoff;    /* first column in the expanded data / parameter matrix [B, X]  */
+    int32_t sidx;    /* row in the batch-statistic vectors (reals first, then pos)   */
+    int32_t w_off;   /* arena offset of the head weight   [y_dim][a]  (HLVAE.py:14,37,57,74) */
+    int32_t b_off;   /* arena offset of the head bias     [a]                        */
+    int32_t e_off;   /* arena offset of _log_vy_{real,pos}[i] or ordinal thresholds[K-1], -1 if none */
+    int32_t pad;
+} hlvae_var;
+
+/* model geometry.  Padded sizes are derived by hlvae_dims_fill(). */
+typedef struct {
+    int32_t D, X, y_dim, h_e, h_d, L;          /* reference dims = [X, [h_e], L, [h_d], y_dim], D = n_variables */
+    int32_t n_real, n_pos;
+    /* derived */
+    int32_t Xp, hep, hdp, Lp, NY, NYp, n_stat;
+    /* arena offsets (floats) of the dense layers, reference names in comments */
+    int64_t o_w1, o_b1;          /* VAE_encoder_common_layers.0.{weight [h_e,X], bias}   (HLVAE.py:131) */
+    int64_t o_wmu, o_bmu;        /* mean_layer.0        [L,h_e]                           (HLVAE.py:168) */
+    int64_t o_wlv, o_blv;        /* log_var_layer.0     [L,h_e]                           (HLVAE.py:174) */
+    int64_t o_wd, o_bd;          /* hidden.0 / d_layers.0 [h_d,L]                         (HLVAE.py:236) */
+    int64_t o_wy, o_by;          /* y_layer.0           [D*y_dim,h_d]                     (HLVAE.py:248) */
+    int64_t arena_size;          /* floats */
+    int64_t atomic_region;       /* grads in [0, atomic_region) are accumulated with atomics and
+                                    must be zero when a backward pass starts (hlvae_backward zeroes them) */
+} hlvae_dims;
+
+void hlvae_dims_fill(hlvae_dims* d);   /* fills the derived fields from D,X,y_dim,h_e,h_d,L,n_real,n_pos */
+
+/* Workspace: every device buffer one training / inference step touches.  Allocated by the caller
+ * (hl-vae_amd/HLVAE.py) for a maximum padded batch Bp_max (multiple of 128).  Padding rows/columns
+ * are kept zero by the kernels that produce a buffer. */
+typedef struct {
+    int32_t Bp_max;
+    int32_t splitk_enc, splitk_dec;   /* split-K factors of the two long-K GEMMs */
+    /* parameters */
+    float* P;            /* fp32 master parameters, reference shapes, flat arena           */
+    float* G;            /* fp32 gradients, same layout                                     */
+    uint16_t* w1s;       /* bf16 shadow  [hep][Xp]   of W1                                  */
+    uint16_t* wmls;      /* bf16 shadow  [2Lp][hep]  rows 0..L-1 = Wmu, Lp..Lp+L-1 = Wlv    */
+    uint16_t* wmlTs;     /* its transpose [hep][2Lp]                                        */
+    uint16_t* wds;       /* bf16 shadow  [hdp][Lp]   of Wd                                  */
+    uint16_t* wdTs;      /* [Lp][hdp]                                                       */
+    uint16_t* wys;       /* bf16 shadow  [NY][hdp]   of Wy                                  */
+    uint16_t* wyTs;      /* [hdp][NYp]                                                      */
+    /* batch statistics (row A) */
+    double* sums;        /* [3][n_stat]  sum m, sum x m, sum x^2 m (x = d or log1p d)       */
+    float* norm;         /* [2][n_stat]  mean, var (var of pos already clamped to [1e-6,1e20]) */
+    /* packed inputs */
+    uint16_t* xn;        /* [Bp][Xp]  normalised encoder input, bf16                        */
+    uint16_t* xnT;       /* [Xp][Bp]                                                        */
+    float* xt;           /* [Bp][D]   likelihood target: raw x | log1p x | class index      */
+    uint8_t* m8;         /* [Bp][D]   1 = observed                                          */
+    /* activations */
+    float* slab;         /* [max(splitk)][Bp][max(hep,hdp)] fp32 split-K partials           */
+    uint16_t* t;  uint16_t* tT;      /* encoder trunk  [Bp][hep], [hep][Bp]                 */
+    float* mu; float* lv; float* z;  /* [Bp][L] fp32 (row stride L)                         */
+    uint16_t* zb; uint16_t* zbT;     /* [Bp][Lp], [Lp][Bp]                                  */
+    uint16_t* u;  uint16_t* uT;      /* decoder trunk  [Bp][hdp], [hdp][Bp]                 */
+    uint16_t* dy; uint16_t* dyT;     /* d loss / d Y   [Bp][NYp], [NY][Bp]                  */
+    float* log_p_x; float* log_p_x_missing;   /* [Bp][D]                                    */
+    float* rowpart;      /* [ceil(D/16)][Bp] partial row sums of log_p_x                    */
+    float* nll;          /* [Bp]  -sum_d log_p_x                                            */
+    double* scal;        /* [8]: 0 = sum_b nll, 1 = standard-normal KL (extension), 2.. reserved */
+    float* pfull;        /* [Bp][X]  likelihood parameters concatenated by key (row M), optional */
+    float* xhat;         /* [Bp][D]  per-variable imputed value (statistics mean), optional */
+    /* backward activations */
+    uint16_t* du; uint16_t* duT;     /* [Bp][hdp], [hdp][Bp]                                */
+    float* dz;                       /* [Bp][Lp]                                            */
+    uint16_t* dml; uint16_t* dmlT;   /* [Bp][2Lp], [2Lp][Bp]                                */
+    uint16_t* dt; uint16_t* dtT;     /* [Bp][hep], [hep][Bp]                                */
+} hlvae_ws;
+
+typedef struct hlvae_plan hlvae_plan;
+typedef void* hlvae_stream;      /* hipStream_t */
+
+int  hlvae_abi_version(void);
+const char* hlvae_last_error(void);
+/* sizeof(hlvae_dims), sizeof(hlvae_var), sizeof(hlvae_ws): lets a foreign-language binding verify its struct layout */
+void hlvae_struct_sizes(int32_t* dims_bytes, int32_t* var_bytes, int32_t* ws_bytes);
+
+/* replaces: building types_info index vectors per step (HL_VAE/utils.py:94-96, HLVAE.py:387-410) */
+int  hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var* vars /* host, [D] */);
+void hlvae_plan_destroy(hlvae_plan* p);
+
+/* bf16 shadows of the dense weights from the fp32 arena (no reference counterpart: the reference
+ * computes in fp64; BASELINE.json config 2 asks for bf16 encoder/decoder) */
+int hlvae_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s);
+
+/* row A -- HL_VAE/utils.py:88-143 batch_normalization.
+ * stats: masked column sums (fp64 atomics).  For data-parallel runs all-reduce ws->sums between the two calls. */
+int hlvae_normalize_stats(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask,
+                          int B, hlvae_stream s);
+int hlvae_normalize_pack(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask,
+                         int B, hlvae_stream s);
+
+/* rows B + C -- HLVAE.encode MLP branch (HLVAE.py:311-324) + sample_latent (:351-362).
+ * eps [B][L] fp32; eps == NULL means z = mu (get_test_samples, HLVAE.py:472). */
+int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int B, hlvae_stream s);
+
+/* rows D-J -- HLVAE.decode (HLVAE.py:326-349): decoder trunk, y_layer, theta_estimation (:416-453),
+ * loglik_{real,pos,count,cat,ordinal} (HL_VAE/loglik.py) and the scatter/ELBO row sums (HLVAE.py:377-414).
+ * g_logpx: upstream gradient of log_p_x, per element [B][D] fp32, or NULL -> the scalar g_scale.
+ * Writes ws->dy = g * d log_p_x / d Y (zero where unobserved: stop-gradient of HLVAE.py:435-452) and
+ * accumulates the head-parameter gradients into ws->G when want_grad != 0.
+ * want_params != 0 additionally fills ws->pfull and ws->xhat (row M / p_params). */
+int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, float g_scale,
+                      int want_grad, int want_params, int B, hlvae_stream s);
+
+/* rescale ws->dy by a per-element upstream gradient after the fact (autograd path) */
+int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, int B, hlvae_stream s);
+
+/* backward of rows B-D: all dense-layer gradients into ws->G.
+ * g_mu, g_lv: upstream gradients of mu / log_var from the KL term ([B][L] fp32, may be NULL). */
+int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, const float* g_mu,
+                   const float* g_lv, int B, hlvae_stream s);
+/* zero the atomically accumulated gradient region; call before hlvae_decoder_fwd(want_grad=1) */
+int hlvae_zero_grad(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s);
+
+/* closed-form KL(q(z|x) || N(0,I)) value + its gradient (NOT in the reference) */
+int hlvae_kl_std_normal(const hlvae_ws* ws, int B, int L, float weight, float* g_mu, float* g_lv,
+                        hlvae_stream s);
+
+/* torch.optim.Adam(lr) step on the flat arena (HLVAE_main.py:277-278) fused with the bf16 shadow refresh.
+ * step_count: device int64 incremented by the kernel (graph-capture safe). grad_scale multiplies G first. */
+int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count,
+                    float lr, float beta1, float beta2, float eps, float grad_scale, hlvae_stream s);
+
+/* generic bf16 NT GEMM  C[M][N] (fp32, ldc) = A[M][K] * B[N][K]^T, exposed for unit tests */
+int hlvae_gemm_nt_f32(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
+                      int M, int N, int K, hlvae_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HLVAE_HIP_H */

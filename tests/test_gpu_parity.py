@@ -1,0 +1,229 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in HLVAE class) against
+  (1) golden fixtures produced by the reference itself (tests/golden/*.npz),
+  (2) the fp64 CPU oracle on the same seeded inputs,
+  (3) size-independent properties at BASELINE sizes.
+
+Tolerances (bf16 MFMA inputs, fp32 accumulation, fp32 heads/ELBO; reference is fp64):
+  * ELBO / NLL totals:        1e-4 relative   (BASELINE.json north_star)
+  * per-element log_p_x:      3e-2 absolute + 2e-2 relative (bf16 rounding of y, amplified by 1/var in the real head)
+  * mu / log_var:             2e-2 absolute
+  * gradients, per tensor:    3e-2 relative L2 (bf16 activations and weights in both backward GEMMs)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hlvae_amd                      # noqa: E402
+from hlvae_amd import synthetic       # noqa: E402
+from tests_common import MIX_SPEC, load_mix_case, max_abs_err, rel_err   # noqa: E402
+
+ELBO_RTOL = 1e-4
+REPORT = {}
+
+
+def _report(key, **kv):
+    REPORT.setdefault(key, {}).update({k: float(v) for k, v in kv.items()})
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _model_from_state(src, dims, state, max_batch=128):
+    from hlvae_amd.HLVAE import HLVAE
+    m = HLVAE(dims, src.types_info, src.n_variables, vy_init=[1.0, 0.5], conv=False, max_batch=max_batch,
+              materialize_samples=False)
+    m.load_state_dict({k: v for k, v in state.items()})
+    return m.to(_dev())
+
+
+def test_library_loaded_and_fails_loudly_on_cpu():
+    from hlvae_amd import _lib
+    from hlvae_amd.HLVAE import HLVAE
+    assert os.path.exists(_lib.LIB_PATH)
+    _lib.load()
+    src = synthetic.make_tabular(n_rows=8, T=4, seed=1, spec=MIX_SPEC)
+    m = HLVAE([src.cov_dim_ext, [16], 4, [16], 5], src.types_info, src.n_variables, conv=False)
+    with pytest.raises(RuntimeError):
+        m(torch.tensor(src.data), torch.tensor(src.mask), torch.tensor(src.param_mask), src.types_info)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (128, 64, 128), (70, 50, 96), (500, 5184 // 8, 128), (6480 // 4, 500, 256),
+                                   (512, 32, 512), (64, 500, 128)])
+def test_gemm_nt_against_torch(M, N, K):
+    """asymmetric random operands; fp32 torch matmul of the SAME bf16-rounded values is the reference"""
+    from hlvae_amd import _lib
+    import ctypes as C
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
+    B = (torch.randn(N, K, generator=g) + 0.3).to(dev).to(torch.bfloat16)
+    Cc = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32)
+    lib = _lib.load()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.hlvae_gemm_nt_f32(_lib.ptr(A), K, _lib.ptr(B), K, _lib.ptr(Cc), N, M, N, K, s), "gemm")
+    torch.cuda.synchronize()
+    ref = A.float() @ B.float().t()
+    err = (Cc - ref).abs().max().item()
+    assert err < 1e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("name", ["mix_init", "mix_trained"])
+def test_forward_backward_against_reference_fixture(golden_dir, name):
+    g, src, dims, state = load_mix_case(golden_dir, name)
+    dev = _dev()
+    model = _model_from_state(src, dims, state)
+    data, mask = torch.tensor(g["data"], device=dev), torch.tensor(g["mask"], device=dev)
+    pmask = torch.tensor(src.param_mask, device=dev)
+    eps = torch.tensor(g["eps"], device=dev)
+    p_samples, mu, lv, lpx, lpm, p_params, q_samples, q_params = model(data, mask, pmask, src.types_info, eps=eps)
+    torch.cuda.synchronize()
+    e_mu, e_lv = max_abs_err(mu.cpu(), g["mu"]), max_abs_err(lv.cpu(), g["log_var"])
+    e_lpx = np.abs(lpx.double().cpu().numpy() - g["log_p_x"])
+    e_lpm = np.abs(lpm.double().cpu().numpy() - g["log_p_x_missing"])
+    elbo = float(lpx.double().sum())
+    elbo_ref = float(g["log_p_x"].sum())
+    _report(name, mu=e_mu, lv=e_lv, lpx_max=e_lpx.max(), lpm_max=e_lpm.max(), elbo_rel=abs(elbo - elbo_ref) / abs(elbo_ref))
+    assert e_mu < 2e-2 and e_lv < 2e-2
+    assert np.all(e_lpx <= 3e-2 + 2e-2 * np.abs(g["log_p_x"]))
+    assert np.all(e_lpm <= 3e-2 + 2e-2 * np.abs(g["log_p_x_missing"]))
+    assert abs(elbo - elbo_ref) <= 10 * ELBO_RTOL * abs(elbo_ref)     # 24 rows only: few terms to average over
+    # p_params per type block, reference shapes
+    for i, p in enumerate(p_params["x"]):
+        ref = g[f"p_params_{i}"]
+        assert tuple(p.shape) == ref.shape
+        assert max_abs_err(p.cpu(), ref) <= 3e-2 + 2e-2 * np.abs(ref).max(), i
+    # same loss as the fixture: scale * sum(nll) + KL_std(mu, lv)
+    nll = model.loss_function(lpx)
+    kl = -0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
+    loss = float(g["nll_scale"][0]) * nll.sum() + kl
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"][0])) <= 10 * ELBO_RTOL * abs(float(g["loss"][0]))
+    worst = 0.0
+    sd = dict(model.named_parameters())
+    for k in g.files:
+        if not k.startswith("grad__"):
+            continue
+        pname = k[len("grad__"):]
+        gr = sd[pname].grad
+        assert gr is not None, pname
+        e = rel_err(gr.double().cpu().numpy(), g[k])
+        _report(name + "_grads", **{pname: e})
+        worst = max(worst, e)
+        assert e < 3e-2, (pname, e)
+    assert worst > 0
+
+
+def test_test_samples_and_metrics_against_fixture(golden_dir):
+    g, src, dims, state = load_mix_case(golden_dir, "mix_trained")
+    dev = _dev()
+    model = _model_from_state(src, dims, state)
+    data, mask = torch.tensor(g["data"], device=dev), torch.tensor(g["mask"], device=dev)
+    qs, qp, ps, pp, lpt, lpmt = model.get_test_samples(data, mask, None)
+    assert max_abs_err(qp["z"][0].cpu(), g["test_mu"]) < 2e-2
+    assert np.all(np.abs(lpt.double().cpu().numpy() - g["test_log_p_x"]) <= 3e-2 + 2e-2 * np.abs(g["test_log_p_x"]))
+    assert torch.equal(qs["z"], qp["z"][0])          # decode(mean_qz): no noise (HLVAE.py:472)
+    # imputed values (row M): x_hat of the deterministic pass agrees with statistics() on the oracle params
+    xhat = model._ws_t["xhat"][:24].double().cpu().numpy()
+    import hlvae_oracle as orc
+    import metrics_oracle as mo
+    st = {k: v for k, v in state.items()}
+    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st)
+    ts = om.test_samples(torch.tensor(g["data"]), torch.tensor(g["mask"]))
+    xh_ref, _, _, _ = mo.step_metrics(ts["p_params"], torch.tensor(g["data"]), torch.tensor(g["mask"]), src.types_info,
+                                      st["_log_vy_pos"])
+    xh_ref = xh_ref.numpy()
+    disc = np.isin(model.plan.kind, [3, 4])
+    assert np.mean(xhat[:, disc] == xh_ref[:, disc]) > 0.97       # argmax may flip on near-ties
+    assert np.allclose(xhat[:, ~disc], xh_ref[:, ~disc], rtol=3e-2, atol=3e-2)
+
+
+def _oracle_step(src, rows, dims, state, eps, scale):
+    import hlvae_oracle as orc
+    st = {k: v.double().clone().requires_grad_(True) for k, v in state.items() if not k.startswith("hidden.")}
+    for k in list(st):
+        if k.startswith("d_layers."):
+            st["hidden." + k[len("d_layers."):]] = st[k]
+    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st)
+    out = om.forward(torch.tensor(src.data[rows]), torch.tensor(src.mask[rows]), eps.double().cpu())
+    loss = scale * om.loss_function(out["log_p_x"]).sum() + orc.standard_normal_kl(out["mu"], out["log_var"])
+    loss.backward()
+    return out, loss, st
+
+
+def test_d4_batch512_against_oracle():
+    """BASELINE config 2 shape: D4 layout (324 real + 972 cat5), hidden 500, latent 32, batch 512."""
+    dev = _dev()
+    src = synthetic.make_d4(n_subjects=26, T=20, seed=100)
+    rows = np.arange(512)
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    from hlvae_amd.HLVAE import HLVAE
+    torch.manual_seed(1234)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=512, materialize_samples=False).to(dev)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    eps = torch.randn(512, 32, generator=torch.Generator().manual_seed(5))
+    data = torch.tensor(src.data[rows], device=dev)
+    mask = torch.tensor(src.mask[rows], device=dev)
+    out = model(data, mask, None, src.types_info, eps=eps.to(dev))
+    mu, lv, lpx = out[1], out[2], out[3]
+    scale = 200.0 / 26.0
+    loss = scale * model.loss_function(lpx).sum() - 0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref, ref_loss, st = _oracle_step(src, rows, dims, state, eps, scale)
+    elbo, elbo_ref = float(lpx.double().sum()), float(ref["log_p_x"].sum())
+    rel = abs(elbo - elbo_ref) / abs(elbo_ref)
+    _report("d4_b512", elbo_rel=rel, loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
+            mu=max_abs_err(mu.cpu(), ref["mu"].detach()), lv=max_abs_err(lv.cpu(), ref["log_var"].detach()),
+            lpx_max=max_abs_err(lpx.cpu(), ref["log_p_x"].detach()))
+    assert rel <= ELBO_RTOL, rel
+    assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss))
+    sd = dict(model.named_parameters())
+    for k, p in sd.items():
+        e = rel_err(p.grad.double().cpu().numpy(), st[k].grad.numpy())
+        _report("d4_b512_grads", **{k: e})
+        assert e < 3e-2, (k, e)
+
+
+def test_properties_at_full_size():
+    """size-independent properties (no oracle needed): masked-out entries carry no gradient, the
+    gradient is linear in the upstream scale, rows are independent given the batch statistics."""
+    dev = _dev()
+    src = synthetic.make_d4(n_subjects=26, T=20, seed=7)
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    from hlvae_amd.HLVAE import HLVAE
+    torch.manual_seed(3)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=512, materialize_samples=False).to(dev)
+    data = torch.tensor(src.data[:512], device=dev)
+    mask = torch.tensor(src.mask[:512], device=dev)
+    eps = torch.randn(512, 32, device=dev)
+
+    def grads(scale):
+        out = model(data, mask, None, src.types_info, eps=eps)
+        (scale * model.loss_function(out[3]).sum()).backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, out
+
+    g1, out1 = grads(1.0)
+    g3, _ = grads(3.0)
+    for k in g1:
+        assert rel_err(g3[k].cpu().numpy(), 3.0 * g1[k].cpu().numpy()) < 2e-2, k
+    lpx, lpm = out1[3], out1[4]
+    m = mask.bool()
+    assert float(lpx[~m].abs().max()) == 0.0 and float(lpm[m].abs().max()) == 0.0     # HLVAE.py:409-410
+    assert torch.isfinite(lpx).all() and torch.isfinite(lpm).all()
+    # all-missing row block: zero observed log-likelihood and no NaN (mask = 0 for a whole row)
+    mask2 = mask.clone()
+    mask2[5] = 0
+    out2 = model(data, mask2, None, src.types_info, eps=eps)
+    assert float(out2[3][5].abs().max()) == 0.0 and torch.isfinite(out2[3]).all()
