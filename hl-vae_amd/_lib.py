@@ -59,6 +59,8 @@ _SIGS = {
     "hlvae_kl_std_normal": (C.c_int, [C.POINTER(HlvaeWs), C.c_int, C.c_int, C.c_float, _vp, _vp, _vp]),
     "hlvae_adam_step": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _vp]),
+    "hlvae_prof_enable": (None, [C.c_int]),
+    "hlvae_prof_report": (C.c_int, [C.c_char_p, C.c_int]),
     "hlvae_gemm_nt_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
 }
 

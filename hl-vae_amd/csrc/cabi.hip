@@ -7,12 +7,12 @@
 #include "common.h"
 
 // launchers implemented next to their kernels
-int hl_launch_gemm_f32(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, int, float*, hipStream_t);
-int hl_launch_gemm_splitk(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, hipStream_t);
+int hl_launch_gemm_f32(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, int, float*, const char*, hipStream_t);
+int hl_launch_gemm_splitk(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, const char*, hipStream_t);
 int hl_launch_reduce_act(int, const float*, int, int, int, const float*, int, const bf16_t*, bf16_t*, bf16_t*, int, int,
-                         float*, hipStream_t);
+                         float*, const char*, hipStream_t);
 int hl_launch_gemm_act(int, const bf16_t*, int, const bf16_t*, int, int, int, int, const float*, int, const bf16_t*,
-                       bf16_t*, int, bf16_t*, int, int, float*, hipStream_t);
+                       bf16_t*, int, bf16_t*, int, int, float*, const char*, hipStream_t);
 int hl_launch_mid_fwd(int, const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, float*,
                       float*, float*, bf16_t*, bf16_t*, int, int, int, hipStream_t);
 int hl_launch_mid_bwd(int, const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*,
@@ -35,9 +35,58 @@ void hl_set_error(const char* fmt, ...) {
 
 static inline int padded_batch(int B) { return ru(B, 128); }
 
+// ---- per-kernel event timing -----------------------------------------------------------------------
+#include <map>
+#include <string>
+struct ProfRec { const char* name; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+void hl_prof_begin(const char* name, hipStream_t s) {
+    if (!g_prof_on) return;
+    ProfRec r{name, prof_event(), prof_event()};
+    if (r.a) (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+}
+void hl_prof_end(hipStream_t s) {
+    if (!g_prof_on || g_prof.empty()) return;
+    if (g_prof.back().b) (void)hipEventRecord(g_prof.back().b, s);
+}
+
 extern "C" {
 
 int hlvae_abi_version(void) { return HLVAE_ABI_VERSION; }
+
+void hlvae_prof_enable(int on) { g_prof_on = on != 0; }
+
+int hlvae_prof_report(char* buf, int buflen) {
+    HL_CHECK(hipDeviceSynchronize());
+    std::map<std::string, std::pair<long, double>> agg;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (r.a && r.b && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto& e = agg[r.name];
+            e.first += 1;
+            e.second += ms;
+        }
+        if (r.a) g_prof_pool.push_back(r.a);
+        if (r.b) g_prof_pool.push_back(r.b);
+    }
+    g_prof.clear();
+    int n = 0;
+    for (auto& kv : agg) {
+        int w = snprintf(buf + n, buflen > n ? buflen - n : 0, "%s %ld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        if (w < 0 || n + w >= buflen) break;
+        n += w;
+    }
+    return 0;
+}
 const char* hlvae_last_error(void) { return g_err; }
 void hlvae_struct_sizes(int32_t* dims_bytes, int32_t* var_bytes, int32_t* ws_bytes) {
     if (dims_bytes) *dims_bytes = (int32_t)sizeof(hlvae_dims);
@@ -141,9 +190,9 @@ int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps,
     int rc;
     HL_REQUIRE(ws->splitk_enc >= 1, HLVAE_EINVAL, "splitk_enc");
     // trunk: T = relu(Xn W1^T + b1)   (HLVAE.py:316-317, evaluated once)
-    if ((rc = hl_launch_gemm_splitk(ws->xn, d.Xp, ws->w1s, d.Xp, ws->slab, d.hep, Bp, d.hep, d.Xp, ws->splitk_enc, st))) return rc;
+    if ((rc = hl_launch_gemm_splitk(ws->xn, d.Xp, ws->w1s, d.Xp, ws->slab, d.hep, Bp, d.hep, d.Xp, ws->splitk_enc, "enc1_splitk", st))) return rc;
     if ((rc = hl_launch_reduce_act(0, ws->slab, ws->splitk_enc, Bp, d.hep, ws->P + d.o_b1, d.h_e, nullptr, ws->t, ws->tT,
-                                   Bp, B, nullptr, st))) return rc;
+                                   Bp, B, nullptr, "enc1_reduce_relu", st))) return rc;
     // mean / log-var heads + clamp + reparameterisation
     return hl_launch_mid_fwd(d.Lp, ws->t, d.hep, ws->wmls, d.hep, ws->P + d.o_bmu, ws->P + d.o_blv, eps, ws->mu, ws->lv,
                              ws->z, ws->zb, ws->zbT, Bp, B, d.L, st);
@@ -155,7 +204,7 @@ int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_lo
     int rc;
     // U = relu(z Wd^T + bd)   (HLVAE.py:336)
     if ((rc = hl_launch_gemm_act(0, ws->zb, d.Lp, ws->wds, d.Lp, Bp, d.hdp, d.Lp, ws->P + d.o_bd, d.h_d, nullptr, ws->u,
-                                 d.hdp, ws->uT, Bp, B, nullptr, st))) return rc;
+                                 d.hdp, ws->uT, Bp, B, nullptr, "dec1_relu", st))) return rc;
     return hl_launch_y_heads(p, ws, g_logpx, g_scale, want_grad, want_params, B, Bp, st);
 }
 
@@ -177,24 +226,24 @@ int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, co
     int rc;
     HL_REQUIRE(ws->splitk_dec >= 1, HLVAE_EINVAL, "splitk_dec");
     // d Wy = dY^T U                                  [NY][h_d]
-    if ((rc = hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, st))) return rc;
+    if ((rc = hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", st))) return rc;
     // d U = (dY Wy) * relu'(U); d bd
-    if ((rc = hl_launch_gemm_splitk(ws->dy, d.NYp, ws->wyTs, d.NYp, ws->slab, d.hdp, Bp, d.hdp, d.NYp, ws->splitk_dec, st))) return rc;
+    if ((rc = hl_launch_gemm_splitk(ws->dy, d.NYp, ws->wyTs, d.NYp, ws->slab, d.hdp, Bp, d.hdp, d.NYp, ws->splitk_dec, "dU_splitk", st))) return rc;
     if ((rc = hl_launch_reduce_act(1, ws->slab, ws->splitk_dec, Bp, d.hdp, nullptr, d.h_d, ws->u, ws->du, ws->duT, Bp, B,
-                                   ws->G + d.o_bd, st))) return rc;
+                                   ws->G + d.o_bd, "dU_reduce_relu_bwd", st))) return rc;
     // d Wd = dU^T z                                  [h_d][L]
-    if ((rc = hl_launch_gemm_f32(ws->duT, Bp, ws->zbT, Bp, ws->G + d.o_wd, d.L, d.h_d, d.L, Bp, 0, 0, nullptr, st))) return rc;
+    if ((rc = hl_launch_gemm_f32(ws->duT, Bp, ws->zbT, Bp, ws->G + d.o_wd, d.L, d.h_d, d.L, Bp, 0, 0, nullptr, "dWd", st))) return rc;
     // d z -> d mu, d log_var (clamp + reparameterisation backward); d bmu, d blv
     if ((rc = hl_launch_mid_bwd(d.Lp, ws->du, d.hdp, ws->wdTs, d.hdp, eps, ws->lv, g_mu, g_lv, ws->dz, ws->dml, ws->dmlT,
                                 Bp, B, d.L, ws->G + d.o_bmu, ws->G + d.o_blv, st))) return rc;
     // d [Wmu; Wlv] = dml^T T                         2 x [L][h_e]
     if ((rc = hl_launch_gemm_f32(ws->dmlT, Bp, ws->tT, Bp, ws->G + d.o_wmu, d.h_e, 2 * d.Lp, d.h_e, Bp, d.Lp, d.L,
-                                 ws->G + d.o_wlv, st))) return rc;
+                                 ws->G + d.o_wlv, "dWmu_dWlv", st))) return rc;
     // d T = (dml [Wmu; Wlv]) * relu'(T); d b1
     if ((rc = hl_launch_gemm_act(1, ws->dml, 2 * d.Lp, ws->wmlTs, 2 * d.Lp, Bp, d.hep, 2 * d.Lp, nullptr, d.h_e, ws->t,
-                                 ws->dt, d.hep, ws->dtT, Bp, B, ws->G + d.o_b1, st))) return rc;
+                                 ws->dt, d.hep, ws->dtT, Bp, B, ws->G + d.o_b1, "dT_relu_bwd", st))) return rc;
     // d W1 = dT^T Xn                                 [h_e][X]   (no input gradient for layer 1)
-    return hl_launch_gemm_f32(ws->dtT, Bp, ws->xnT, Bp, ws->G + d.o_w1, d.X, d.h_e, d.X, Bp, 0, 0, nullptr, st);
+    return hl_launch_gemm_f32(ws->dtT, Bp, ws->xnT, Bp, ws->G + d.o_w1, d.X, d.h_e, d.X, Bp, 0, 0, nullptr, "dW1", st);
 }
 
 int hlvae_kl_std_normal(const hlvae_ws* ws, int B, int L, float weight, float* g_mu, float* g_lv, hlvae_stream s) {
@@ -211,7 +260,7 @@ int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m
 int hlvae_gemm_nt_f32(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc, int M, int N, int K,
                       hlvae_stream s) {
     HL_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, HLVAE_EINVAL, "gemm: bad arguments");
-    return hl_launch_gemm_f32(A, lda, B, ldb, C, ldc, M, N, K, 0, 0, nullptr, (hipStream_t)s);
+    return hl_launch_gemm_f32(A, lda, B, ldb, C, ldc, M, N, K, 0, 0, nullptr, "gemm_nt_f32", (hipStream_t)s);
 }
 
 }  // extern "C"

@@ -42,6 +42,16 @@ struct hlvae_plan {
 };
 
 void hl_set_error(const char* fmt, ...);
+
+// optional per-kernel HIP-event timing (hlvae_prof_enable / hlvae_prof_report); a no-op when disabled
+void hl_prof_begin(const char* name, hipStream_t s);
+void hl_prof_end(hipStream_t s);
+struct HlProfScope {
+    hipStream_t s;
+    HlProfScope(const char* name, hipStream_t st) : s(st) { hl_prof_begin(name, st); }
+    ~HlProfScope() { hl_prof_end(s); }
+};
+#define HL_PROF(name, stream) HlProfScope _hl_prof_scope(name, stream)
 #define HL_CHECK(expr)                                                            \
     do {                                                                          \
         hipError_t _e = (expr);                                                   \

@@ -264,8 +264,9 @@ __global__ __launch_bounds__(HL_THREADS) void k_mid_bwd(const bf16_t* __restrict
 // host launchers (called from cabi.hip)
 // ------------------------------------------------------------------------------------------------
 int hl_launch_gemm_f32(const bf16_t* A, int lda, const bf16_t* B, int ldb, float* C, int ldc, int M, int N, int K,
-                       int band, int band_rows, float* C2, hipStream_t s) {
+                       int band, int band_rows, float* C2, const char* label, hipStream_t s) {
     HL_REQUIRE(K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0, HLVAE_ESHAPE, "gemm_f32: K=%d lda=%d ldb=%d", K, lda, ldb);
+    HL_PROF(label, s);
     if (N <= 32) {
         dim3 grid((N + 31) / 32, (M + 63) / 64);
         if (K % 64 == 0)
@@ -291,21 +292,23 @@ int hl_launch_gemm_f32(const bf16_t* A, int lda, const bf16_t* B, int ldb, float
 
 // C = sum over splits; returns the number of splits used (<= S_max) through *S_used
 int hl_launch_gemm_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, float* slab, int ldn, int M, int N, int K,
-                          int S, hipStream_t s) {
+                          int S, const char* label, hipStream_t s) {
     HL_REQUIRE(K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && S >= 1, HLVAE_ESHAPE, "splitk: K=%d S=%d", K, S);
     const int ksteps = K / 64;
     const int per = (ksteps + S - 1) / S;
     HL_REQUIRE(per * (S - 1) < ksteps, HLVAE_ESHAPE, "splitk: S=%d leaves an empty split for %d k-steps", S, ksteps);
     dim3 grid((N + 63) / 64, (M + 63) / 64, S);
+    HL_PROF(label, s);
     k_gemm_splitk<64, 64, 64, 2, 2><<<grid, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per);
     HL_LAUNCH_CHECK();
     return 0;
 }
 
 int hl_launch_reduce_act(int mode, const float* slab, int S, int M, int ldn, const float* bias, int nvalid,
-                         const bf16_t* ref, bf16_t* out, bf16_t* outT, int ldT, int B, float* gbias, hipStream_t s) {
+                         const bf16_t* ref, bf16_t* out, bf16_t* outT, int ldT, int B, float* gbias, const char* label, hipStream_t s) {
     dim3 grid(ldn / 64, M / 64);
     HL_REQUIRE(ldn % 64 == 0 && M % 64 == 0, HLVAE_ESHAPE, "reduce_act: M=%d ldn=%d", M, ldn);
+    HL_PROF(label, s);
     if (mode == 0)
         k_reduce_act<0><<<grid, HL_THREADS, 0, s>>>(slab, S, M, ldn, bias, nvalid, ref, out, outT, ldT, B, gbias);
     else
@@ -316,9 +319,10 @@ int hl_launch_reduce_act(int mode, const float* slab, int S, int M, int ldn, con
 
 int hl_launch_gemm_act(int mode, const bf16_t* A, int lda, const bf16_t* Bm, int ldb, int M, int N, int K,
                        const float* bias, int nvalid, const bf16_t* ref, bf16_t* out, int ldo, bf16_t* outT, int ldT,
-                       int B, float* gbias, hipStream_t s) {
+                       int B, float* gbias, const char* label, hipStream_t s) {
     HL_REQUIRE(K % 32 == 0 && M % 64 == 0 && N % 64 == 0, HLVAE_ESHAPE, "gemm_act: M=%d N=%d K=%d", M, N, K);
     dim3 grid(N / 64, M / 64);
+    HL_PROF(label, s);
     if (K % 64 == 0) {
         if (mode == 0)
             k_gemm_act<64, 0><<<grid, HL_THREADS, 0, s>>>(A, lda, Bm, ldb, M, N, K, bias, nvalid, ref, out, ldo, outT, ldT, B, gbias);
@@ -338,6 +342,7 @@ int hl_launch_mid_fwd(int Lp, const bf16_t* T, int ldt, const bf16_t* Wml, int K
                       const float* eps, float* mu, float* lv, float* z, bf16_t* zb, bf16_t* zbT, int Bp, int B, int L,
                       hipStream_t s) {
     HL_REQUIRE(K % 64 == 0 && Bp % 64 == 0, HLVAE_ESHAPE, "mid_fwd: K=%d Bp=%d", K, Bp);
+    HL_PROF("enc_head_reparam", s);
     if (Lp == 32)
         k_mid_fwd<32><<<Bp / 64, HL_THREADS, 0, s>>>(T, ldt, Wml, K, bmu, blv, eps, mu, lv, z, zb, zbT, Bp, B, L);
     else if (Lp == 64)
@@ -352,6 +357,7 @@ int hl_launch_mid_bwd(int Lp, const bf16_t* dU, int ldu, const bf16_t* WdT, int 
                       const float* g_mu, const float* g_lv, float* dz, bf16_t* dml, bf16_t* dmlT, int Bp, int B, int L,
                       float* gbmu, float* gblv, hipStream_t s) {
     HL_REQUIRE(K % 64 == 0 && Bp % 64 == 0, HLVAE_ESHAPE, "mid_bwd: K=%d Bp=%d", K, Bp);
+    HL_PROF("dz_reparam_bwd", s);
     if (Lp == 32)
         k_mid_bwd<32><<<Bp / 64, HL_THREADS, 0, s>>>(dU, ldu, WdT, K, eps, lv, g_mu, g_lv, dz, dml, dmlT, Bp, B, L, gbmu, gblv);
     else if (Lp == 64)

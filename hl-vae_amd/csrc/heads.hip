@@ -560,6 +560,8 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
     float* pf = want_params ? ws->pfull : nullptr;
     float* xh = want_params ? ws->xhat : nullptr;
     HL_REQUIRE(!want_params || (ws->pfull && ws->xhat), HLVAE_EINVAL, "want_params without pfull/xhat buffers");
+    {
+    HL_PROF("y_heads_loglik", s);
     if ((long)(Bp / 128) * NT >= 512) {
         dim3 grid(NT, Bp / 128);
         k_y_heads<5, 128><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,
@@ -573,8 +575,10 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
                                                      d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing, ws->rowpart,
                                                      pf, d.X, xh, B, want_grad);
     }
+    }
     HL_LAUNCH_CHECK();
     HL_CHECK(hipMemsetAsync(ws->scal, 0, sizeof(double), s));
+    HL_PROF("elbo_rowsum", s);
     k_rowsum<<<(Bp + 255) / 256, 256, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal);
     HL_LAUNCH_CHECK();
     return 0;
@@ -582,6 +586,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
 
 int hl_launch_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g, int B, int Bp, hipStream_t s) {
     const hlvae_dims& d = p->d;
+    HL_PROF("scale_dy", s);
     k_scale_dy<<<1024, 256, 0, s>>>(ws->dy, d.NYp, ws->dyT, Bp, g, B, d.D, d.y_dim);
     HL_LAUNCH_CHECK();
     return 0;

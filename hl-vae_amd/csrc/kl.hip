@@ -22,6 +22,7 @@ int hl_launch_kl_std(const hlvae_ws* ws, int B, int L, float weight, float* g_mu
     const int n = B * L;
     int blocks = (n + 255) / 256;
     if (blocks > 256) blocks = 256;
+    HL_PROF("kl_std_normal", s);
     k_kl_std<<<blocks, 256, 0, s>>>(ws->mu, ws->lv, n, weight, g_mu, g_lv, ws->scal + 1);
     HL_LAUNCH_CHECK();
     return 0;

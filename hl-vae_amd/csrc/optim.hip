@@ -65,6 +65,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_shadow(const float* __restrict__
 static int shadow(const float* src, int R, int C, bf16_t* dst, int ldd, int row_off, bf16_t* dstT, int ldT, int Rcover,
                   int Ccover, hipStream_t s) {
     dim3 grid((Ccover + 63) / 64, (Rcover + 63) / 64);
+    HL_PROF("shadow_cast", s);
     k_shadow<<<grid, HL_THREADS, 0, s>>>(src, R, C, dst, ldd, row_off, dstT, ldT, Rcover, Ccover);
     HL_LAUNCH_CHECK();
     return 0;
@@ -92,7 +93,10 @@ int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64
     const long n4 = d.arena_size / 4;
     int blocks = (int)((n4 + HL_THREADS - 1) / HL_THREADS);
     if (blocks > 2048) blocks = 2048;
+    {
+    HL_PROF("adam", s);
     k_adam<<<blocks, HL_THREADS, 0, s>>>(ws->P, ws->G, m1, m2, n4, step_count, lr, b1, b2, eps, gscale);
+    }
     HL_LAUNCH_CHECK();
     k_inc_step<<<1, 1, 0, s>>>(step_count);
     HL_LAUNCH_CHECK();

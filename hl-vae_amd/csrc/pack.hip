@@ -122,6 +122,7 @@ int hl_launch_stats(const hlvae_plan* p, const hlvae_ws* ws, const double* data,
     int gy = (B + 4 * 16 - 1) / (4 * 16);
     if (gy > 64) gy = 64;
     dim3 grid((d.n_stat + 63) / 64, gy);
+    HL_PROF("colstats", s);
     k_colstats<<<grid, block, 0, s>>>(data, mask, p->vars_dev, p->stat_var_dev, d.n_stat, d.X, d.D, B, ws->sums);
     HL_LAUNCH_CHECK();
     return 0;
@@ -131,10 +132,12 @@ int hl_launch_pack(const hlvae_plan* p, const hlvae_ws* ws, const double* data, 
                    hipStream_t s) {
     const hlvae_dims& d = p->d;
     if (d.n_stat > 0) {
+        HL_PROF("finish_stats", s);
         k_finish_stats<<<(d.n_stat + 255) / 256, 256, 0, s>>>(ws->sums, p->vars_dev, p->stat_var_dev, d.n_stat, ws->norm);
         HL_LAUNCH_CHECK();
     }
     dim3 grid(d.Xp / 64, Bp / 64);
+    HL_PROF("normalize_pack", s);
     k_normalize_pack<<<grid, HL_THREADS, 0, s>>>(data, mask, p->vars_dev, p->col2var_dev, ws->norm, d.n_stat, d.X, d.Xp,
                                                  d.D, B, Bp, ws->xn, ws->xnT, ws->xt, ws->m8);
     HL_LAUNCH_CHECK();

@@ -1,0 +1,105 @@
+"""Roofline accounting for bench.py: algorithmic bytes / flops of every kernel of the step and a live
+HIP-event measurement of each kernel's average duration (library facility hlvae_prof_enable /
+hlvae_prof_report: events are recorded on the stream the kernel is launched on).
+
+Per-unit figures, B = rows per step, P_n = parameters:
+  F_fwd   = 2 (X h + h 2L + L h + h D y)  flop/row ;  F_train = 3 F_fwd - 2 X h
+  Adam    = 28 B / parameter  (4 grad read + 3 x (4 read + 4 write) for master, m, v)
+Peaks from MI355X_MICROARCH.md: HBM 8 TB/s, dense bf16 MFMA 2.5 PFLOP/s.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _lib
+
+HBM_PEAK_GBS = 8000.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def _ru(v, m):
+    return (v + m - 1) // m * m
+
+
+def algorithmic_work(model, B):
+    """label -> (bytes, flops) per launch (algorithmic: every operand read once, every result written once)."""
+    d = model._dims
+    Bp = _ru(B, 128)
+    X, Xp, D, he, hep, hd, hdp, L, Lp, NY = d.X, d.Xp, d.D, d.h_e, d.hep, d.h_d, d.hdp, d.L, d.Lp, d.NY
+    S_e, S_d = model._ws.splitk_enc, model._ws.splitk_dec
+    Pn = model._arena_size
+    w = {}
+    w["colstats"] = (B * d.n_stat * 16, 0)
+    w["finish_stats"] = (d.n_stat * 32, 0)
+    w["normalize_pack"] = (B * (X + D) * 8 + 2 * B * Xp * 2 + B * D * 5, 0)
+    w["enc1_splitk"] = ((B * Xp + hep * Xp) * 2 + S_e * B * hep * 4, 2 * B * X * he)
+    w["enc1_reduce_relu"] = (S_e * B * hep * 4 + 2 * B * hep * 2, 0)
+    w["enc_head_reparam"] = ((B * hep + 2 * Lp * hep) * 2 + B * L * 16 + 2 * B * Lp * 2, 2 * B * he * 2 * L)
+    w["dec1_relu"] = ((B * Lp + hdp * Lp) * 2 + 2 * B * hdp * 2, 2 * B * L * hd)
+    w["y_heads_loglik"] = ((B * hdp + NY * hdp) * 2 + B * D * 5 + 2 * B * NY * 2 + 2 * B * D * 4, 2 * B * NY * hd + 150 * B * D)
+    w["elbo_rowsum"] = (((D + 15) // 16) * B * 4, 0)
+    w["kl_std_normal"] = (B * L * 16, 0)
+    w["dWy"] = ((NY * Bp + hdp * Bp) * 2 + NY * hd * 4, 2 * B * NY * hd)
+    w["dU_splitk"] = ((B * d.NYp + hdp * d.NYp) * 2 + S_d * B * hdp * 4, 2 * B * NY * hd)
+    w["dU_reduce_relu_bwd"] = (S_d * B * hdp * 4 + 3 * B * hdp * 2, 0)
+    w["dWd"] = ((hdp * Bp + Lp * Bp) * 2 + hd * L * 4, 2 * B * hd * L)
+    w["dz_reparam_bwd"] = ((B * hdp + Lp * hdp) * 2 + B * L * 16 + 2 * B * 2 * Lp * 2, 2 * B * hd * L)
+    w["dWmu_dWlv"] = ((2 * Lp * Bp + hep * Bp) * 2 + 2 * L * he * 4, 2 * B * 2 * L * he)
+    w["dT_relu_bwd"] = ((B * 2 * Lp + hep * 2 * Lp) * 2 + 3 * B * hep * 2, 2 * B * 2 * L * he)
+    w["dW1"] = ((hep * Bp + Xp * Bp) * 2 + he * X * 4, 2 * B * X * he)
+    w["adam"] = (Pn * 28, 0)
+    n_w = he * X + 2 * L * he + hd * L + NY * hd
+    w["shadow_cast"] = (n_w * 4 + (he * X + 2 * (2 * L * he + hd * L + NY * hd)) * 2, 0)   # all 5 launches together
+    return w
+
+
+def measure_dominant_kernel(trainer, batch, steps, eager_steps=None):
+    """Run `steps` eager steps with the library's per-kernel HIP events on, find the kernel with the
+    largest total time and price it against its roofline.  Returns the bench.py 'roofline' object
+    (plus the per-kernel table for DESIGN.md / profiles)."""
+    lib = _lib.load()
+    m = trainer.model
+    n = steps if eager_steps is None else eager_steps
+    n = max(5, min(n, 100))
+    B = batch["data"].shape[0]
+    import torch
+    for _ in range(3):
+        trainer.step(batch["data"], batch["mask"], batch["P_batch"], train_x=batch.get("labels"))
+    torch.cuda.synchronize()
+    lib.hlvae_prof_enable(1)
+    for _ in range(n):
+        trainer.step(batch["data"], batch["mask"], batch["P_batch"], train_x=batch.get("labels"))
+    lib.hlvae_prof_enable(0)
+    buf = C.create_string_buffer(1 << 16)
+    _lib.check(lib.hlvae_prof_report(buf, len(buf)), "hlvae_prof_report")
+    work = algorithmic_work(m, B)
+    table = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, tot = line.split()
+        cnt, tot = int(cnt), float(tot)
+        per_step_launches = cnt / n
+        avg_us = 1e3 * tot / cnt
+        by, fl = work.get(name, (0, 0))
+        if name == "shadow_cast":          # five launches share one label; bytes are for all of them
+            by, fl = by / per_step_launches, 0
+        table[name] = dict(launches_per_step=per_step_launches, avg_us=avg_us, us_per_step=avg_us * per_step_launches,
+                           bytes=by, flops=fl)
+    if not table:
+        return None
+    dom = max(table, key=lambda k: table[k]["us_per_step"])
+    t = table[dom]
+    t_hbm = t["bytes"] / (HBM_PEAK_GBS * 1e9)
+    t_mfma = t["flops"] / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+    if t_hbm >= t_mfma:
+        ach = t["bytes"] / (t["avg_us"] * 1e-6) / 1e9
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
+    else:
+        ach = t["flops"] / (t["avg_us"] * 1e-6) / 1e12
+        roof = dict(bound="mfma", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_BF16_PEAK_TFLOPS,
+                    traffic=None)
+    roof["kernel"] = dom
+    roof["avg_us"] = t["avg_us"]
+    roof["algorithmic_per_launch"] = t["bytes"] if roof["bound"] == "hbm" else t["flops"]
+    roof["kernels_us_per_step"] = {k: round(v["us_per_step"], 2) for k, v in sorted(table.items(), key=lambda kv: -kv[1]["us_per_step"])}
+    roof["sum_kernels_us_per_step"] = round(sum(v["us_per_step"] for v in table.values()), 2)
+    return roof

@@ -1,0 +1,125 @@
+"""The ELBO training step -- the hot loop of the reference's ``hensman_training``
+(reference training.py:70-143) as one device-resident sequence of HIP launches:
+
+    normalise/pack -> encoder -> reparameterise -> decoder + heads + log-lik (+ their backward)
+    -> KL (+ its gradient) -> dense backward -> [RCCL all-reduce of the flat gradient arena]
+    -> fused Adam (+ bf16 shadow refresh) -> [natural-gradient update of (m, H)]
+
+No autograd graph, no host synchronisation: every scalar the reference pulls to the host with
+``.item()`` (training.py:139-143) stays in a device buffer that the caller reads when it wants.
+The whole step can be captured into a HIP graph (``capture=True``) and replayed.
+
+``loss = P / P_batch * sum_b nll_b + KL``  (training.py:121-124), so the upstream gradient of
+every log_p_x[b, d] is the scalar  -P / P_batch, which lets the head kernel emit dY in the same
+pass as the forward.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional
+
+import torch
+
+from . import _lib
+from .HLVAE import HLVAE
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr=1e-3) semantics (reference HLVAE_main.py:277-278) on the model's flat arena:
+    one HBM-streaming kernel for all parameters, fused with the bf16 shadow refresh."""
+
+    def __init__(self, model: HLVAE, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        dev = model.device
+        self.m1 = torch.zeros(model._arena_size, dtype=torch.float32, device=dev)
+        self.m2 = torch.zeros(model._arena_size, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step(self, grad_scale: float = 1.0):
+        m = self.model
+        lib = _lib.load()
+        _lib.check(lib.hlvae_adam_step(m._plan_handle, C.byref(m._ws), _lib.ptr(self.m1), _lib.ptr(self.m2),
+                                       _lib.ptr(self.step_count), C.c_float(self.lr), C.c_float(self.betas[0]),
+                                       C.c_float(self.betas[1]), C.c_float(self.eps), C.c_float(grad_scale), m._stream()),
+                   "hlvae_adam_step")
+        m.mark_shadows_fresh()
+
+
+class ELBOTrainer:
+    """One object per model: owns the optimiser state and (optionally) captured HIP graphs.
+
+    kl = "normal": closed-form KL(q(z|x) || N(0, I)) -- NOT in the reference (its only KL is the GP prior,
+                   SURVEY.md 0.3); this is the GP-free configuration of BASELINE.json configs 2-4.
+    kl = "gp":     the reference's GP-prior KL; ``gp`` must be a hlvae_amd.elbo_functions.GPPrior.
+    kl = None:     no KL term (reconstruction only).
+    """
+
+    def __init__(self, model: HLVAE, P_total: int, kl: Optional[str] = "normal", gp=None, lr: float = 1e-3,
+                 max_batch: int = 512, dp=None, metrics: bool = False):
+        if model.device.type != "cuda":
+            raise RuntimeError("ELBOTrainer needs the model on the GPU (no CPU fallback)")
+        self.model, self.P_total, self.kl, self.gp, self.dp, self.metrics = model, P_total, kl, gp, dp, metrics
+        model._max_batch = max(model._max_batch, max_batch)
+        model._ensure_device_state(max_batch)
+        self.opt = FusedAdam(model, lr=lr)
+        dev, L = model.device, model.z_dim
+        Bp = model._ws.Bp_max
+        self.g_mu = torch.zeros(Bp, L, dtype=torch.float32, device=dev)
+        self.g_lv = torch.zeros(Bp, L, dtype=torch.float32, device=dev)
+        self._graphs = {}
+
+    # -- the step, eager ------------------------------------------------------------------------
+    def step(self, data: torch.Tensor, mask: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None,
+             train_x: Optional[torch.Tensor] = None):
+        """data [B, X] fp64, mask [B, D] fp64 (already resident on the GPU), P_batch = subjects in the batch."""
+        m = self.model
+        lib = _lib.load()
+        B = data.shape[0]
+        m._ensure_device_state(B)
+        ws, s = C.byref(m._ws), m._stream()
+        if eps is None:
+            eps = torch.randn(B, m.z_dim, device=m.device, dtype=torch.float32)
+        scale = float(self.P_total) / float(P_batch)
+        hook = self.dp.allreduce_stats if self.dp is not None else None
+        # forward (+ head backward in the same pass: upstream gradient of log_p_x is -scale)
+        m._run_normalize(data, mask, B, hook)
+        _lib.check(lib.hlvae_encoder_fwd(m._plan_handle, ws, _lib.ptr(eps), B, s), "encoder_fwd")
+        _lib.check(lib.hlvae_zero_grad(m._plan_handle, ws, s), "zero_grad")
+        _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 1, int(self.metrics), B, s), "decoder_fwd")
+        g_mu = g_lv = None
+        if self.kl == "normal":
+            _lib.check(lib.hlvae_kl_std_normal(ws, B, m.z_dim, C.c_float(1.0), _lib.ptr(self.g_mu), _lib.ptr(self.g_lv), s), "kl")
+            g_mu, g_lv = self.g_mu, self.g_lv
+        elif self.kl == "gp":
+            g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch)
+        _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(eps), _lib.ptr(g_mu), _lib.ptr(g_lv), B, s), "backward")
+        m._fwd_token += 1
+        if self.dp is not None:
+            self.dp.allreduce_grads(m._grad_arena)
+        self.opt.step()
+        if self.kl == "gp":
+            self.gp.optimizer_step()
+
+    # -- captured -------------------------------------------------------------------------------
+    def capture(self, key, data: torch.Tensor, mask: torch.Tensor, P_batch: int, train_x=None):
+        """Capture one step reading the given (static) input tensors into a HIP graph."""
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # warm-up on the side stream (allocations, lazy init)
+                self.step(data, mask, P_batch, train_x=train_x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            self.step(data, mask, P_batch, train_x=train_x)
+        self._graphs[key] = g
+        return g
+
+    def replay(self, key):
+        self._graphs[key].replay()
+
+    # -- device-resident scalars (the reference's .item() values, training.py:139-143) ----------
+    def scalars(self):
+        sc = self.model._ws_t["scal"]
+        return {"nll_sum": sc[0], "kl": sc[1]}

@@ -164,6 +164,12 @@ int hlvae_kl_std_normal(const hlvae_ws* ws, int B, int L, float weight, float* g
 int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count,
                     float lr, float beta1, float beta2, float eps, float grad_scale, hlvae_stream s);
 
+/* Per-kernel HIP-event timing (bench.py's roofline leg): while enabled every kernel launch of this library is
+ * bracketed by hipEventRecord on its own stream.  hlvae_prof_report synchronises the device and writes one line
+ * "<kernel-label> <launches> <total_ms>" per label into buf.  Do not enable during hipGraph capture. */
+void hlvae_prof_enable(int on);
+int  hlvae_prof_report(char* buf, int buflen);
+
 /* generic bf16 NT GEMM  C[M][N] (fp32, ldc) = A[M][K] * B[N][K]^T, exposed for unit tests */
 int hlvae_gemm_nt_f32(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc,
                       int M, int N, int K, hlvae_stream s);

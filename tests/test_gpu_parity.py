@@ -89,8 +89,8 @@ def test_forward_backward_against_reference_fixture(golden_dir, name):
     p_samples, mu, lv, lpx, lpm, p_params, q_samples, q_params = model(data, mask, pmask, src.types_info, eps=eps)
     torch.cuda.synchronize()
     e_mu, e_lv = max_abs_err(mu.cpu(), g["mu"]), max_abs_err(lv.cpu(), g["log_var"])
-    e_lpx = np.abs(lpx.double().cpu().numpy() - g["log_p_x"])
-    e_lpm = np.abs(lpm.double().cpu().numpy() - g["log_p_x_missing"])
+    e_lpx = np.abs(lpx.detach().double().cpu().numpy() - g["log_p_x"])
+    e_lpm = np.abs(lpm.detach().double().cpu().numpy() - g["log_p_x_missing"])
     elbo = float(lpx.double().sum())
     elbo_ref = float(g["log_p_x"].sum())
     _report(name, mu=e_mu, lv=e_lv, lpx_max=e_lpx.max(), lpm_max=e_lpm.max(), elbo_rel=abs(elbo - elbo_ref) / abs(elbo_ref))
@@ -132,7 +132,7 @@ def test_test_samples_and_metrics_against_fixture(golden_dir):
     data, mask = torch.tensor(g["data"], device=dev), torch.tensor(g["mask"], device=dev)
     qs, qp, ps, pp, lpt, lpmt = model.get_test_samples(data, mask, None)
     assert max_abs_err(qp["z"][0].cpu(), g["test_mu"]) < 2e-2
-    assert np.all(np.abs(lpt.double().cpu().numpy() - g["test_log_p_x"]) <= 3e-2 + 2e-2 * np.abs(g["test_log_p_x"]))
+    assert np.all(np.abs(lpt.detach().double().cpu().numpy() - g["test_log_p_x"]) <= 3e-2 + 2e-2 * np.abs(g["test_log_p_x"]))
     assert torch.equal(qs["z"], qp["z"][0])          # decode(mean_qz): no noise (HLVAE.py:472)
     # imputed values (row M): x_hat of the deterministic pass agrees with statistics() on the oracle params
     xhat = model._ws_t["xhat"][:24].double().cpu().numpy()
@@ -191,6 +191,9 @@ def test_d4_batch512_against_oracle():
     assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss))
     sd = dict(model.named_parameters())
     for k, p in sd.items():
+        if p.grad is None or st[k].grad is None:
+            assert k == "_disp_param" or p.numel() == 0, k      # unused dispersion parameter / empty type block
+            continue
         e = rel_err(p.grad.double().cpu().numpy(), st[k].grad.numpy())
         _report("d4_b512_grads", **{k: e})
         assert e < 3e-2, (k, e)

@@ -10,14 +10,19 @@ MIX_SPEC = [("real", 1), ("cat", 3), ("pos", 1), ("ordinal", 4), ("count", 1), (
             ("ordinal", 5), ("pos", 1), ("cat", 5), ("count", 1), ("cat", 3), ("real", 1), ("ordinal", 4)]
 
 
+def _np(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().double().numpy()
+    return np.asarray(a, dtype=np.float64)
+
+
 def rel_err(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a, b = _np(a), _np(b)
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
 
 
 def max_abs_err(a, b):
-    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+    return float(np.max(np.abs(_np(a) - _np(b))))
 
 
 def load_mix_case(golden_dir, name):
