@@ -68,8 +68,10 @@ class _Anchor(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, data, mask, eps, B):
         ctx.model, ctx.B = model, B
-        ctx.data, ctx.mask, ctx.eps = data, mask, eps
+        ctx.data, ctx.mask = data, mask
+        ctx.set_materialize_grads(False)
         ctx.token = model._run_forward(data, mask, eps, B, want_params=True)
+        ctx.eps = model._ws_t["eps"][:B].clone()      # the noise actually used (given or generated in-kernel)
         mu, lv, z, lpx, lpm = model._clone_outputs(B)
         ctx.mark_non_differentiable(lpm)
         return mu, lv, z, lpx, lpm
@@ -77,9 +79,9 @@ class _Anchor(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_mu, g_lv, g_z, g_lpx, g_lpm):
         model, B = ctx.model, ctx.B
-        if g_z is not None and bool((g_z != 0).any()):
+        if g_z is not None:
             raise NotImplementedError("gradient through the latent sample z itself is not on the hot path")
-        if model._fwd_token != ctx.token:     # another forward overwrote the workspace: recompute
+        if model._fwd_token != ctx.token:     # another forward overwrote the workspace: recompute with the same noise
             model._run_forward(ctx.data, ctx.mask, ctx.eps, B, want_params=False)
         f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
         model._run_backward(ctx.eps, f32(g_lpx), f32(g_mu), f32(g_lv), B)
@@ -171,6 +173,7 @@ class HLVAE(nn.Module):
         self._shadow_versions = None
         self._fwd_token = 0
         self._block_cols = None
+        self._grad_region_clean = True
 
     # ------------------------------------------------------------------ arena / parameters
     def _bind_arena(self, arena: torch.Tensor):
@@ -297,9 +300,12 @@ class HLVAE(nn.Module):
         bf, f32 = torch.bfloat16, torch.float32
         z = lambda *s, dt=bf: torch.zeros(*s, dtype=dt, device=dev)
         ksteps_e, ksteps_d = d.Xp // 64, d.NYp // 64
-        # split-K so that (Bp/64)*(h/64)*S is about 2-3 waves of the 256 CUs, with no empty split
+        # split-K: a multiple of 8 slices when K allows it (one K-slice per XCD: each slice of the operands is pulled
+        # into exactly one L2), enough blocks for about two waves of the 256 CUs, and no empty split
         def pick(ksteps, tiles):
             S = max(1, min(ksteps, (640 + tiles - 1) // tiles))
+            if S >= 8:
+                S = (S // 8) * 8
             per = (ksteps + S - 1) // S
             return (ksteps + per - 1) // per
         S_e = pick(ksteps_e, (Bp // 64) * (d.hep // 64))
@@ -309,16 +315,18 @@ class HLVAE(nn.Module):
             G=z(self._arena_size, dt=f32),
             w1s=z(d.hep, d.Xp), wmls=z(2 * d.Lp, d.hep), wmlTs=z(d.hep, 2 * d.Lp), wds=z(d.hdp, d.Lp),
             wdTs=z(d.Lp, d.hdp), wys=z(d.NY, d.hdp), wyTs=z(d.hdp, d.NYp),
-            sums=z(3, max(d.n_stat, 1), dt=torch.float64), norm=z(2, max(d.n_stat, 1), dt=f32),
+            sums=z(_lib.STAT_CHUNKS, 3, max(d.n_stat, 1), dt=torch.float64), norm=z(2, max(d.n_stat, 1), dt=f32),
             xn=z(Bp, d.Xp), xnT=z(d.Xp, Bp), xt=z(Bp, d.D, dt=f32), m8=z(Bp, d.D, dt=torch.uint8),
             slab=z(max(S_e, S_d), Bp, max(d.hep, d.hdp), dt=f32),
             t=z(Bp, d.hep), tT=z(d.hep, Bp), mu=z(Bp, d.L, dt=f32), lv=z(Bp, d.L, dt=f32), z=z(Bp, d.L, dt=f32),
             zb=z(Bp, d.Lp), zbT=z(d.Lp, Bp), u=z(Bp, d.hdp), uT=z(d.hdp, Bp), dy=z(Bp, d.NYp), dyT=z(d.NY, Bp),
             log_p_x=z(Bp, d.D, dt=f32), log_p_x_missing=z(Bp, d.D, dt=f32), rowpart=z(NT, Bp, dt=f32),
-            nll=z(Bp, dt=f32), scal=z(8, dt=torch.float64), pfull=z(Bp, d.X, dt=f32), xhat=z(Bp, d.D, dt=f32),
+            nll=z(Bp, dt=f32), scal=z(8, dt=torch.float64), klpart=z(max(Bp // 64, 1), dt=torch.float64),
+            eps=z(Bp, d.L, dt=f32), rng=z(2, dt=torch.int64), pfull=z(Bp, d.X, dt=f32), xhat=z(Bp, d.D, dt=f32),
             du=z(Bp, d.hdp), duT=z(d.hdp, Bp), dz=z(Bp, d.Lp, dt=f32), dml=z(Bp, 2 * d.Lp), dmlT=z(2 * d.Lp, Bp),
             dt=z(Bp, d.hep), dtT=z(d.hep, Bp))
         t["P"] = self._arena
+        t["rng"][0] = int(torch.randint(0, 2 ** 62, (1,)).item())          # Philox seed from torch's global RNG
         ws = _lib.HlvaeWs()
         ws.Bp_max, ws.splitk_enc, ws.splitk_dec = Bp, S_e, S_d
         for name in _lib.WS_POINTERS:
@@ -359,10 +367,19 @@ class HLVAE(nn.Module):
             stats_hook(self._ws_t["sums"])          # data-parallel: all-reduce the masked column sums
         _lib.check(lib.hlvae_normalize_pack(self._plan_handle, ws, _lib.ptr(data), _lib.ptr(mask), B, s), "normalize_pack")
 
-    def _run_forward(self, data, mask, eps, B, want_params=True, g_scale=1.0, want_grad=False, stats_hook=None):
+    def _run_encoder(self, eps, sample, B):
+        """eps given -> that noise; eps None and sample -> in-kernel Philox noise (host offset advances per
+        call so eager calls never reuse a noise tensor); sample False -> z = mu."""
+        lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
+        self._rng_calls = getattr(self, "_rng_calls", 0) + 1
+        _lib.check(lib.hlvae_encoder_fwd(self._plan_handle, ws, _lib.ptr(eps), int(bool(sample)),
+                                         C.c_uint64(self._rng_calls << 32), B, s), "encoder_fwd")
+
+    def _run_forward(self, data, mask, eps, B, want_params=True, g_scale=1.0, want_grad=False, stats_hook=None,
+                     sample=True):
         lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
         self._run_normalize(data, mask, B, stats_hook)
-        _lib.check(lib.hlvae_encoder_fwd(self._plan_handle, ws, _lib.ptr(eps), B, s), "encoder_fwd")
+        self._run_encoder(eps, sample, B)
         if want_grad:
             _lib.check(lib.hlvae_zero_grad(self._plan_handle, ws, s), "zero_grad")
         _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, None, C.c_float(g_scale), int(want_grad), int(want_params),
@@ -381,7 +398,8 @@ class HLVAE(nn.Module):
         _lib.check(lib.hlvae_zero_grad(self._plan_handle, ws, s), "zero_grad")
         _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, _lib.ptr(g_lpx), C.c_float(0.0 if g_lpx is None else 1.0),
                                          1, 0, B, s), "decoder_fwd(grad)")
-        _lib.check(lib.hlvae_backward(self._plan_handle, ws, _lib.ptr(eps), _lib.ptr(g_mu), _lib.ptr(g_lv), B, s), "backward")
+        _lib.check(lib.hlvae_backward(self._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(0.0), B, s), "backward")
+        self._grad_region_clean = False
 
     def _assign_grads(self):
         G = self._grad_arena
@@ -457,13 +475,13 @@ class HLVAE(nn.Module):
     def forward(self, data, mask, param_mask, types_info, do_test=False, eps=None):
         """HLVAE.forward (HLVAE.py:364-375).  ``param_mask`` is implied by ``mask`` (each variable's bit
         repeated over its parameter slots, read_functions.py:173-176) and is not read.
-        ``eps`` (optional, [B, L]) fixes the reparameterisation noise; default: torch's CUDA RNG."""
+        ``eps`` (optional, [B, L]) fixes the reparameterisation noise; default: Philox4x32-10 normals generated
+        inside the encoder kernel (seeded once from torch's global RNG; the reference uses randn_like, HLVAE.py:361)."""
         data, mask = self._prep_inputs(data, mask)
         B = data.shape[0]
         self._ensure_device_state(B)
-        if eps is None:
-            eps = torch.randn(B, self.z_dim, device=self.device, dtype=torch.float32)
-        eps = eps.to(device=self.device, dtype=torch.float32).contiguous()
+        if eps is not None:
+            eps = eps.to(device=self.device, dtype=torch.float32).contiguous()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._order)
         if need_grad:
             mu, lv, z, lpx, lpm = _Anchor.apply(self._anchor, self, data, mask, eps, B)
@@ -483,9 +501,8 @@ class HLVAE(nn.Module):
         B = data.shape[0]
         self._ensure_device_state(B)
         lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
-        eps = torch.randn(B, self.z_dim, device=self.device, dtype=torch.float32) if self.training else None
         self._run_normalize(data, mask, B)
-        _lib.check(lib.hlvae_encoder_fwd(self._plan_handle, ws, _lib.ptr(eps), B, s), "encoder_fwd")
+        self._run_encoder(None, self.training, B)        # the reference samples in encode() (HLVAE.py:321)
         self._fwd_token += 1
         t = self._ws_t
         mu, lv, z = t["mu"][:B].clone(), t["lv"][:B].clone(), t["z"][:B].clone()
@@ -521,7 +538,7 @@ class HLVAE(nn.Module):
             data, mask = self._prep_inputs(data, miss_list)
             B = data.shape[0]
             self._ensure_device_state(B)
-            self._run_forward(data, mask, None, B, want_params=True)      # eps = None -> z = mu
+            self._run_forward(data, mask, None, B, want_params=True, sample=False)      # z = mu
             mu, lv, z, lpx, lpm = self._clone_outputs(B)
             p_params = {"x": self._p_params(B)}
             p_samples = {"x": self._p_samples(p_params["x"], B) if self.materialize_samples else None}

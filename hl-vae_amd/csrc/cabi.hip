@@ -14,16 +14,15 @@ int hl_launch_reduce_act(int, const float*, int, int, int, const float*, int, co
 int hl_launch_gemm_act(int, const bf16_t*, int, const bf16_t*, int, int, int, int, const float*, int, const bf16_t*,
                        bf16_t*, int, bf16_t*, int, int, float*, const char*, hipStream_t);
 int hl_launch_mid_fwd(int, const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, float*,
-                      float*, float*, bf16_t*, bf16_t*, int, int, int, hipStream_t);
+                      const uint64_t*, uint64_t, float*, float*, float*, bf16_t*, bf16_t*, int, int, int, double*, hipStream_t);
 int hl_launch_mid_bwd(int, const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*,
-                      const float*, float*, bf16_t*, bf16_t*, int, int, int, float*, float*, hipStream_t);
+                      const float*, const float*, float, float*, bf16_t*, bf16_t*, int, int, int, float*, float*, hipStream_t);
 int hl_launch_y_heads(const hlvae_plan*, const hlvae_ws*, const float*, float, int, int, int, int, hipStream_t);
 int hl_launch_scale_dy(const hlvae_plan*, const hlvae_ws*, const float*, int, int, hipStream_t);
 int hl_launch_stats(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, hipStream_t);
 int hl_launch_pack(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, int, hipStream_t);
 int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
 int hl_adam(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t);
-int hl_launch_kl_std(const hlvae_ws*, int, int, float, float*, float*, hipStream_t);
 
 static thread_local char g_err[512] = "";
 void hl_set_error(const char* fmt, ...) {
@@ -137,7 +136,17 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     hlvae_plan* p = new hlvae_plan();
     p->d = d;
     p->vars_dev = nullptr; p->col2var_dev = nullptr; p->stat_var_dev = nullptr;
-    hipError_t e = hipMalloc(&p->vars_dev, sizeof(hlvae_var) * d.D);
+    p->kmax = 2;
+    for (int i = 0; i < d.D; ++i)
+        if ((vars[i].kind == HLVAE_CAT || vars[i].kind == HLVAE_ORDINAL) && vars[i].ncls > p->kmax) p->kmax = vars[i].ncls;
+    for (auto& st : p->side) st = nullptr;
+    for (auto& ev : p->ev) ev = nullptr;
+    hipError_t e = hipSuccess;
+    for (auto& st : p->side)
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    for (auto& ev : p->ev)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&p->vars_dev, sizeof(hlvae_var) * d.D);
     if (e == hipSuccess) e = hipMalloc(&p->col2var_dev, sizeof(int32_t) * d.Xp);
     if (e == hipSuccess) e = hipMalloc(&p->stat_var_dev, sizeof(int32_t) * stat_var.size());
     if (e == hipSuccess) e = hipMemcpy(p->vars_dev, vars, sizeof(hlvae_var) * d.D, hipMemcpyHostToDevice);
@@ -157,6 +166,10 @@ void hlvae_plan_destroy(hlvae_plan* p) {
     if (p->vars_dev) (void)hipFree(p->vars_dev);
     if (p->col2var_dev) (void)hipFree(p->col2var_dev);
     if (p->stat_var_dev) (void)hipFree(p->stat_var_dev);
+    for (auto& st : p->side)
+        if (st) (void)hipStreamDestroy(st);
+    for (auto& ev : p->ev)
+        if (ev) (void)hipEventDestroy(ev);
     delete p;
 }
 
@@ -185,7 +198,8 @@ int hlvae_normalize_pack(const hlvae_plan* p, const hlvae_ws* ws, const double* 
     return hl_launch_pack(p, ws, data, mask, B, Bp, st);
 }
 
-int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int B, hlvae_stream s) {
+int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int sample, uint64_t rng_host_offset,
+                      int B, hlvae_stream s) {
     CHECK_B();
     int rc;
     HL_REQUIRE(ws->splitk_enc >= 1, HLVAE_EINVAL, "splitk_enc");
@@ -194,8 +208,9 @@ int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps,
     if ((rc = hl_launch_reduce_act(0, ws->slab, ws->splitk_enc, Bp, d.hep, ws->P + d.o_b1, d.h_e, nullptr, ws->t, ws->tT,
                                    Bp, B, nullptr, "enc1_reduce_relu", st))) return rc;
     // mean / log-var heads + clamp + reparameterisation
-    return hl_launch_mid_fwd(d.Lp, ws->t, d.hep, ws->wmls, d.hep, ws->P + d.o_bmu, ws->P + d.o_blv, eps, ws->mu, ws->lv,
-                             ws->z, ws->zb, ws->zbT, Bp, B, d.L, st);
+    return hl_launch_mid_fwd(d.Lp, ws->t, d.hep, ws->wmls, d.hep, ws->P + d.o_bmu, ws->P + d.o_blv, sample ? eps : nullptr,
+                             ws->eps, sample ? ws->rng : nullptr, rng_host_offset, ws->mu, ws->lv, ws->z, ws->zb, ws->zbT,
+                             Bp, B, d.L, ws->klpart, st);
 }
 
 int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, float g_scale, int want_grad,
@@ -220,35 +235,45 @@ int hlvae_zero_grad(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s) {
     return 0;
 }
 
-int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, const float* g_mu, const float* g_lv,
+int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
                    int B, hlvae_stream s) {
     CHECK_B();
     int rc;
     HL_REQUIRE(ws->splitk_dec >= 1, HLVAE_EINVAL, "splitk_dec");
+    // The weight-gradient GEMMs are leaves of the dependency graph: they run on two side streams (fork/join with
+    // events, so the structure is preserved under hipGraph capture) beside the critical path
+    //   dY -> dU -> d(mu, lv) -> dT -> dW1.
+    hipStream_t s0 = p->side[0], s1 = p->side[1];
+    HL_CHECK(hipEventRecord(p->ev[0], st));
+    HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
     // d Wy = dY^T U                                  [NY][h_d]
-    if ((rc = hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", st))) return rc;
+    if ((rc = hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
     // d U = (dY Wy) * relu'(U); d bd
     if ((rc = hl_launch_gemm_splitk(ws->dy, d.NYp, ws->wyTs, d.NYp, ws->slab, d.hdp, Bp, d.hdp, d.NYp, ws->splitk_dec, "dU_splitk", st))) return rc;
     if ((rc = hl_launch_reduce_act(1, ws->slab, ws->splitk_dec, Bp, d.hdp, nullptr, d.h_d, ws->u, ws->du, ws->duT, Bp, B,
                                    ws->G + d.o_bd, "dU_reduce_relu_bwd", st))) return rc;
+    HL_CHECK(hipEventRecord(p->ev[1], st));
+    HL_CHECK(hipStreamWaitEvent(s1, p->ev[1], 0));
     // d Wd = dU^T z                                  [h_d][L]
-    if ((rc = hl_launch_gemm_f32(ws->duT, Bp, ws->zbT, Bp, ws->G + d.o_wd, d.L, d.h_d, d.L, Bp, 0, 0, nullptr, "dWd", st))) return rc;
-    // d z -> d mu, d log_var (clamp + reparameterisation backward); d bmu, d blv
-    if ((rc = hl_launch_mid_bwd(d.Lp, ws->du, d.hdp, ws->wdTs, d.hdp, eps, ws->lv, g_mu, g_lv, ws->dz, ws->dml, ws->dmlT,
-                                Bp, B, d.L, ws->G + d.o_bmu, ws->G + d.o_blv, st))) return rc;
+    if ((rc = hl_launch_gemm_f32(ws->duT, Bp, ws->zbT, Bp, ws->G + d.o_wd, d.L, d.h_d, d.L, Bp, 0, 0, nullptr, "dWd", s1))) return rc;
+    // d z -> d mu, d log_var (clamp + reparameterisation backward, + KL(q||N(0,I)) gradient); d bmu, d blv
+    if ((rc = hl_launch_mid_bwd(d.Lp, ws->du, d.hdp, ws->wdTs, d.hdp, ws->eps, ws->lv, g_mu, g_lv, ws->mu, kl_std_weight,
+                                ws->dz, ws->dml, ws->dmlT, Bp, B, d.L, ws->G + d.o_bmu, ws->G + d.o_blv, st))) return rc;
+    HL_CHECK(hipEventRecord(p->ev[2], st));
+    HL_CHECK(hipStreamWaitEvent(s1, p->ev[2], 0));
     // d [Wmu; Wlv] = dml^T T                         2 x [L][h_e]
     if ((rc = hl_launch_gemm_f32(ws->dmlT, Bp, ws->tT, Bp, ws->G + d.o_wmu, d.h_e, 2 * d.Lp, d.h_e, Bp, d.Lp, d.L,
-                                 ws->G + d.o_wlv, "dWmu_dWlv", st))) return rc;
+                                 ws->G + d.o_wlv, "dWmu_dWlv", s1))) return rc;
     // d T = (dml [Wmu; Wlv]) * relu'(T); d b1
     if ((rc = hl_launch_gemm_act(1, ws->dml, 2 * d.Lp, ws->wmlTs, 2 * d.Lp, Bp, d.hep, 2 * d.Lp, nullptr, d.h_e, ws->t,
                                  ws->dt, d.hep, ws->dtT, Bp, B, ws->G + d.o_b1, "dT_relu_bwd", st))) return rc;
     // d W1 = dT^T Xn                                 [h_e][X]   (no input gradient for layer 1)
-    return hl_launch_gemm_f32(ws->dtT, Bp, ws->xnT, Bp, ws->G + d.o_w1, d.X, d.h_e, d.X, Bp, 0, 0, nullptr, "dW1", st);
-}
-
-int hlvae_kl_std_normal(const hlvae_ws* ws, int B, int L, float weight, float* g_mu, float* g_lv, hlvae_stream s) {
-    HL_REQUIRE(ws && B > 0 && L > 0, HLVAE_EINVAL, "kl_std_normal: bad arguments");
-    return hl_launch_kl_std(ws, B, L, weight, g_mu, g_lv, (hipStream_t)s);
+    if ((rc = hl_launch_gemm_f32(ws->dtT, Bp, ws->xnT, Bp, ws->G + d.o_w1, d.X, d.h_e, d.X, Bp, 0, 0, nullptr, "dW1", st))) return rc;
+    HL_CHECK(hipEventRecord(p->ev[3], s0));
+    HL_CHECK(hipEventRecord(p->ev[4], s1));
+    HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
+    HL_CHECK(hipStreamWaitEvent(st, p->ev[4], 0));
+    return 0;
 }
 
 int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr,

@@ -9,6 +9,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // one 16x16 accu
 typedef uint16_t bf16_t;                                        // storage type of bf16 buffers
 
 #define HL_THREADS 256
+#define HL_STAT_CHUNKS 16   // row chunks of the batch statistics (partial sums instead of atomics)
 #define HL_WAVE 64
 
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -34,11 +35,24 @@ __device__ __forceinline__ float sigmoid_f(float t) { return 1.f / (1.f + __expf
 
 static inline int ru(int v, int m) { return (v + m - 1) / m * m; }
 
+// XCD-aware block id: MI355X deals workgroups round-robin over its 8 XCDs (block b and b + 8 share an XCD and
+// its private 4 MiB L2).  This bijective remap gives every XCD a CONTIGUOUS range of logical ids, so that tiles
+// which share an operand panel (consecutive logical ids) hit the same L2 instead of pulling the panel through
+// the fabric eight times.  Speed only: results never depend on the placement.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 struct hlvae_plan {
     hlvae_dims d;
     hlvae_var* vars_dev;      // [D]
     int32_t* col2var_dev;     // [Xp]  variable of an expanded column, -1 in the padding
     int32_t* stat_var_dev;    // [n_stat] variable index of each statistics row
+    int kmax;                 // largest class count among cat / ordinal variables (selects the head-kernel instance)
+    // fork/join side streams: independent weight-gradient GEMMs run beside the critical path of the backward
+    hipStream_t side[2];
+    hipEvent_t ev[6];
 };
 
 void hl_set_error(const char* fmt, ...);

@@ -372,7 +372,7 @@ __device__ __forceinline__ void proc_ord(float* Cs, int v, int rg, int m0, int B
 }
 
 // arena offset of accumulator n of a variable (or -1)
-template <int YD>
+template <int YD, int KMAX>
 __device__ __forceinline__ int acc_dest(const hlvae_var& var, int n) {
     const int K = var.ncls;
     switch (var.kind) {
@@ -382,7 +382,7 @@ __device__ __forceinline__ int acc_dest(const hlvae_var& var, int n) {
         case HLVAE_COUNT:
             return n < YD ? var.w_off + n : (n == YD ? var.b_off : -1);
         case HLVAE_CAT: {
-            const int KM = K <= 3 ? 3 : (K <= 5 ? 5 : 8);
+            const int KM = (KMAX <= 3 || K <= 3) ? 3 : ((KMAX <= 5 || K <= 5) ? (KMAX < 5 ? KMAX : 5) : KMAX);
             if (n < YD * (KM - 1)) {
                 const int k = n / (KM - 1), j = n % (KM - 1);
                 return j < K - 1 ? var.w_off + k * (K - 1) + j : -1;
@@ -398,7 +398,7 @@ __device__ __forceinline__ int acc_dest(const hlvae_var& var, int n) {
     return -1;
 }
 
-template <int YD, int BM>
+template <int YD, int BM, int KMAX>
 __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
     const bf16_t* __restrict__ U, int ldu, const bf16_t* __restrict__ Wy, int K, const hlvae_var* __restrict__ vars,
     const float* __restrict__ P, float* __restrict__ G, long o_by, const float* __restrict__ norm, int n_stat,
@@ -409,10 +409,14 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
     constexpr int BN = 16 * YD;
     using Gm = GemmNT<BM, BN, 64, 4, 1>;
     constexpr int CLD = Gm::CLD;
-    constexpr int NACC = HeadAcc<YD, 8>::N;
+    constexpr int NACC = HeadAcc<YD, KMAX>::N;
     constexpr int RED_BYTES = 4 * 16 * NACC * 4;
     __shared__ __attribute__((aligned(16))) char smem[Gm::SMEM_BYTES + RED_BYTES];
-    const int tn = blockIdx.x, m0 = blockIdx.y * BM, n0 = tn * BN;
+    // 1-D grid, XCD-aware: the tiles_m row-blocks that share one 16-variable panel of Wy get consecutive
+    // logical ids and therefore one XCD's L2
+    const int tiles_m = Bp / BM;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = lid / tiles_m, m0 = (lid % tiles_m) * BM, n0 = tn * BN;
     const int NY = D * YD;
     typename Gm::Acc accm;
     Gm::zero(accm);
@@ -450,23 +454,23 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
                                               logpx_miss, pfull, X, xhat, acc, lpo);
                 break;
             case HLVAE_CAT:
-                if (var.ncls <= 3)
+                if (KMAX <= 3 || var.ncls <= 3)
                     proc_cat<YD, BM, CLD, NACC, 3>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
                                                    logpx_miss, pfull, X, xhat, acc, lpo);
-                else if (var.ncls <= 5)
-                    proc_cat<YD, BM, CLD, NACC, 5>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
-                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                else if (KMAX <= 5 || var.ncls <= 5)
+                    proc_cat<YD, BM, CLD, NACC, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem,
+                                                                      g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo);
                 else
-                    proc_cat<YD, BM, CLD, NACC, 8>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
-                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                    proc_cat<YD, BM, CLD, NACC, KMAX>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                      logpx_miss, pfull, X, xhat, acc, lpo);
                 break;
             case HLVAE_ORDINAL:
-                if (var.ncls <= 5)
-                    proc_ord<YD, BM, CLD, NACC, 5>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
-                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                if (KMAX <= 5 || var.ncls <= 5)
+                    proc_ord<YD, BM, CLD, NACC, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem,
+                                                                      g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo);
                 else
-                    proc_ord<YD, BM, CLD, NACC, 8>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
-                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                    proc_ord<YD, BM, CLD, NACC, KMAX>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                      logpx_miss, pfull, X, xhat, acc, lpo);
                 break;
         }
     } else {   // columns past the last variable: keep the tile clean
@@ -502,20 +506,25 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
         const int dd = tn * 16 + vv;
         if (dd >= D) continue;
         const hlvae_var vr = vars[dd];
-        const int dst = acc_dest<YD>(vr, n);
+        const int dst = acc_dest<YD, KMAX>(vr, n);
         if (dst < 0) continue;
         const float sum = red[(0 * 16 + vv) * NACC + n] + red[(1 * 16 + vv) * NACC + n] +
                           red[(2 * 16 + vv) * NACC + n] + red[(3 * 16 + vv) * NACC + n];
         atomicAdd(G + dst, sum);
     }
     // dY tile -> HBM (bf16, both layouts) and d by = column sums
-    for (int idx = tid; idx < BM * BN; idx += HL_THREADS) {
-        const int r = idx / BN, c = idx % BN;
-        if (n0 + c < NY) dy[(size_t)(m0 + r) * lddy + n0 + c] = f2bf(Cs[r * CLD + c]);
+    // (two bf16 per 32-bit store; columns in [NY, NYp) of the tile are zero, so pairs may spill into the padding)
+    for (int idx = tid; idx < BM * BN / 2; idx += HL_THREADS) {
+        const int r = idx / (BN / 2), c = (idx % (BN / 2)) * 2;
+        if (n0 + c < lddy)
+            *reinterpret_cast<uint32_t*>(dy + (size_t)(m0 + r) * lddy + n0 + c) =
+                (uint32_t)f2bf(Cs[r * CLD + c]) | ((uint32_t)f2bf(Cs[r * CLD + c + 1]) << 16);
     }
-    for (int idx = tid; idx < BM * BN; idx += HL_THREADS) {
-        const int c = idx / BM, r = idx % BM;
-        if (n0 + c < NY) dyT[(size_t)(n0 + c) * Bp + m0 + r] = f2bf(Cs[r * CLD + c]);
+    for (int idx = tid; idx < BM * BN / 2; idx += HL_THREADS) {
+        const int c = idx / (BM / 2), r = (idx % (BM / 2)) * 2;
+        if (n0 + c < NY)
+            *reinterpret_cast<uint32_t*>(dyT + (size_t)(n0 + c) * Bp + m0 + r) =
+                (uint32_t)f2bf(Cs[r * CLD + c]) | ((uint32_t)f2bf(Cs[(r + 1) * CLD + c]) << 16);
     }
     for (int c = tid; c < BN; c += HL_THREADS) {
         if (n0 + c >= NY) continue;
@@ -525,16 +534,39 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
     }
 }
 
-// nll[b] = -sum_tiles rowpart[t][b];  scal[0] = sum_b nll[b]   (HLVAE.py:377-379, training.py:104)
-__global__ void k_rowsum(const float* __restrict__ rowpart, int NT, int Bp, int B, float* __restrict__ nll,
-                         double* __restrict__ scal) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    float s = 0.f;
-    if (b < B)
-        for (int t = 0; t < NT; ++t) s += rowpart[(size_t)t * Bp + b];
-    if (b < Bp) nll[b] = -s;
-    double tot = wave_sum_d((double)(-s));
-    if ((threadIdx.x & 63) == 0) atomicAdd(scal, tot);
+// ELBO bookkeeping in ONE block (no atomics, no memset, deterministic):
+//   nll[b]  = -sum_tiles rowpart[t][b]                         (HLVAE.py:377-379)
+//   scal[0] = sum_b nll[b]                                     (training.py:104)
+//   scal[1] = sum of the per-block KL(q || N(0,I)) partials    (extension)
+//   rng[1] += 1: advances the Philox offset of the reparameterisation noise for the next step
+__global__ __launch_bounds__(1024) void k_elbo_finalize(const float* __restrict__ rowpart, int NT, int Bp, int B,
+                                                        float* __restrict__ nll, double* __restrict__ scal,
+                                                        const double* __restrict__ klpart, int nkl,
+                                                        uint64_t* __restrict__ rng) {
+    __shared__ double red[16];
+    double tot = 0.0;
+    for (int b = threadIdx.x; b < Bp; b += blockDim.x) {
+        float s = 0.f;
+        if (b < B) {
+#pragma unroll 9
+            for (int t = 0; t < NT; ++t) s += rowpart[(size_t)t * Bp + b];
+        }
+        nll[b] = -s;
+        tot += (double)(-s);
+    }
+    tot = wave_sum_d(tot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        scal[0] = t;
+        double k = 0.0;
+        if (klpart != nullptr)
+            for (int i = 0; i < nkl; ++i) k += klpart[i];
+        scal[1] = k;
+        if (rng != nullptr) rng[1] += 1;
+    }
 }
 
 // dY *= g[b][d] after the fact (autograd path with a non-uniform upstream gradient)
@@ -561,25 +593,22 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
     float* xh = want_params ? ws->xhat : nullptr;
     HL_REQUIRE(!want_params || (ws->pfull && ws->xhat), HLVAE_EINVAL, "want_params without pfull/xhat buffers");
     {
-    HL_PROF("y_heads_loglik", s);
-    if ((long)(Bp / 128) * NT >= 512) {
-        dim3 grid(NT, Bp / 128);
-        k_y_heads<5, 128><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,
-                                                      ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy,
-                                                      d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing, ws->rowpart,
-                                                      pf, d.X, xh, B, want_grad);
-    } else {
-        dim3 grid(NT, Bp / 64);
-        k_y_heads<5, 64><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,
-                                                     ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy,
-                                                     d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing, ws->rowpart,
-                                                     pf, d.X, xh, B, want_grad);
-    }
+        HL_PROF("y_heads_loglik", s);
+        const bool big = (long)(Bp / 128) * NT >= 512;
+        const int grid = NT * (big ? Bp / 128 : Bp / 64);
+#define HL_LAUNCH_HEADS(BMv, KMv)                                                                                      \
+        k_y_heads<5, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,  \
+                                                          ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, \
+                                                          d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing,       \
+                                                          ws->rowpart, pf, d.X, xh, B, want_grad)
+        if (p->kmax <= 3) { if (big) HL_LAUNCH_HEADS(128, 3); else HL_LAUNCH_HEADS(64, 3); }
+        else if (p->kmax <= 5) { if (big) HL_LAUNCH_HEADS(128, 5); else HL_LAUNCH_HEADS(64, 5); }
+        else { if (big) HL_LAUNCH_HEADS(128, 8); else HL_LAUNCH_HEADS(64, 8); }
+#undef HL_LAUNCH_HEADS
     }
     HL_LAUNCH_CHECK();
-    HL_CHECK(hipMemsetAsync(ws->scal, 0, sizeof(double), s));
-    HL_PROF("elbo_rowsum", s);
-    k_rowsum<<<(Bp + 255) / 256, 256, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal);
+    HL_PROF("elbo_finalize", s);
+    k_elbo_finalize<<<1, 1024, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal, ws->klpart, Bp / 64, ws->rng);
     HL_LAUNCH_CHECK();
     return 0;
 }

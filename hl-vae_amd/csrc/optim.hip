@@ -1,104 +1,178 @@
-// Adam on the flat fp32 arena (torch.optim.Adam semantics, reference HLVAE_main.py:277-278) and the
-// bf16 shadow copies of the dense weights that the MFMA kernels read.  HBM-bound: per parameter
-// 4 B grad + 3 x (4 B read + 4 B write) state, float4 per lane, grid-stride.
+// Adam on the flat fp32 arena (torch.optim.Adam semantics, reference HLVAE_main.py:277-278) fused with the
+// refresh of the bf16 shadow copies that the MFMA kernels read.  HBM-bound: per parameter 4 B grad +
+// 3 x (4 B read + 4 B write) state (+ 2-4 B of shadow).
+//
+// Two launches cover the arena:
+//   k_adam_flat   the "small" region [0, atomic_region): head parameters and biases, float4 per lane.
+//                 It also ZEROES the gradients it has consumed: that region is accumulated with atomics by
+//                 the next step, so no separate memset is needed.
+//   k_adam_tiled  the five dense weight matrices in 64 x 64 tiles: the updated tile is staged in LDS and
+//                 written as padded bf16 in both layouts (row-major shadow + transposed shadow).
 #include "common.h"
 
-__global__ __launch_bounds__(HL_THREADS) void k_adam(float* __restrict__ P, const float* __restrict__ G,
-                                                     float* __restrict__ M1, float* __restrict__ M2, long n4,
-                                                     const int64_t* __restrict__ step_count, float lr, float b1,
-                                                     float b2, float eps, float gscale) {
-    const float t = (float)(*step_count + 1);
-    const float bc1 = 1.f - powf(b1, t);
-    const float bc2 = 1.f - powf(b2, t);
-    const float step_size = lr / bc1;
-    const float rs_bc2 = rsqrtf(bc2);
+struct AdamScalars {
+    float step_size, rs_bc2, b1, b2, eps, gscale;
+};
+
+// step_count[0] = completed steps (read by k_adam_flat, which publishes step_count[1] = step_count[0] + 1);
+// k_adam_tiled reads step_count[1] and copies it back to step_count[0] when it is done.  One writer each,
+// ordered by the stream, so no separate "increment" launch is needed.
+__device__ __forceinline__ AdamScalars adam_scalars(float t, float lr, float b1, float b2, float eps, float gscale) {
+    AdamScalars a;
+    a.step_size = lr / (1.f - powf(b1, t));
+    a.rs_bc2 = rsqrtf(1.f - powf(b2, t));
+    a.b1 = b1; a.b2 = b2; a.eps = eps; a.gscale = gscale;
+    return a;
+}
+
+__device__ __forceinline__ float adam_one(float p, float g, float& m, float& v, const AdamScalars& a) {
+    g *= a.gscale;
+    m = a.b1 * m + (1.f - a.b1) * g;
+    v = a.b2 * v + (1.f - a.b2) * g * g;
+    return p - a.step_size * m / (sqrtf(v) * a.rs_bc2 + a.eps);
+}
+
+__global__ __launch_bounds__(HL_THREADS) void k_adam_flat(float* __restrict__ P, float* __restrict__ G,
+                                                          float* __restrict__ M1, float* __restrict__ M2, long n4,
+                                                          int64_t* __restrict__ step_count, float lr, float b1,
+                                                          float b2, float eps, float gscale, int zero_grad) {
+    const int64_t done = step_count[0];
+    const AdamScalars a = adam_scalars((float)(done + 1), lr, b1, b2, eps, gscale);
+    if (blockIdx.x == 0 && threadIdx.x == 0) step_count[1] = done + 1;
     float4* P4 = reinterpret_cast<float4*>(P);
-    const float4* G4 = reinterpret_cast<const float4*>(G);
+    float4* G4 = reinterpret_cast<float4*>(G);
     float4* M14 = reinterpret_cast<float4*>(M1);
     float4* M24 = reinterpret_cast<float4*>(M2);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 p = P4[i], g = G4[i], m = M14[i], v = M24[i];
-        float* pp = &p.x; float* gg = &g.x; float* mm = &m.x; float* vv = &v.x;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = gg[k] * gscale;
-            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
-            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
-            pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) * rs_bc2 + eps);
-        }
+        p.x = adam_one(p.x, g.x, m.x, v.x, a);
+        p.y = adam_one(p.y, g.y, m.y, v.y, a);
+        p.z = adam_one(p.z, g.z, m.z, v.z, a);
+        p.w = adam_one(p.w, g.w, m.w, v.w, a);
         P4[i] = p;
         M14[i] = m;
         M24[i] = v;
+        if (zero_grad) G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
-__global__ void k_inc_step(int64_t* step_count) { *step_count += 1; }
+struct ShadowMat {
+    long off;          // arena offset of the fp32 matrix [R][C] (dense)
+    int R, C;
+    bf16_t* dst;       // [..][ldd] row-major bf16, rows shifted by row_off
+    int ldd, row_off;
+    bf16_t* dstT;      // [..][ldT] transposed bf16 or nullptr
+    int ldT;
+    int Rcover, Ccover;   // region of dst (rows, cols) to fill, zero outside [R][C]
+    int tiles_c, tile0;   // tiles per row of tiles, first block index
+};
+struct ShadowSet {
+    ShadowMat m[5];
+    int n, total_tiles;
+};
 
-// fp32 [R][C] (dense, row stride C) -> bf16 [Rp][Cp] (zero padded) and optionally its transpose [Cp2][Rp2].
-// 64 x 64 tiles through LDS so both writes are coalesced.
-__global__ __launch_bounds__(HL_THREADS) void k_shadow(const float* __restrict__ src, int R, int C, bf16_t* __restrict__ dst,
-                                                       int ldd, int row_off, bf16_t* __restrict__ dstT, int ldT,
-                                                       int Rcover, int Ccover) {
+// update == 1: Adam step then shadows;  update == 0: shadows only (after load_state_dict / external optimiser)
+__global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float* __restrict__ P, const float* __restrict__ G,
+                                                           float* __restrict__ M1, float* __restrict__ M2,
+                                                           int64_t* __restrict__ step_count, float lr, float b1,
+                                                           float b2, float eps, float gscale, int update) {
     constexpr int T = 64, CLD = T + 1;
     __shared__ float tile[T * CLD];
-    const int c0 = blockIdx.x * T, r0 = blockIdx.y * T;
+    int mi = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k)
+        if (k < set.n && (int)blockIdx.x >= set.m[k].tile0) mi = k;
+    const ShadowMat mt = set.m[mi];
+    const int tl = blockIdx.x - mt.tile0;
+    const int r0 = (tl / mt.tiles_c) * T, c0 = (tl % mt.tiles_c) * T;
+    AdamScalars a;
+    if (update) a = adam_scalars((float)step_count[1], lr, b1, b2, eps, gscale);
     for (int idx = threadIdx.x; idx < T * T; idx += HL_THREADS) {
         const int r = idx / T, c = idx % T;
-        float v = 0.f;
-        if (r0 + r < R && c0 + c < C) v = src[(size_t)(r0 + r) * C + c0 + c];
-        tile[r * CLD + c] = v;
+        float pv = 0.f;
+        if (r0 + r < mt.R && c0 + c < mt.C) {
+            const long o = mt.off + (long)(r0 + r) * mt.C + c0 + c;
+            pv = P[o];
+            if (update) {
+                float m = M1[o], v = M2[o];
+                pv = adam_one(pv, G[o], m, v, a);
+                P[o] = pv;
+                M1[o] = m;
+                M2[o] = v;
+            }
+        }
+        tile[r * CLD + c] = pv;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < T * T; idx += HL_THREADS) {
         const int r = idx / T, c = idx % T;
-        if (r0 + r < Rcover && c0 + c < Ccover) dst[(size_t)(row_off + r0 + r) * ldd + c0 + c] = f2bf(tile[r * CLD + c]);
+        if (r0 + r < mt.Rcover && c0 + c < mt.Ccover)
+            mt.dst[(size_t)(mt.row_off + r0 + r) * mt.ldd + c0 + c] = f2bf(tile[r * CLD + c]);
     }
-    if (dstT != nullptr) {
+    if (mt.dstT != nullptr) {
         for (int idx = threadIdx.x; idx < T * T; idx += HL_THREADS) {
             const int c = idx / T, r = idx % T;
-            if (r0 + r < Rcover && c0 + c < Ccover)
-                dstT[(size_t)(c0 + c) * ldT + row_off + r0 + r] = f2bf(tile[r * CLD + c]);
+            if (r0 + r < mt.Rcover && c0 + c < mt.Ccover)
+                mt.dstT[(size_t)(c0 + c) * mt.ldT + mt.row_off + r0 + r] = f2bf(tile[r * CLD + c]);
         }
     }
+    if (update && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) step_count[0] = step_count[1];
 }
 
-static int shadow(const float* src, int R, int C, bf16_t* dst, int ldd, int row_off, bf16_t* dstT, int ldT, int Rcover,
-                  int Ccover, hipStream_t s) {
-    dim3 grid((Ccover + 63) / 64, (Rcover + 63) / 64);
-    HL_PROF("shadow_cast", s);
-    k_shadow<<<grid, HL_THREADS, 0, s>>>(src, R, C, dst, ldd, row_off, dstT, ldT, Rcover, Ccover);
-    HL_LAUNCH_CHECK();
-    return 0;
+static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws) {
+    const hlvae_dims& d = p->d;
+    ShadowSet s;
+    auto put = [&](int i, long off, int R, int C, bf16_t* dst, int ldd, int row_off, bf16_t* dstT, int ldT, int Rc, int Cc) {
+        ShadowMat& m = s.m[i];
+        m.off = off; m.R = R; m.C = C; m.dst = dst; m.ldd = ldd; m.row_off = row_off; m.dstT = dstT; m.ldT = ldT;
+        m.Rcover = Rc; m.Ccover = Cc;
+        m.tiles_c = (Cc + 63) / 64;
+    };
+    // Wy [NY][h_d] -> wys [NY][hdp] (+ [hdp][NYp]);  W1 [h_e][X] -> w1s [hep][Xp];
+    // Wd [h_d][L] -> wds [hdp][Lp] (+ [Lp][hdp]);  [Wmu; Wlv] [L][h_e] each -> wmls [2Lp][hep] (+ [hep][2Lp])
+    put(0, d.o_wy, d.NY, d.h_d, ws->wys, d.hdp, 0, ws->wyTs, d.NYp, d.NY, d.hdp);
+    put(1, d.o_w1, d.h_e, d.X, ws->w1s, d.Xp, 0, nullptr, 0, d.hep, d.Xp);
+    put(2, d.o_wd, d.h_d, d.L, ws->wds, d.Lp, 0, ws->wdTs, d.hdp, d.hdp, d.Lp);
+    put(3, d.o_wmu, d.L, d.h_e, ws->wmls, d.hep, 0, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep);
+    put(4, d.o_wlv, d.L, d.h_e, ws->wmls, d.hep, d.Lp, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep);
+    s.n = 5;
+    int t = 0;
+    for (int i = 0; i < 5; ++i) {
+        s.m[i].tile0 = t;
+        t += s.m[i].tiles_c * ((s.m[i].Rcover + 63) / 64);
+    }
+    s.total_tiles = t;
+    return s;
 }
 
 int hl_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s) {
-    const hlvae_dims& d = p->d;
-    int rc;
-    // W1 [h_e][X] -> w1s [hep][Xp]
-    if ((rc = shadow(ws->P + d.o_w1, d.h_e, d.X, ws->w1s, d.Xp, 0, nullptr, 0, d.hep, d.Xp, s))) return rc;
-    // [Wmu; Wlv] [L][h_e] each -> wmls [2Lp][hep] (+ transpose [hep][2Lp])
-    if ((rc = shadow(ws->P + d.o_wmu, d.L, d.h_e, ws->wmls, d.hep, 0, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep, s))) return rc;
-    if ((rc = shadow(ws->P + d.o_wlv, d.L, d.h_e, ws->wmls, d.hep, d.Lp, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep, s))) return rc;
-    // Wd [h_d][L] -> wds [hdp][Lp] (+ [Lp][hdp])
-    if ((rc = shadow(ws->P + d.o_wd, d.h_d, d.L, ws->wds, d.Lp, 0, ws->wdTs, d.hdp, d.hdp, d.Lp, s))) return rc;
-    // Wy [NY][h_d] -> wys [NY][hdp] (+ [hdp][NYp])
-    if ((rc = shadow(ws->P + d.o_wy, d.NY, d.h_d, ws->wys, d.hdp, 0, ws->wyTs, d.NYp, d.NY, d.hdp, s))) return rc;
+    const ShadowSet set = make_set(p, ws);
+    HL_PROF("shadow_cast", s);
+    k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0);
+    HL_LAUNCH_CHECK();
     return 0;
 }
 
 int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
             float b2, float eps, float gscale, hipStream_t s) {
     const hlvae_dims& d = p->d;
-    HL_REQUIRE(d.arena_size % 4 == 0, HLVAE_ESHAPE, "arena size %ld not a multiple of 4", (long)d.arena_size);
-    const long n4 = d.arena_size / 4;
+    HL_REQUIRE(d.atomic_region % 4 == 0, HLVAE_ESHAPE, "atomic region %ld not a multiple of 4", (long)d.atomic_region);
+    const long n4 = d.atomic_region / 4;
     int blocks = (int)((n4 + HL_THREADS - 1) / HL_THREADS);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    // the two launches touch disjoint parts of the arena; k_adam_tiled only needs step_count[1] from k_adam_flat,
+    // so the (tiny) flat launch goes first on the same stream and costs one boundary, no fork needed
     {
-    HL_PROF("adam", s);
-    k_adam<<<blocks, HL_THREADS, 0, s>>>(ws->P, ws->G, m1, m2, n4, step_count, lr, b1, b2, eps, gscale);
+        HL_PROF("adam_small", s);
+        k_adam_flat<<<blocks, HL_THREADS, 0, s>>>(ws->P, ws->G, m1, m2, n4, step_count, lr, b1, b2, eps, gscale, 1);
     }
     HL_LAUNCH_CHECK();
-    k_inc_step<<<1, 1, 0, s>>>(step_count);
+    const ShadowSet set = make_set(p, ws);
+    {
+        HL_PROF("adam_weights_shadows", s);
+        k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 1);
+    }
     HL_LAUNCH_CHECK();
-    return hl_refresh_shadows(p, ws, s);
+    return 0;
 }

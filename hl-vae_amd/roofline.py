@@ -30,15 +30,13 @@ def algorithmic_work(model, B):
     Pn = model._arena_size
     w = {}
     w["colstats"] = (B * d.n_stat * 16, 0)
-    w["finish_stats"] = (d.n_stat * 32, 0)
     w["normalize_pack"] = (B * (X + D) * 8 + 2 * B * Xp * 2 + B * D * 5, 0)
     w["enc1_splitk"] = ((B * Xp + hep * Xp) * 2 + S_e * B * hep * 4, 2 * B * X * he)
     w["enc1_reduce_relu"] = (S_e * B * hep * 4 + 2 * B * hep * 2, 0)
     w["enc_head_reparam"] = ((B * hep + 2 * Lp * hep) * 2 + B * L * 16 + 2 * B * Lp * 2, 2 * B * he * 2 * L)
     w["dec1_relu"] = ((B * Lp + hdp * Lp) * 2 + 2 * B * hdp * 2, 2 * B * L * hd)
     w["y_heads_loglik"] = ((B * hdp + NY * hdp) * 2 + B * D * 5 + 2 * B * NY * 2 + 2 * B * D * 4, 2 * B * NY * hd + 150 * B * D)
-    w["elbo_rowsum"] = (((D + 15) // 16) * B * 4, 0)
-    w["kl_std_normal"] = (B * L * 16, 0)
+    w["elbo_finalize"] = (((D + 15) // 16) * B * 4, 0)
     w["dWy"] = ((NY * Bp + hdp * Bp) * 2 + NY * hd * 4, 2 * B * NY * hd)
     w["dU_splitk"] = ((B * d.NYp + hdp * d.NYp) * 2 + S_d * B * hdp * 4, 2 * B * NY * hd)
     w["dU_reduce_relu_bwd"] = (S_d * B * hdp * 4 + 3 * B * hdp * 2, 0)
@@ -47,9 +45,11 @@ def algorithmic_work(model, B):
     w["dWmu_dWlv"] = ((2 * Lp * Bp + hep * Bp) * 2 + 2 * L * he * 4, 2 * B * 2 * L * he)
     w["dT_relu_bwd"] = ((B * 2 * Lp + hep * 2 * Lp) * 2 + 3 * B * hep * 2, 2 * B * 2 * L * he)
     w["dW1"] = ((hep * Bp + Xp * Bp) * 2 + he * X * 4, 2 * B * X * he)
-    w["adam"] = (Pn * 28, 0)
     n_w = he * X + 2 * L * he + hd * L + NY * hd
-    w["shadow_cast"] = (n_w * 4 + (he * X + 2 * (2 * L * he + hd * L + NY * hd)) * 2, 0)   # all 5 launches together
+    shadow_bytes = (he * X + 2 * (2 * L * he + hd * L + NY * hd)) * 2
+    w["adam_small"] = (model._atomic_region * 32, 0)
+    w["adam_weights_shadows"] = (n_w * 28 + shadow_bytes, 0)
+    w["shadow_cast"] = (n_w * 4 + shadow_bytes, 0)
     return w
 
 
@@ -80,8 +80,6 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None):
         per_step_launches = cnt / n
         avg_us = 1e3 * tot / cnt
         by, fl = work.get(name, (0, 0))
-        if name == "shadow_cast":          # five launches share one label; bytes are for all of them
-            by, fl = by / per_step_launches, 0
         table[name] = dict(launches_per_step=per_step_launches, avg_us=avg_us, us_per_step=avg_us * per_step_launches,
                            bytes=by, flops=fl)
     if not table:

@@ -33,7 +33,7 @@ class FusedAdam:
         dev = model.device
         self.m1 = torch.zeros(model._arena_size, dtype=torch.float32, device=dev)
         self.m2 = torch.zeros(model._arena_size, dtype=torch.float32, device=dev)
-        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.step_count = torch.zeros(2, dtype=torch.int64, device=dev)
 
     def step(self, grad_scale: float = 1.0):
         m = self.model
@@ -63,9 +63,6 @@ class ELBOTrainer:
         model._ensure_device_state(max_batch)
         self.opt = FusedAdam(model, lr=lr)
         dev, L = model.device, model.z_dim
-        Bp = model._ws.Bp_max
-        self.g_mu = torch.zeros(Bp, L, dtype=torch.float32, device=dev)
-        self.g_lv = torch.zeros(Bp, L, dtype=torch.float32, device=dev)
         self._graphs = {}
 
     # -- the step, eager ------------------------------------------------------------------------
@@ -77,26 +74,25 @@ class ELBOTrainer:
         B = data.shape[0]
         m._ensure_device_state(B)
         ws, s = C.byref(m._ws), m._stream()
-        if eps is None:
-            eps = torch.randn(B, m.z_dim, device=m.device, dtype=torch.float32)
         scale = float(self.P_total) / float(P_batch)
         hook = self.dp.allreduce_stats if self.dp is not None else None
-        # forward (+ head backward in the same pass: upstream gradient of log_p_x is -scale)
+        # forward (+ head backward in the same pass: upstream gradient of log_p_x is -scale).
+        # eps None -> reparameterisation noise from the in-kernel Philox stream (device-side offset: graph safe)
         m._run_normalize(data, mask, B, hook)
-        _lib.check(lib.hlvae_encoder_fwd(m._plan_handle, ws, _lib.ptr(eps), B, s), "encoder_fwd")
-        _lib.check(lib.hlvae_zero_grad(m._plan_handle, ws, s), "zero_grad")
+        _lib.check(lib.hlvae_encoder_fwd(m._plan_handle, ws, _lib.ptr(eps), 1, C.c_uint64(0), B, s), "encoder_fwd")
+        if not m._grad_region_clean:     # normally the fused Adam leaves the atomically-accumulated region zeroed
+            _lib.check(lib.hlvae_zero_grad(m._plan_handle, ws, s), "zero_grad")
         _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 1, int(self.metrics), B, s), "decoder_fwd")
         g_mu = g_lv = None
-        if self.kl == "normal":
-            _lib.check(lib.hlvae_kl_std_normal(ws, B, m.z_dim, C.c_float(1.0), _lib.ptr(self.g_mu), _lib.ptr(self.g_lv), s), "kl")
-            g_mu, g_lv = self.g_mu, self.g_lv
-        elif self.kl == "gp":
+        kl_w = 1.0 if self.kl == "normal" else 0.0
+        if self.kl == "gp":
             g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch)
-        _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(eps), _lib.ptr(g_mu), _lib.ptr(g_lv), B, s), "backward")
+        _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), B, s), "backward")
         m._fwd_token += 1
         if self.dp is not None:
             self.dp.allreduce_grads(m._grad_arena)
         self.opt.step()
+        m._grad_region_clean = True
         if self.kl == "gp":
             self.gp.optimizer_step()
 

@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 1
+#define HLVAE_ABI_VERSION 2
+#define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define HLVAE_ESHAPE (-2)   /* operand shapes do not match what the kernel grid assumes */
@@ -82,7 +83,7 @@ typedef struct {
     uint16_t* wys;       /* bf16 shadow  [NY][hdp]   of Wy                                  */
     uint16_t* wyTs;      /* [hdp][NYp]                                                      */
     /* batch statistics (row A) */
-    double* sums;        /* [3][n_stat]  sum m, sum x m, sum x^2 m (x = d or log1p d)       */
+    double* sums;        /* [HLVAE_STAT_CHUNKS][3][n_stat] per-row-chunk partial sums of m, x m, x^2 m (x = d or log1p d) */
     float* norm;         /* [2][n_stat]  mean, var (var of pos already clamped to [1e-6,1e20]) */
     /* packed inputs */
     uint16_t* xn;        /* [Bp][Xp]  normalised encoder input, bf16                        */
@@ -99,7 +100,10 @@ typedef struct {
     float* log_p_x; float* log_p_x_missing;   /* [Bp][D]                                    */
     float* rowpart;      /* [ceil(D/16)][Bp] partial row sums of log_p_x                    */
     float* nll;          /* [Bp]  -sum_d log_p_x                                            */
-    double* scal;        /* [8]: 0 = sum_b nll, 1 = standard-normal KL (extension), 2.. reserved */
+    double* scal;        /* [8]: 0 = sum_b nll, 1 = KL(q || N(0,I)) of the batch (extension), 2.. reserved */
+    double* klpart;      /* [Bp/64] per-block KL partial sums                                */
+    float* eps;          /* [Bp][L] reparameterisation noise actually used (kept for backward) */
+    uint64_t* rng;       /* [2]: Philox seed, offset (advanced by one per step on device)    */
     float* pfull;        /* [Bp][X]  likelihood parameters concatenated by key (row M), optional */
     float* xhat;         /* [Bp][D]  per-variable imputed value (statistics mean), optional */
     /* backward activations */
@@ -133,8 +137,11 @@ int hlvae_normalize_pack(const hlvae_plan* p, const hlvae_ws* ws, const double* 
                          int B, hlvae_stream s);
 
 /* rows B + C -- HLVAE.encode MLP branch (HLVAE.py:311-324) + sample_latent (:351-362).
- * eps [B][L] fp32; eps == NULL means z = mu (get_test_samples, HLVAE.py:472). */
-int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int B, hlvae_stream s);
+ * noise: eps != NULL -> that [B][L] fp32 tensor;  eps == NULL && sample != 0 -> Philox4x32-10 normals generated in
+ * the kernel from ws->rng (+ rng_host_offset);  sample == 0 -> z = mu (get_test_samples, HLVAE.py:472).
+ * The noise used is kept in ws->eps for hlvae_backward.  Also writes the per-block partials of KL(q || N(0,I)). */
+int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int sample, uint64_t rng_host_offset,
+                      int B, hlvae_stream s);
 
 /* rows D-J -- HLVAE.decode (HLVAE.py:326-349): decoder trunk, y_layer, theta_estimation (:416-453),
  * loglik_{real,pos,count,cat,ordinal} (HL_VAE/loglik.py) and the scatter/ELBO row sums (HLVAE.py:377-414).
@@ -148,19 +155,18 @@ int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_lo
 /* rescale ws->dy by a per-element upstream gradient after the fact (autograd path) */
 int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, int B, hlvae_stream s);
 
-/* backward of rows B-D: all dense-layer gradients into ws->G.
- * g_mu, g_lv: upstream gradients of mu / log_var from the KL term ([B][L] fp32, may be NULL). */
-int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, const float* g_mu,
-                   const float* g_lv, int B, hlvae_stream s);
+/* backward of rows B-D: all dense-layer gradients into ws->G (reads the noise from ws->eps).
+ * g_mu, g_lv: upstream gradients of mu / log_var from the KL term ([B][L] fp32, may be NULL);
+ * kl_std_weight != 0 adds the gradient of kl_std_weight * KL(q(z|x) || N(0,I)) in the same kernel
+ * (closed form; NOT in the reference). */
+int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv,
+                   float kl_std_weight, int B, hlvae_stream s);
 /* zero the atomically accumulated gradient region; call before hlvae_decoder_fwd(want_grad=1) */
 int hlvae_zero_grad(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s);
 
-/* closed-form KL(q(z|x) || N(0,I)) value + its gradient (NOT in the reference) */
-int hlvae_kl_std_normal(const hlvae_ws* ws, int B, int L, float weight, float* g_mu, float* g_lv,
-                        hlvae_stream s);
-
 /* torch.optim.Adam(lr) step on the flat arena (HLVAE_main.py:277-278) fused with the bf16 shadow refresh.
- * step_count: device int64 incremented by the kernel (graph-capture safe). grad_scale multiplies G first. */
+ * step_count: device int64[2] advanced by the kernels (graph-capture safe). grad_scale multiplies G first.
+ * The small-parameter gradient region [0, atomic_region) is zeroed after it is consumed. */
 int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count,
                     float lr, float beta1, float beta2, float eps, float grad_scale, hlvae_stream s);
 

@@ -93,8 +93,10 @@ def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.
     return st
 
 
-def batch_normalization(data, mask, blocks, conv=False):
-    """Row A.  HL_VAE/utils.py:88-143 (MLP path: types_info['conv'] False)."""
+def batch_normalization(data, mask, blocks, conv=False, stats=None):
+    """Row A.  HL_VAE/utils.py:88-143 (MLP path: types_info['conv'] False).
+    ``stats`` (test-only): [[mean, var]_real, [mean, var]_pos] to use instead of this batch's own statistics
+    (the data-parallel tests normalise a shard with the statistics of the global batch)."""
     out = torch.zeros_like(data)
     norm = [[], []]
     for b in blocks:
@@ -107,6 +109,8 @@ def batch_normalization(data, mask, blocks, conv=False):
                 continue
             mean = (obs * m).sum(0) / m.sum(0)                            # :105
             var = torch.sum(((obs - mean) * m) ** 2, 0) / m.sum(0)        # :106
+            if stats is not None:
+                mean, var = stats[0]
             out[:, b["exp"]] = (obs - mean[None, :]) / torch.sqrt(var + 1e-5) * m   # :107
             norm[0] = [mean, var]
         elif b["type"] == "count":
@@ -119,6 +123,8 @@ def batch_normalization(data, mask, blocks, conv=False):
             mean = (lg * m).sum(0) / m.sum(0)                             # :126
             var = torch.sum(((lg - mean) * m) ** 2, 0) / m.sum(0)         # :127
             var = torch.clamp(var, 1e-6, 1e20)                            # :128
+            if stats is not None:
+                mean, var = stats[1]
             out[:, b["exp"]] = (lg - mean[None, :]) / torch.sqrt(var + 1e-5) * m    # :129
             norm[1] = [mean, var]
         else:                                                             # cat / ordinal :133-139
@@ -242,9 +248,9 @@ class OracleHLVAE:
         log_p_x, log_p_x_missing, params = loglik_blocks(theta, data, mask, self.blocks, self.st, norm)
         return log_p_x, log_p_x_missing, params, theta
 
-    def forward(self, data, mask, eps):
+    def forward(self, data, mask, eps, stats=None):
         """HLVAE.forward (HLVAE.py:364-375) with explicit noise.  Returns a dict."""
-        X_list, norm = batch_normalization(data, mask, self.blocks, conv=False)
+        X_list, norm = batch_normalization(data, mask, self.blocks, conv=False, stats=stats)
         mu, lv = self.encode_params(X_list)
         z = mu + eps * torch.exp(0.5 * lv)                                # row C: HLVAE.py:360-362
         log_p_x, log_p_x_missing, params, theta = self.decode(z, data, mask, norm)
