@@ -72,6 +72,7 @@ struct ShadowSet {
 };
 
 // update == 1: Adam step then shadows;  update == 0: shadows only (after load_state_dict / external optimiser)
+// float4 per lane along the columns (C % 4 == 0 and 16-B aligned segments are checked on the host)
 __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float* __restrict__ P, const float* __restrict__ G,
                                                            float* __restrict__ M1, float* __restrict__ M2,
                                                            int64_t* __restrict__ step_count, float lr, float b1,
@@ -87,33 +88,49 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
     const int r0 = (tl / mt.tiles_c) * T, c0 = (tl % mt.tiles_c) * T;
     AdamScalars a;
     if (update) a = adam_scalars((float)step_count[1], lr, b1, b2, eps, gscale);
-    for (int idx = threadIdx.x; idx < T * T; idx += HL_THREADS) {
-        const int r = idx / T, c = idx % T;
-        float pv = 0.f;
-        if (r0 + r < mt.R && c0 + c < mt.C) {
-            const long o = mt.off + (long)(r0 + r) * mt.C + c0 + c;
-            pv = P[o];
+    const int c4 = (threadIdx.x & 15) * 4, rq = threadIdx.x >> 4;      // 16 float4 per tile row, 16 rows per pass
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = rq + 16 * i;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < mt.R && c0 + c4 < mt.C) {        // C % 4 == 0: the float4 is entirely inside the row
+            const long o = mt.off + (long)(r0 + r) * mt.C + c0 + c4;
+            p = *reinterpret_cast<const float4*>(P + o);
             if (update) {
-                float m = M1[o], v = M2[o];
-                pv = adam_one(pv, G[o], m, v, a);
-                P[o] = pv;
-                M1[o] = m;
-                M2[o] = v;
+                const float4 g = *reinterpret_cast<const float4*>(G + o);
+                float4 m = *reinterpret_cast<const float4*>(M1 + o), v = *reinterpret_cast<const float4*>(M2 + o);
+                p.x = adam_one(p.x, g.x, m.x, v.x, a);
+                p.y = adam_one(p.y, g.y, m.y, v.y, a);
+                p.z = adam_one(p.z, g.z, m.z, v.z, a);
+                p.w = adam_one(p.w, g.w, m.w, v.w, a);
+                *reinterpret_cast<float4*>(P + o) = p;
+                *reinterpret_cast<float4*>(M1 + o) = m;
+                *reinterpret_cast<float4*>(M2 + o) = v;
             }
         }
-        tile[r * CLD + c] = pv;
+        if (r0 + r < mt.Rcover && c0 + c4 < mt.Ccover) {        // row-major shadow: 4 bf16 = one 8-byte store
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(p.x) | ((uint32_t)f2bf(p.y) << 16);
+            pk.y = (uint32_t)f2bf(p.z) | ((uint32_t)f2bf(p.w) << 16);
+            *reinterpret_cast<uint2*>(mt.dst + (size_t)(mt.row_off + r0 + r) * mt.ldd + c0 + c4) = pk;
+        }
+        if (mt.dstT != nullptr) {
+            tile[r * CLD + c4 + 0] = p.x; tile[r * CLD + c4 + 1] = p.y;
+            tile[r * CLD + c4 + 2] = p.z; tile[r * CLD + c4 + 3] = p.w;
+        }
     }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < T * T; idx += HL_THREADS) {
-        const int r = idx / T, c = idx % T;
-        if (r0 + r < mt.Rcover && c0 + c < mt.Ccover)
-            mt.dst[(size_t)(mt.row_off + r0 + r) * mt.ldd + c0 + c] = f2bf(tile[r * CLD + c]);
-    }
-    if (mt.dstT != nullptr) {
-        for (int idx = threadIdx.x; idx < T * T; idx += HL_THREADS) {
-            const int c = idx / T, r = idx % T;
-            if (r0 + r < mt.Rcover && c0 + c < mt.Ccover)
-                mt.dstT[(size_t)(c0 + c) * mt.ldT + mt.row_off + r0 + r] = f2bf(tile[r * CLD + c]);
+    if (mt.dstT != nullptr) {          // block-uniform branch
+        __syncthreads();
+        const int r4 = (threadIdx.x & 15) * 4, cq = threadIdx.x >> 4;   // lane -> (column, 4 consecutive rows)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cq + 16 * i;
+            if (r0 + r4 < mt.Rcover && c0 + c < mt.Ccover) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(tile[(r4 + 0) * CLD + c]) | ((uint32_t)f2bf(tile[(r4 + 1) * CLD + c]) << 16);
+                pk.y = (uint32_t)f2bf(tile[(r4 + 2) * CLD + c]) | ((uint32_t)f2bf(tile[(r4 + 3) * CLD + c]) << 16);
+                *reinterpret_cast<uint2*>(mt.dstT + (size_t)(c0 + c) * mt.ldT + mt.row_off + r0 + r4) = pk;
+            }
         }
     }
     if (update && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) step_count[0] = step_count[1];
@@ -145,8 +162,21 @@ static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws) {
     return s;
 }
 
+static int check_set(const ShadowSet& s) {
+    for (int i = 0; i < s.n; ++i) {
+        const ShadowMat& m = s.m[i];
+        // (a 4-row group of the transposed shadow may run past Rcover: it lands in the zero padding, ldT >= ru(Rcover, 4))
+        HL_REQUIRE(m.C % 4 == 0 && m.off % 4 == 0 && m.ldd % 4 == 0 && m.Ccover % 4 == 0 &&
+                       (m.dstT == nullptr || (m.ldT % 4 == 0 && m.row_off % 4 == 0 && m.ldT >= m.row_off + ru(m.Rcover, 4))),
+                   HLVAE_ESHAPE, "weight matrix %d: hidden / latent / input widths must be multiples of 4 (C=%d off=%ld)", i,
+                   m.C, m.off);
+    }
+    return 0;
+}
+
 int hl_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s) {
     const ShadowSet set = make_set(p, ws);
+    if (int rc = check_set(set)) return rc;
     HL_PROF("shadow_cast", s);
     k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0);
     HL_LAUNCH_CHECK();
@@ -169,6 +199,7 @@ int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64
     }
     HL_LAUNCH_CHECK();
     const ShadowSet set = make_set(p, ws);
+    if (int rc = check_set(set)) return rc;
     {
         HL_PROF("adam_weights_shadows", s);
         k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 1);

@@ -93,41 +93,53 @@ __global__ __launch_bounds__(HL_PACK_THREADS) void k_normalize_pack(
     }
     __syncthreads();
     const float mean = s_mean[c], rstd = s_rstd[c];
+    // Unconditional loads from clamped rows (no branches around the loads), 32-bit offsets from two base pointers.
+    const bool has_col = kind >= 0;
+    const double* dcol = data + (has_col ? x : 0);
+    const double* mcol = mask + d;
+    const bool logk = (kind == HLVAE_POS) || (kind == HLVAE_COUNT);
+    const bool disc = (kind == HLVAE_CAT) || (kind == HLVAE_ORDINAL);
+    const bool fits = c + K <= T;                      // the variable's K columns sit inside this 64-lane tile
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = rq + 16 * i, b = b0 + r;
-        float out = 0.f;
-        if (b < B && kind >= 0) {
-            const bool ob = mask[(size_t)b * D + d] != 0.0;
-            const float raw = (float)data[(size_t)b * X + x];
-            if (kind == HLVAE_REAL) out = ob ? (raw - mean) * rstd : 0.f;
-            else if (kind == HLVAE_POS) out = ob ? (log1pf(raw) - mean) * rstd : 0.f;
-            else if (kind == HLVAE_COUNT) out = ob ? __logf(raw) : 0.f;     // :116-121
-            else out = ob ? raw : 0.f;                                       // cat / ordinal: d * mask (:133-139)
-            if (first) {                                                     // likelihood target + mask of the variable
-                float tv;
-                if (kind == HLVAE_REAL || kind == HLVAE_COUNT) {
-                    tv = raw;
-                } else if (kind == HLVAE_POS) {
-                    tv = log1pf(raw);                                        // loglik.py:84
-                } else if (kind == HLVAE_CAT) {                              // one-hot -> class index, -1 if all zero
+        const int bc = min(b, B - 1);
+        const float raw = (float)dcol[(size_t)bc * X];
+        const bool ob = (mcol[(size_t)bc * D] != 0.0) && (b < B) && has_col;
+        float fr = raw;
+        if (logk) fr = (kind == HLVAE_POS) ? log1pf(raw) : __logf(raw);       // utils.py:125 / :118
+        tile[r * CLD + c] = ob ? (fr - mean) * rstd : 0.f;                    // mean = 0, rstd = 1 unless real / pos
+        // likelihood target of the variable: the first lane of a cat / ordinal variable collects the other K-1
+        // columns from its neighbour lanes (shuffles are executed by every lane of the wave)
+        float nb[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) nb[k] = __shfl_down(raw, k + 1, 64);
+        if (first && b < B) {
+            float tv = logk && kind == HLVAE_POS ? fr : raw;                  // real, count: raw x; pos: log1p x
+            if (disc) {
+                float v[8];
+                v[0] = raw;
+#pragma unroll
+                for (int k = 1; k < 8; ++k)
+                    v[k] = (k < K) ? (fits ? nb[k - 1] : (float)dcol[(size_t)bc * X + k]) : 0.f;
+                if (kind == HLVAE_CAT) {                  // one-hot -> class index, -1 if the row is all zero
                     int cls = -1;
-                    double best = 0.0;
-                    for (int k = 0; k < K; ++k) {
-                        const double v = data[(size_t)b * X + x + k];
-                        if (v > best) { best = v; cls = k; }
-                    }
+                    float best = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < K && v[k] > best) { best = v[k]; cls = k; }
                     tv = (float)cls;
-                } else {                                                     // thermometer -> sum(int(data)) - 1 (loglik.py:172)
+                } else {                                  // thermometer -> sum(int(data)) - 1 (loglik.py:172)
                     int sum = 0;
-                    for (int k = 0; k < K; ++k) sum += (int)data[(size_t)b * X + x + k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (k < K) sum += (int)v[k];
                     tv = (float)(sum - 1);
                 }
-                xt[(size_t)b * D + d] = tv;
-                m8[(size_t)b * D + d] = ob ? 1 : 0;
             }
+            xt[(size_t)b * D + d] = tv;
+            m8[(size_t)b * D + d] = ob ? 1 : 0;
         }
-        tile[r * CLD + c] = out;
     }
     __syncthreads();
     // row-major: 2 columns per lane (one 32-bit store), transposed: 2 rows per lane

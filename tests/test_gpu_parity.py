@@ -302,3 +302,51 @@ def test_inkernel_noise_statistics():
     assert abs(float(e1.mean())) < 0.03 and abs(float(e1.var()) - 1.0) < 0.05
     assert float((e1 - e2).abs().max()) > 0.5
     assert abs(float((e1 * e2).mean())) < 0.03
+
+
+def test_gp_prior_training_step_against_oracle(golden_dir):
+    """row K on the device: one fused step with the GP-prior KL (batched fp64 torch-ROCm ops feeding g_mu / g_lv into the
+    HIP backward) against the oracles: NLL, KL value, and the direction of the first Adam update."""
+    import hlvae_oracle as orc
+    import gp_oracle as gpo
+    from hlvae_amd.elbo_functions import GPPrior
+    from hlvae_amd.training import ELBOTrainer
+    dev = _dev()
+    src = synthetic.make_tabular(n_rows=48, T=6, seed=7, spec=MIX_SPEC)
+    dims = [src.cov_dim_ext, [16], 4, [16], 5]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=5, std=0.2)
+    model = _model_from_state(src, dims, state)
+    labels = torch.tensor(src.labels, device=dev)
+    gp = GPPrior(dims[2], labels, M=10, id_covariate=2, N_total=480, seed=3)
+    m0, H0, z0 = gp.m.clone(), gp.H.clone(), gp.zt_list.detach().clone()
+    tr = ELBOTrainer(model, P_total=80, kl="gp", gp=gp, max_batch=128)
+    eps = torch.randn(48, dims[2], generator=torch.Generator().manual_seed(9))
+    data, mask = torch.tensor(src.data, device=dev), torch.tensor(src.mask, device=dev)
+    tr.step(data, mask, 8, eps=eps.to(dev), train_x=labels)
+    torch.cuda.synchronize()
+    nll_gpu, kld_gpu = float(tr.scalars()["nll_sum"]), float(gp.last_kld)
+    # oracle
+    st = {k: v.double().clone().requires_grad_(True) for k, v in state.items() if not k.startswith("hidden.")}
+    for k in list(st):
+        if k.startswith("d_layers."):
+            st["hidden." + k[len("d_layers."):]] = st[k]
+    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st)
+    out = om.forward(torch.tensor(src.data), torch.tensor(src.mask), eps.double())
+    spec = gpo.spec_from_config([2], [], [0], [{"cont_covariate": 0, "cat_covariate": 2}, {"cont_covariate": 0, "cat_covariate": 3},
+                                               {"cont_covariate": 1, "cat_covariate": 4}], [], 2)
+    kprm = gpo.init_kernel_params(spec, dims[2])
+    kld, gm, gH = gpo.minibatch_kld_upper_bound_iter(spec, kprm, torch.ones(dims[2], dtype=torch.float64), dims[2], m0.cpu(), H0.cpu(),
+                                                     torch.tensor(src.labels), out["mu"], out["log_var"], z0.cpu(), 80, 8, 480,
+                                                     True, 2, 1e-6)
+    nll = om.loss_function(out["log_p_x"]).sum()
+    (nll * 80 / 8 + kld.sum()).backward()
+    assert abs(nll_gpu - float(nll)) <= 1e-3 * abs(float(nll))
+    assert abs(kld_gpu - float(kld)) <= 1e-3 * abs(float(kld)) + 1e-2
+    # Adam's first update is -lr * sign(g): the encoder weights feel the GP gradient through mu / log_var
+    w = dict(model.named_parameters())["mean_layer.0.weight"].detach().double().cpu()
+    delta = w - state["mean_layer.0.weight"].double()
+    gref = st["mean_layer.0.weight"].grad
+    big = gref.abs() > 0.05 * gref.abs().max()
+    assert (torch.sign(delta[big]) == -torch.sign(gref[big])).double().mean() > 0.97
+    m_ref, H_ref = gpo.natural_gradient_update(m0.cpu(), H0.cpu(), gm.detach(), gH.detach(), 0.01)
+    assert rel_err(gp.m.cpu(), m_ref) < 1e-2 and rel_err(gp.H.cpu(), H_ref) < 1e-2
