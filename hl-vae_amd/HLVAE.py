@@ -383,13 +383,13 @@ class HLVAE(nn.Module):
         if want_grad:
             _lib.check(lib.hlvae_zero_grad(self._plan_handle, ws, s), "zero_grad")
         _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, None, C.c_float(g_scale), int(want_grad), int(want_params),
-                                         B, s), "decoder_fwd")
+                                         0, B, s), "decoder_fwd")
         self._fwd_token += 1
         return self._fwd_token
 
     def _run_decoder_only(self, B, want_params=True):
         lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
-        _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, None, C.c_float(1.0), 0, int(want_params), B, s), "decoder_fwd")
+        _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, None, C.c_float(1.0), 0, int(want_params), 1, B, s), "decoder_fwd")
         self._fwd_token += 1
 
     def _run_backward(self, eps, g_lpx, g_mu, g_lv, B):
@@ -397,7 +397,7 @@ class HLVAE(nn.Module):
         lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
         _lib.check(lib.hlvae_zero_grad(self._plan_handle, ws, s), "zero_grad")
         _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, _lib.ptr(g_lpx), C.c_float(0.0 if g_lpx is None else 1.0),
-                                         1, 0, B, s), "decoder_fwd(grad)")
+                                         1, 0, 0, B, s), "decoder_fwd(grad)")
         _lib.check(lib.hlvae_backward(self._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(0.0), B, s), "backward")
         self._grad_region_clean = False
 

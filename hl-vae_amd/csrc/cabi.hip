@@ -9,19 +9,15 @@
 // launchers implemented next to their kernels
 int hl_launch_gemm_f32(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, int, float*, const char*, hipStream_t);
 int hl_launch_gemm_splitk(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, const char*, hipStream_t);
-int hl_launch_reduce_act(int, const float*, int, int, int, const float*, int, const bf16_t*, bf16_t*, bf16_t*, int, int,
-                         float*, const char*, hipStream_t);
 int hl_launch_gemm_act(int, const bf16_t*, int, const bf16_t*, int, int, int, int, const float*, int, const bf16_t*,
                        bf16_t*, int, bf16_t*, int, int, float*, const char*, hipStream_t);
-int hl_launch_mid_fwd(int, const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*, float*,
-                      const uint64_t*, uint64_t, float*, float*, float*, bf16_t*, bf16_t*, int, int, int, double*, hipStream_t);
-int hl_launch_mid_bwd(int, const bf16_t*, int, const bf16_t*, int, const float*, const float*, const float*,
-                      const float*, const float*, float, float*, bf16_t*, bf16_t*, int, int, int, float*, float*, hipStream_t);
 int hl_launch_y_heads(const hlvae_plan*, const hlvae_ws*, const float*, float, int, int, int, int, hipStream_t);
 int hl_launch_scale_dy(const hlvae_plan*, const hlvae_ws*, const float*, int, int, hipStream_t);
 int hl_launch_stats(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, hipStream_t);
 int hl_launch_pack(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, int, hipStream_t);
 int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
+int hl_launch_mid_fwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, int, uint64_t, int, int, hipStream_t);
+int hl_launch_mid_bwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, const float*, float, int, int, hipStream_t);
 int hl_adam(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t);
 
 static thread_local char g_err[512] = "";
@@ -203,23 +199,21 @@ int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps,
     CHECK_B();
     int rc;
     HL_REQUIRE(ws->splitk_enc >= 1, HLVAE_EINVAL, "splitk_enc");
-    // trunk: T = relu(Xn W1^T + b1)   (HLVAE.py:316-317, evaluated once)
+    // trunk product Xn W1^T as split-K slabs (HLVAE.py:316-317, evaluated once) ...
     if ((rc = hl_launch_gemm_splitk(ws->xn, d.Xp, ws->w1s, d.Xp, ws->slab, d.hep, Bp, d.hep, d.Xp, ws->splitk_enc, "enc1_splitk", st))) return rc;
-    if ((rc = hl_launch_reduce_act(0, ws->slab, ws->splitk_enc, Bp, d.hep, ws->P + d.o_b1, d.h_e, nullptr, ws->t, ws->tT,
-                                   Bp, B, nullptr, "enc1_reduce_relu", st))) return rc;
-    // mean / log-var heads + clamp + reparameterisation
-    return hl_launch_mid_fwd(d.Lp, ws->t, d.hep, ws->wmls, d.hep, ws->P + d.o_bmu, ws->P + d.o_blv, sample ? eps : nullptr,
-                             ws->eps, sample ? ws->rng : nullptr, rng_host_offset, ws->mu, ws->lv, ws->z, ws->zb, ws->zbT,
-                             Bp, B, d.L, ws->klpart, st);
+    // ... then bias + ReLU, mean / log-var heads, clamp, reparameterisation AND the decoder trunk in one fused kernel
+    return hl_launch_mid_fwd_fused(p, ws, eps, sample, rng_host_offset, B, Bp, st);
 }
 
 int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, float g_scale, int want_grad,
-                      int want_params, int B, hlvae_stream s) {
+                      int want_params, int trunk, int B, hlvae_stream s) {
     CHECK_B();
     int rc;
-    // U = relu(z Wd^T + bd)   (HLVAE.py:336)
-    if ((rc = hl_launch_gemm_act(0, ws->zb, d.Lp, ws->wds, d.Lp, Bp, d.hdp, d.Lp, ws->P + d.o_bd, d.h_d, nullptr, ws->u,
-                                 d.hdp, ws->uT, Bp, B, nullptr, "dec1_relu", st))) return rc;
+    if (trunk) {   // U = relu(z Wd^T + bd) from ws->zb (HLVAE.py:336): only when z was set by the caller (decode(z));
+                   // after hlvae_encoder_fwd the trunk is already in ws->u
+        if ((rc = hl_launch_gemm_act(0, ws->zb, d.Lp, ws->wds, d.Lp, Bp, d.hdp, d.Lp, ws->P + d.o_bd, d.h_d, nullptr, ws->u,
+                                     d.hdp, ws->uT, Bp, B, nullptr, "dec1_relu", st))) return rc;
+    }
     return hl_launch_y_heads(p, ws, g_logpx, g_scale, want_grad, want_params, B, Bp, st);
 }
 
@@ -248,25 +242,15 @@ int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, c
     HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
     // d Wy = dY^T U                                  [NY][h_d]
     if ((rc = hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
-    // d U = (dY Wy) * relu'(U); d bd
+    // d U slabs = dY Wy (split-K), then the fused middle: dU -> dz -> d(mu, lv) -> dT, bias gradients
     if ((rc = hl_launch_gemm_splitk(ws->dy, d.NYp, ws->wyTs, d.NYp, ws->slab, d.hdp, Bp, d.hdp, d.NYp, ws->splitk_dec, "dU_splitk", st))) return rc;
-    if ((rc = hl_launch_reduce_act(1, ws->slab, ws->splitk_dec, Bp, d.hdp, nullptr, d.h_d, ws->u, ws->du, ws->duT, Bp, B,
-                                   ws->G + d.o_bd, "dU_reduce_relu_bwd", st))) return rc;
+    if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st))) return rc;
     HL_CHECK(hipEventRecord(p->ev[1], st));
     HL_CHECK(hipStreamWaitEvent(s1, p->ev[1], 0));
-    // d Wd = dU^T z                                  [h_d][L]
+    // d Wd = dU^T z  [h_d][L];   d [Wmu; Wlv] = dml^T T  2 x [L][h_e]     (side stream)
     if ((rc = hl_launch_gemm_f32(ws->duT, Bp, ws->zbT, Bp, ws->G + d.o_wd, d.L, d.h_d, d.L, Bp, 0, 0, nullptr, "dWd", s1))) return rc;
-    // d z -> d mu, d log_var (clamp + reparameterisation backward, + KL(q||N(0,I)) gradient); d bmu, d blv
-    if ((rc = hl_launch_mid_bwd(d.Lp, ws->du, d.hdp, ws->wdTs, d.hdp, ws->eps, ws->lv, g_mu, g_lv, ws->mu, kl_std_weight,
-                                ws->dz, ws->dml, ws->dmlT, Bp, B, d.L, ws->G + d.o_bmu, ws->G + d.o_blv, st))) return rc;
-    HL_CHECK(hipEventRecord(p->ev[2], st));
-    HL_CHECK(hipStreamWaitEvent(s1, p->ev[2], 0));
-    // d [Wmu; Wlv] = dml^T T                         2 x [L][h_e]
     if ((rc = hl_launch_gemm_f32(ws->dmlT, Bp, ws->tT, Bp, ws->G + d.o_wmu, d.h_e, 2 * d.Lp, d.h_e, Bp, d.Lp, d.L,
                                  ws->G + d.o_wlv, "dWmu_dWlv", s1))) return rc;
-    // d T = (dml [Wmu; Wlv]) * relu'(T); d b1
-    if ((rc = hl_launch_gemm_act(1, ws->dml, 2 * d.Lp, ws->wmlTs, 2 * d.Lp, Bp, d.hep, 2 * d.Lp, nullptr, d.h_e, ws->t,
-                                 ws->dt, d.hep, ws->dtT, Bp, B, ws->G + d.o_b1, "dT_relu_bwd", st))) return rc;
     // d W1 = dT^T Xn                                 [h_e][X]   (no input gradient for layer 1)
     if ((rc = hl_launch_gemm_f32(ws->dtT, Bp, ws->xnT, Bp, ws->G + d.o_w1, d.X, d.h_e, d.X, Bp, 0, 0, nullptr, "dW1", st))) return rc;
     HL_CHECK(hipEventRecord(p->ev[3], s0));

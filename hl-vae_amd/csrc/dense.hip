@@ -93,68 +93,6 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// slab reduction + activation.  MODE 0: out = relu(sum + bias)       (encoder trunk, HLVAE.py:316)
-//                               MODE 1: out = sum * (ref > 0)        (ReLU backward), bias-grad colsum
-// rows >= B are written as zero (batch padding).  32 x 32 tiles, one float4 per lane and slab.
-// ------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(HL_THREADS) void k_reduce_act(const float* __restrict__ slab, int S, int M, int ldn,
-                                                           const float* __restrict__ bias, int nvalid,
-                                                           const bf16_t* __restrict__ ref, bf16_t* __restrict__ out,
-                                                           bf16_t* __restrict__ outT, int ldT, int B,
-                                                           float* __restrict__ gbias) {
-    constexpr int BM = 32, BN = 32, CLD = BN + 1;
-    __shared__ float Cs[BM * CLD];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
-    const int gr = m0 + r, gc = n0 + c4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gr < B) {
-        const float* src = slab + (size_t)gr * ldn + gc;
-        const size_t sstride = (size_t)M * ldn;
-#pragma unroll 4
-        for (int s = 0; s < S; ++s) {
-            const float4 t = *reinterpret_cast<const float4*>(src + s * sstride);
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        float* vv = &v.x;
-        if (MODE == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float t = (gc + k < nvalid) ? vv[k] + bias[gc + k] : 0.f;
-                vv[k] = t > 0.f ? t : 0.f;
-            }
-        } else {
-            const uint2 rf = *reinterpret_cast<const uint2*>(ref + (size_t)gr * ldn + gc);
-            const bf16_t rr[4] = {(bf16_t)(rf.x & 0xffff), (bf16_t)(rf.x >> 16), (bf16_t)(rf.y & 0xffff), (bf16_t)(rf.y >> 16)};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) vv[k] = (gc + k < nvalid && bf2f(rr[k]) > 0.f) ? vv[k] : 0.f;
-        }
-    }
-    {   // row-major store: 4 bf16 = 8 bytes per lane
-        uint2 pk;
-        pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-        pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-        *reinterpret_cast<uint2*>(out + (size_t)gr * ldn + gc) = pk;
-    }
-    Cs[r * CLD + c4 + 0] = v.x; Cs[r * CLD + c4 + 1] = v.y; Cs[r * CLD + c4 + 2] = v.z; Cs[r * CLD + c4 + 3] = v.w;
-    __syncthreads();
-    {   // transposed store: lane -> (column, 4 consecutive rows)
-        const int c = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;
-        uint2 pk;
-        pk.x = (uint32_t)f2bf(Cs[(r4 + 0) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 1) * CLD + c]) << 16);
-        pk.y = (uint32_t)f2bf(Cs[(r4 + 2) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 3) * CLD + c]) << 16);
-        *reinterpret_cast<uint2*>(outT + (size_t)(n0 + c) * ldT + m0 + r4) = pk;
-    }
-    if (MODE == 1 && gbias != nullptr && threadIdx.x < BN && n0 + threadIdx.x < nvalid) {
-        float sum = 0.f;
-#pragma unroll 8
-        for (int rr = 0; rr < BM; ++rr) sum += Cs[rr * CLD + threadIdx.x];
-        atomicAdd(gbias + n0 + threadIdx.x, sum);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // GEMM + elementwise epilogue into dual bf16.  MODE 0: relu(acc + bias)   (decoder trunk, HLVAE.py:336)
 //                                             MODE 1: acc * (ref > 0)    (d trunk of the encoder), colsum
 // ------------------------------------------------------------------------------------------------
@@ -192,150 +130,6 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_act(const bf16_t* __restric
     __syncthreads();
     tile_store_dual_bf16<64, 64, G::CLD>(Cs, out, ldo, outT, ldT, m0, n0, M, N);
     if (MODE == 1 && gbias != nullptr) tile_colsum_atomic<64, 64, G::CLD>(Cs, gbias, n0, nvalid);
-}
-
-// ------------------------------------------------------------------------------------------------
-// encoder head + reparameterisation (rows B tail + C): [mu | lv_raw] = T * [Wmu; Wlv]^T + bias,
-// lv = clamp(lv_raw, -15, 15) (HLVAE.py:319), z = mu + eps * exp(lv / 2) (HLVAE.py:360-362).
-// Tile: 64 rows x 2*LP columns (mu in [0,LP), log-var in [LP,2LP)).
-// ------------------------------------------------------------------------------------------------
-// Philox4x32-10 counter-based generator (Salmon et al. 2011): 4 x 32 random bits per (counter, key)
-__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
-        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-        key.x += 0x9E3779B9u;
-        key.y += 0xBB67AE85u;
-    }
-    return ctr;
-}
-__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint32_t idx) {
-    const uint4 r = philox4x32(make_uint4(idx, 0u, (uint32_t)offset, (uint32_t)(offset >> 32)),
-                               make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-    const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
-    const float u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);              // [0, 1)
-    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);     // Box-Muller
-}
-
-template <int LP>
-__global__ __launch_bounds__(HL_THREADS) void k_mid_fwd(const bf16_t* __restrict__ T, int ldt,
-                                                        const bf16_t* __restrict__ Wml, int K,
-                                                        const float* __restrict__ bmu, const float* __restrict__ blv,
-                                                        const float* __restrict__ eps, float* __restrict__ eps_out,
-                                                        const uint64_t* __restrict__ rng, uint64_t rng_host_offset,
-                                                        float* __restrict__ mu,
-                                                        float* __restrict__ lv, float* __restrict__ z,
-                                                        bf16_t* __restrict__ zb, bf16_t* __restrict__ zbT, int Bp, int B,
-                                                        int L, double* __restrict__ klpart) {
-    // noise: eps given -> use it; else rng != NULL -> Philox(seed = rng[0], offset = rng[1] + host offset), stored to
-    // eps_out for the backward pass; else z = mu (deterministic pass of get_test_samples, HLVAE.py:472)
-    using G = GemmNT<64, 2 * LP, 64, 2, 2>;
-    __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
-    __shared__ double klred[4];
-    const int m0 = blockIdx.x * 64;
-    typename G::Acc acc;
-    G::zero(acc);
-    G::run(T, ldt, Wml, ldt, m0, 0, Bp, 2 * LP, 0, K, smem, acc);
-    G::to_lds(acc, smem);
-    float* Cs = reinterpret_cast<float*>(smem);
-    uint64_t seed = 0, off = 0;
-    if (eps == nullptr && rng != nullptr) { seed = rng[0]; off = rng[1] + rng_host_offset; }
-    double klacc = 0.0;
-    for (int idx = threadIdx.x; idx < 64 * LP; idx += HL_THREADS) {
-        const int r = idx / LP, j = idx % LP;
-        const int gr = m0 + r;
-        float zv = 0.f;
-        if (gr < B && j < L) {
-            const size_t o = (size_t)gr * L + j;
-            const float m = Cs[r * G::CLD + j] + bmu[j];
-            float l = Cs[r * G::CLD + LP + j] + blv[j];
-            l = fminf(fmaxf(l, -15.f), 15.f);
-            float e = 0.f;
-            if (eps != nullptr) e = eps[o];
-            else if (rng != nullptr) e = philox_normal(seed, off, (uint32_t)o);
-            if (eps_out != nullptr) eps_out[o] = e;
-            const float el = __expf(l);
-            zv = m + e * sqrtf(el);
-            mu[o] = m;
-            lv[o] = l;
-            z[o] = zv;
-            klacc += (double)(-0.5f * (1.f + l - m * m - el));   // KL(q || N(0,I)) term (extension, see kl notes)
-        }
-        Cs[r * G::CLD + j] = zv;   // reuse the mu half of the tile as the z tile
-    }
-    klacc = wave_sum_d(klacc);
-    if ((threadIdx.x & 63) == 0) klred[threadIdx.x >> 6] = klacc;
-    __syncthreads();
-    if (threadIdx.x == 0 && klpart != nullptr) klpart[blockIdx.x] = klred[0] + klred[1] + klred[2] + klred[3];
-    tile_store_dual_bf16<64, LP, G::CLD>(Cs, zb, LP, zbT, Bp, m0, 0, Bp, LP);
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward through z, the clamp and the reparameterisation:
-//   dz = dU * Wd  (A = du [Bp][hdp], B = WdT [LP][hdp]);   d mu = dz + g_mu;
-//   d lv = (dz * eps * 0.5 * exp(lv/2) + g_lv) * [ -15 < lv < 15 ]
-// writes dml = [d mu | d lv] (bf16, both layouts) and the two bias gradients.
-// ------------------------------------------------------------------------------------------------
-template <int LP>
-__global__ __launch_bounds__(HL_THREADS) void k_mid_bwd(const bf16_t* __restrict__ dU, int ldu,
-                                                        const bf16_t* __restrict__ WdT, int K,
-                                                        const float* __restrict__ eps, const float* __restrict__ lv,
-                                                        const float* __restrict__ g_mu, const float* __restrict__ g_lv,
-                                                        const float* __restrict__ mu, float kl_w,
-                                                        float* __restrict__ dz, bf16_t* __restrict__ dml,
-                                                        bf16_t* __restrict__ dmlT, int Bp, int B, int L,
-                                                        float* __restrict__ gbmu, float* __restrict__ gblv) {
-    using G = GemmNT<64, LP, 64, 4, 1>;
-    constexpr int CLD2 = 2 * LP + 1;
-    __shared__ __attribute__((aligned(16))) char smem[(G::SMEM_BYTES > 64 * CLD2 * 4) ? G::SMEM_BYTES : 64 * CLD2 * 4];
-    const int m0 = blockIdx.x * 64;
-    typename G::Acc acc;
-    G::zero(acc);
-    G::run(dU, ldu, WdT, ldu, m0, 0, Bp, LP, 0, K, smem, acc);
-    // the [64][2LP] output tile is wider than the accumulator tile: go through registers
-    float vals[(64 * LP + HL_THREADS - 1) / HL_THREADS];
-    {
-        G::to_lds(acc, smem);
-        const float* Cs = reinterpret_cast<const float*>(smem);
-        int n = 0;
-        for (int idx = threadIdx.x; idx < 64 * LP; idx += HL_THREADS, ++n) vals[n] = Cs[(idx / LP) * G::CLD + idx % LP];
-        __syncthreads();
-    }
-    float* Ds = reinterpret_cast<float*>(smem);
-    int n = 0;
-    for (int idx = threadIdx.x; idx < 64 * LP; idx += HL_THREADS, ++n) {
-        const int r = idx / LP, j = idx % LP;
-        const int gr = m0 + r;
-        float dm = 0.f, dl = 0.f;
-        const float d = vals[n];
-        if (gr < B && j < L) {
-            const size_t o = (size_t)gr * L + j;
-            const float l = lv[o];
-            dm = d + (g_mu != nullptr ? g_mu[o] : 0.f);
-            const float e = eps != nullptr ? eps[o] : 0.f;
-            const float el = __expf(l);
-            dl = d * e * 0.5f * sqrtf(el) + (g_lv != nullptr ? g_lv[o] : 0.f);
-            if (kl_w != 0.f) {                       // d KL(q || N(0,I)): d/dmu = mu, d/dlv = (e^lv - 1)/2
-                dm += kl_w * mu[o];
-                dl += kl_w * 0.5f * (el - 1.f);
-            }
-            if (!(l > -15.f && l < 15.f)) dl = 0.f;
-        }
-        if (gr < Bp) dz[(size_t)gr * LP + j] = (gr < B && j < L) ? d : 0.f;
-        Ds[r * CLD2 + j] = dm;
-        Ds[r * CLD2 + LP + j] = dl;
-    }
-    __syncthreads();
-    tile_store_dual_bf16<64, 2 * LP, CLD2>(Ds, dml, 2 * LP, dmlT, Bp, m0, 0, Bp, 2 * LP);
-    for (int c = threadIdx.x; c < 2 * LP; c += HL_THREADS) {
-        const int j = c < LP ? c : c - LP;
-        if (j >= L) continue;
-        float s = 0.f;
-        for (int r = 0; r < 64; ++r) s += Ds[r * CLD2 + c];
-        atomicAdd((c < LP ? gbmu : gblv) + j, s);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,19 +171,6 @@ int hl_launch_gemm_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, fl
     return 0;
 }
 
-int hl_launch_reduce_act(int mode, const float* slab, int S, int M, int ldn, const float* bias, int nvalid,
-                         const bf16_t* ref, bf16_t* out, bf16_t* outT, int ldT, int B, float* gbias, const char* label, hipStream_t s) {
-    dim3 grid(ldn / 32, M / 32);
-    HL_REQUIRE(ldn % 32 == 0 && M % 32 == 0 && ldT % 4 == 0, HLVAE_ESHAPE, "reduce_act: M=%d ldn=%d", M, ldn);
-    HL_PROF(label, s);
-    if (mode == 0)
-        k_reduce_act<0><<<grid, HL_THREADS, 0, s>>>(slab, S, M, ldn, bias, nvalid, ref, out, outT, ldT, B, gbias);
-    else
-        k_reduce_act<1><<<grid, HL_THREADS, 0, s>>>(slab, S, M, ldn, bias, nvalid, ref, out, outT, ldT, B, gbias);
-    HL_LAUNCH_CHECK();
-    return 0;
-}
-
 int hl_launch_gemm_act(int mode, const bf16_t* A, int lda, const bf16_t* Bm, int ldb, int M, int N, int K,
                        const float* bias, int nvalid, const bf16_t* ref, bf16_t* out, int ldo, bf16_t* outT, int ldT,
                        int B, float* gbias, const char* label, hipStream_t s) {
@@ -411,32 +192,3 @@ int hl_launch_gemm_act(int mode, const bf16_t* A, int lda, const bf16_t* Bm, int
     return 0;
 }
 
-int hl_launch_mid_fwd(int Lp, const bf16_t* T, int ldt, const bf16_t* Wml, int K, const float* bmu, const float* blv,
-                      const float* eps, float* eps_out, const uint64_t* rng, uint64_t rng_off, float* mu, float* lv,
-                      float* z, bf16_t* zb, bf16_t* zbT, int Bp, int B, int L, double* klpart, hipStream_t s) {
-    HL_REQUIRE(K % 64 == 0 && Bp % 64 == 0, HLVAE_ESHAPE, "mid_fwd: K=%d Bp=%d", K, Bp);
-    HL_PROF("enc_head_reparam", s);
-    if (Lp == 32)
-        k_mid_fwd<32><<<Bp / 64, HL_THREADS, 0, s>>>(T, ldt, Wml, K, bmu, blv, eps, eps_out, rng, rng_off, mu, lv, z, zb, zbT, Bp, B, L, klpart);
-    else if (Lp == 64)
-        k_mid_fwd<64><<<Bp / 64, HL_THREADS, 0, s>>>(T, ldt, Wml, K, bmu, blv, eps, eps_out, rng, rng_off, mu, lv, z, zb, zbT, Bp, B, L, klpart);
-    else
-        HL_REQUIRE(false, HLVAE_EINVAL, "latent_dim padded to %d is not supported (max 64)", Lp);
-    HL_LAUNCH_CHECK();
-    return 0;
-}
-
-int hl_launch_mid_bwd(int Lp, const bf16_t* dU, int ldu, const bf16_t* WdT, int K, const float* eps, const float* lv,
-                      const float* g_mu, const float* g_lv, const float* mu, float kl_w, float* dz, bf16_t* dml,
-                      bf16_t* dmlT, int Bp, int B, int L, float* gbmu, float* gblv, hipStream_t s) {
-    HL_REQUIRE(K % 64 == 0 && Bp % 64 == 0, HLVAE_ESHAPE, "mid_bwd: K=%d Bp=%d", K, Bp);
-    HL_PROF("dz_reparam_bwd", s);
-    if (Lp == 32)
-        k_mid_bwd<32><<<Bp / 64, HL_THREADS, 0, s>>>(dU, ldu, WdT, K, eps, lv, g_mu, g_lv, mu, kl_w, dz, dml, dmlT, Bp, B, L, gbmu, gblv);
-    else if (Lp == 64)
-        k_mid_bwd<64><<<Bp / 64, HL_THREADS, 0, s>>>(dU, ldu, WdT, K, eps, lv, g_mu, g_lv, mu, kl_w, dz, dml, dmlT, Bp, B, L, gbmu, gblv);
-    else
-        HL_REQUIRE(false, HLVAE_EINVAL, "latent_dim padded to %d is not supported (max 64)", Lp);
-    HL_LAUNCH_CHECK();
-    return 0;
-}

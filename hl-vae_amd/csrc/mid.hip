@@ -1,0 +1,394 @@
+// The "middle" of the network, fused per 16-row batch tile (one workgroup = 16 rows, 4 waves):
+//
+//  forward   slabs of Xn*W1^T  ->  T = relu(sum + b1)  ->  [mu | lv] = T [Wmu;Wlv]^T + b  -> clamp, noise, z
+//            ->  U = relu(z Wd^T + bd)                                   (HLVAE.py:316-324, 351-362, 336)
+//  backward  slabs of dY*Wy    ->  dU = sum * relu'(U)  ->  dz = dU Wd  ->  d[mu | lv] (reparam, clamp, KL)
+//            ->  dT = d[mu|lv] [Wmu;Wlv] * relu'(T)
+//
+// Between the two long-K GEMMs every tensor is at most 512 x 512, so these stages are pure latency: as
+// separate launches they cost a kernel boundary plus a cold pipeline each (3 + 3 launches, ~60 us).  Fused,
+// the 16-row activation tile never leaves LDS, the small weight matrices (<= 64 KB bf16) are read as MFMA
+// B-fragments straight from L2 (16 B per lane, all k-steps of a product issued back to back), and only what
+// the weight-gradient GEMMs need is written back (the transposed copies).
+#include "common.h"
+
+// Philox4x32-10 counter-based generator (Salmon et al. 2011): 4 x 32 random bits per (counter, key)
+__device__ __forceinline__ uint4 philox4x32_m(uint4 ctr, uint2 key) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += 0x9E3779B9u;
+        key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+__device__ __forceinline__ float philox_normal_m(uint64_t seed, uint64_t offset, uint32_t idx) {
+    const uint4 r = philox4x32_m(make_uint4(idx, 0u, (uint32_t)offset, (uint32_t)(offset >> 32)),
+                                 make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);     // (0, 1]
+    const float u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);              // [0, 1)
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);     // Box-Muller
+}
+
+// 16 x 16 output fragment: A = 16-row bf16 tile in LDS (row stride lda), B = rows [n0, n0+16) of a K-contiguous
+// bf16 matrix in global memory (a weight shadow, L2 resident).  k range in multiples of 32.
+__device__ __forceinline__ f32x4_t mfma_lds_x_global(const bf16_t* As, int lda, const bf16_t* __restrict__ Bg, int ldb,
+                                                     int n0, int k_begin, int k_end, int lane) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const bf16_t* ap = As + (lane & 15) * lda + (lane >> 4) * 8;
+    const bf16_t* bp = Bg + (size_t)(n0 + (lane & 15)) * ldb + (lane >> 4) * 8;
+#pragma unroll 8
+    for (int k = k_begin; k < k_end; k += 32) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ap + k);
+        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(bp + k);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+#define MID_ROWS 16
+#define MID_THREADS 1024   // 16 waves: enough 16-byte loads in flight for the slab reduction, one n-tile (or k-slice) per wave
+
+// ------------------------------------------------------------------------------------------------------------
+// forward.  LDS: tile_a bf16 [16][KA+8] (T, later z), ctile fp32 [16][NC+1] (accumulator staging)
+// ------------------------------------------------------------------------------------------------------------
+template <int LP>
+__global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
+    const float* __restrict__ slab, int S, int Bp, int hep, int h_e, const float* __restrict__ b1,
+    bf16_t* __restrict__ t_out, bf16_t* __restrict__ tT_out,
+    const bf16_t* __restrict__ wml, const float* __restrict__ bmu, const float* __restrict__ blv,
+    const float* __restrict__ eps, float* __restrict__ eps_out, const uint64_t* __restrict__ rng, uint64_t rng_off,
+    float* __restrict__ mu, float* __restrict__ lv, float* __restrict__ z, bf16_t* __restrict__ zb,
+    bf16_t* __restrict__ zbT, int L, double* __restrict__ klpart,
+    const bf16_t* __restrict__ wd, int hdp, int h_d, const float* __restrict__ bd, bf16_t* __restrict__ u_out,
+    bf16_t* __restrict__ uT_out, int B) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lda = hep + 8;                                     // bf16 elements
+    bf16_t* Ta = reinterpret_cast<bf16_t*>(smem);                // [16][hep+8]
+    const int cmax = (hdp > 2 * LP ? hdp : 2 * LP) + 1;
+    float* Ct = reinterpret_cast<float*>(smem + MID_ROWS * lda * 2);        // [16][cmax]
+    bf16_t* Za = reinterpret_cast<bf16_t*>(smem + MID_ROWS * lda * 2 + MID_ROWS * cmax * 4);   // [16][LP+8]
+    float* Cp = reinterpret_cast<float*>(smem + MID_ROWS * lda * 2 + MID_ROWS * cmax * 4 + MID_ROWS * (LP + 8) * 2);   // [KS][16][2LP+1]
+    __shared__ double klred[MID_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * MID_ROWS;
+
+    // ---- stage 1: T tile = relu(sum_s slab + b1), rows >= B and columns >= h_e are zero
+    for (int idx = tid; idx < MID_ROWS * (hep / 4); idx += MID_THREADS) {
+        const int r = idx / (hep / 4), c4 = (idx % (hep / 4)) * 4;
+        const int gr = m0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < B) {
+            const float* src = slab + (size_t)gr * hep + c4;
+            const size_t ss = (size_t)Bp * hep;
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) {
+                const float4 x = *reinterpret_cast<const float4*>(src + s * ss);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            float* vv = &v.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x = (c4 + k < h_e) ? vv[k] + b1[c4 + k] : 0.f;
+                vv[k] = x > 0.f ? x : 0.f;
+            }
+        }
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+        pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+        *reinterpret_cast<uint2*>(Ta + r * lda + c4) = pk;
+        *reinterpret_cast<uint2*>(t_out + (size_t)gr * hep + c4) = pk;
+    }
+    __syncthreads();
+    // transposed copy of T (operand of the [Wmu;Wlv] weight gradient): lane -> (column, 4 rows) = 8 bytes
+    for (int idx = tid; idx < hep * (MID_ROWS / 4); idx += MID_THREADS) {
+        const int c = idx / (MID_ROWS / 4), r4 = (idx % (MID_ROWS / 4)) * 4;
+        uint2 pk;
+        pk.x = (uint32_t)Ta[(r4 + 0) * lda + c] | ((uint32_t)Ta[(r4 + 1) * lda + c] << 16);
+        pk.y = (uint32_t)Ta[(r4 + 2) * lda + c] | ((uint32_t)Ta[(r4 + 3) * lda + c] << 16);
+        *reinterpret_cast<uint2*>(tT_out + (size_t)c * Bp + m0 + r4) = pk;
+    }
+    // ---- stage 2: [mu | lv_raw] = T * Wml^T   (N = 2*LP; 16 waves = NT2 n-tiles x KS2 k-slices, partials summed below)
+    constexpr int NT2 = (2 * LP) / 16, KS2 = (MID_THREADS / 64) / NT2;
+    {
+        const int nt = wave % NT2, kq = wave / NT2;
+        const int kper = ((hep / 32 + KS2 - 1) / KS2) * 32;
+        const int kb = kq * kper, ke = min(hep, kb + kper);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        if (kb < ke) acc = mfma_lds_x_global(Ta, lda, wml, hep, nt * 16, kb, ke, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cp[(kq * MID_ROWS + (lane >> 4) * 4 + r) * (2 * LP + 1) + nt * 16 + (lane & 15)] = acc[r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < MID_ROWS * 2 * LP; idx += MID_THREADS) {
+        const int r = idx / (2 * LP), c = idx % (2 * LP);
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < KS2; ++q) sum += Cp[(q * MID_ROWS + r) * (2 * LP + 1) + c];
+        Ct[r * cmax + c] = sum;
+    }
+    __syncthreads();
+    // ---- stage 3: clamp, noise, z, KL partial
+    uint64_t seed = 0, off = 0;
+    if (eps == nullptr && rng != nullptr) { seed = rng[0]; off = rng[1] + rng_off; }
+    double klacc = 0.0;
+    for (int idx = tid; idx < MID_ROWS * LP; idx += MID_THREADS) {
+        const int r = idx / LP, j = idx % LP;
+        const int gr = m0 + r;
+        float zv = 0.f;
+        if (gr < B && j < L) {
+            const size_t o = (size_t)gr * L + j;
+            const float m = Ct[r * cmax + j] + bmu[j];
+            float l = Ct[r * cmax + LP + j] + blv[j];
+            l = fminf(fmaxf(l, -15.f), 15.f);                    // HLVAE.py:319
+            float e = 0.f;
+            if (eps != nullptr) e = eps[o];
+            else if (rng != nullptr) e = philox_normal_m(seed, off, (uint32_t)o);
+            if (eps_out != nullptr) eps_out[o] = e;
+            const float el = __expf(l);
+            zv = m + e * sqrtf(el);                              // HLVAE.py:360-362
+            mu[o] = m;
+            lv[o] = l;
+            z[o] = zv;
+            klacc += (double)(-0.5f * (1.f + l - m * m - el));
+        }
+        const bf16_t zbv = f2bf(zv);
+        Za[r * (LP + 8) + j] = zbv;
+        zb[(size_t)gr * LP + j] = zbv;
+        zbT[(size_t)j * Bp + gr] = zbv;
+    }
+    klacc = wave_sum_d(klacc);
+    if (lane == 0) klred[wave] = klacc;
+    __syncthreads();
+    if (tid == 0 && klpart != nullptr) {
+        double k = 0.0;
+        for (int w = 0; w < MID_THREADS / 64; ++w) k += klred[w];
+        klpart[blockIdx.x] = k;
+    }
+    // ---- stage 4: U = relu(z Wd^T + bd)   (K = LP, N = hdp)
+    for (int nt = wave; nt < hdp / 16; nt += MID_THREADS / 64) {
+        const f32x4_t acc = mfma_lds_x_global(Za, LP + 8, wd, LP, nt * 16, 0, LP, lane);
+        const int col = nt * 16 + (lane & 15);
+        const float bias = col < h_d ? bd[col] : 0.f;
+        float o4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) * 4 + r;
+            float x = acc[r] + bias;
+            x = (x > 0.f && col < h_d && m0 + row < B) ? x : 0.f;
+            o4[r] = x;
+            Ct[row * cmax + col] = x;
+        }
+        // transposed copy straight from the accumulator fragment: 4 consecutive rows of one column = 8 bytes
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(o4[0]) | ((uint32_t)f2bf(o4[1]) << 16);
+        pk.y = (uint32_t)f2bf(o4[2]) | ((uint32_t)f2bf(o4[3]) << 16);
+        *reinterpret_cast<uint2*>(uT_out + (size_t)col * Bp + m0 + (lane >> 4) * 4) = pk;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < MID_ROWS * (hdp / 4); idx += MID_THREADS) {
+        const int r = idx / (hdp / 4), c4 = (idx % (hdp / 4)) * 4;
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(Ct[r * cmax + c4]) | ((uint32_t)f2bf(Ct[r * cmax + c4 + 1]) << 16);
+        pk.y = (uint32_t)f2bf(Ct[r * cmax + c4 + 2]) | ((uint32_t)f2bf(Ct[r * cmax + c4 + 3]) << 16);
+        *reinterpret_cast<uint2*>(u_out + (size_t)(m0 + r) * hdp + c4) = pk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------------------
+template <int LP>
+__global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
+    const float* __restrict__ slab, int S, int Bp, int hdp, int h_d, const bf16_t* __restrict__ u,
+    bf16_t* __restrict__ duT_out, float* __restrict__ gbd,
+    const bf16_t* __restrict__ wdT, const float* __restrict__ eps, const float* __restrict__ lv,
+    const float* __restrict__ mu, const float* __restrict__ g_mu, const float* __restrict__ g_lv, float kl_w, int L,
+    bf16_t* __restrict__ dmlT_out, float* __restrict__ gbmu, float* __restrict__ gblv,
+    const bf16_t* __restrict__ wmlT, int hep, int h_e, const bf16_t* __restrict__ t, bf16_t* __restrict__ dtT_out,
+    float* __restrict__ gb1, int B) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lda = hdp + 8;
+    bf16_t* Ua = reinterpret_cast<bf16_t*>(smem);                            // dU tile bf16 [16][hdp+8]
+    constexpr int NTZ = LP / 16, KSZ = (MID_THREADS / 64) / NTZ;            // dz: n-tiles x k-slices over the 16 waves
+    float* Cz = reinterpret_cast<float*>(smem + MID_ROWS * lda * 2);         // dz partials [KSZ][16][LP+1]
+    bf16_t* Ma = reinterpret_cast<bf16_t*>(smem + MID_ROWS * lda * 2 + KSZ * MID_ROWS * (LP + 1) * 4);   // dml [16][2LP+8]
+    float* Gs = reinterpret_cast<float*>(smem + MID_ROWS * lda * 2 + KSZ * MID_ROWS * (LP + 1) * 4 + MID_ROWS * (2 * LP + 8) * 2);  // fp32 [16][2LP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * MID_ROWS;
+
+    // ---- stage 1: dU tile = sum_s slab * relu'(U); d bd column sums
+    for (int idx = tid; idx < MID_ROWS * (hdp / 4); idx += MID_THREADS) {
+        const int r = idx / (hdp / 4), c4 = (idx % (hdp / 4)) * 4;
+        const int gr = m0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < B) {
+            const float* src = slab + (size_t)gr * hdp + c4;
+            const size_t ss = (size_t)Bp * hdp;
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) {
+                const float4 x = *reinterpret_cast<const float4*>(src + s * ss);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            const uint2 rf = *reinterpret_cast<const uint2*>(u + (size_t)gr * hdp + c4);
+            const bf16_t rr[4] = {(bf16_t)(rf.x & 0xffff), (bf16_t)(rf.x >> 16), (bf16_t)(rf.y & 0xffff), (bf16_t)(rf.y >> 16)};
+            float* vv = &v.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vv[k] = (c4 + k < h_d && bf2f(rr[k]) > 0.f) ? vv[k] : 0.f;
+        }
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+        pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+        *reinterpret_cast<uint2*>(Ua + r * lda + c4) = pk;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < hdp * (MID_ROWS / 4); idx += MID_THREADS) {     // transposed copy + column sums
+        const int c = idx / (MID_ROWS / 4), r4 = (idx % (MID_ROWS / 4)) * 4;
+        const bf16_t a0 = Ua[(r4 + 0) * lda + c], a1 = Ua[(r4 + 1) * lda + c], a2 = Ua[(r4 + 2) * lda + c],
+                     a3 = Ua[(r4 + 3) * lda + c];
+        uint2 pk;
+        pk.x = (uint32_t)a0 | ((uint32_t)a1 << 16);
+        pk.y = (uint32_t)a2 | ((uint32_t)a3 << 16);
+        *reinterpret_cast<uint2*>(duT_out + (size_t)c * Bp + m0 + r4) = pk;
+        float s = bf2f(a0) + bf2f(a1) + bf2f(a2) + bf2f(a3);                 // 4 lanes of a column are adjacent
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if ((idx & 3) == 0 && c < h_d) atomicAdd(gbd + c, s);
+    }
+    // ---- stage 2: dz = dU * Wd   (N = LP: n-tile = wave % (LP/16), K split over the remaining waves)
+    {
+        const int nt = wave % NTZ, kq = wave / NTZ;
+        const int kper = ((hdp / 32 + KSZ - 1) / KSZ) * 32;
+        const int kb = kq * kper, ke = min(hdp, kb + kper);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        if (kb < ke) acc = mfma_lds_x_global(Ua, lda, wdT, hdp, nt * 16, kb, ke, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cz[(kq * MID_ROWS + (lane >> 4) * 4 + r) * (LP + 1) + nt * 16 + (lane & 15)] = acc[r];
+    }
+    __syncthreads();
+    // ---- stage 3: d mu, d lv  (reparameterisation + clamp backward, + KL(q || N(0,I)) gradient)
+    for (int idx = tid; idx < MID_ROWS * LP; idx += MID_THREADS) {
+        const int r = idx / LP, j = idx % LP;
+        const int gr = m0 + r;
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < KSZ; ++q) d += Cz[(q * MID_ROWS + r) * (LP + 1) + j];
+        float dm = 0.f, dl = 0.f;
+        if (gr < B && j < L) {
+            const size_t o = (size_t)gr * L + j;
+            const float l = lv[o];
+            const float el = __expf(l);
+            dm = d + (g_mu != nullptr ? g_mu[o] : 0.f);
+            dl = d * eps[o] * 0.5f * sqrtf(el) + (g_lv != nullptr ? g_lv[o] : 0.f);
+            if (kl_w != 0.f) {
+                dm += kl_w * mu[o];
+                dl += kl_w * 0.5f * (el - 1.f);
+            }
+            if (!(l > -15.f && l < 15.f)) dl = 0.f;
+        }
+        const bf16_t bm = f2bf(dm), bl = f2bf(dl);
+        Ma[r * (2 * LP + 8) + j] = bm;
+        Ma[r * (2 * LP + 8) + LP + j] = bl;
+        dmlT_out[(size_t)j * Bp + gr] = bm;
+        dmlT_out[(size_t)(LP + j) * Bp + gr] = bl;
+        Gs[r * 2 * LP + j] = dm;
+        Gs[r * 2 * LP + LP + j] = dl;
+    }
+    __syncthreads();
+    if (tid < 2 * LP) {                                          // bias gradients: one atomic per column and tile
+        const int j = tid < LP ? tid : tid - LP;
+        if (j < L) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < MID_ROWS; ++r) sum += Gs[r * 2 * LP + tid];
+            atomicAdd((tid < LP ? gbmu : gblv) + j, sum);
+        }
+    }
+    // ---- stage 4: dT = dml * Wml * relu'(T)   (K = 2*LP, N = hep); only the transposed copy is needed
+    for (int nt = wave; nt < hep / 16; nt += MID_THREADS / 64) {
+        const f32x4_t acc = mfma_lds_x_global(Ma, 2 * LP + 8, wmlT, 2 * LP, nt * 16, 0, 2 * LP, lane);
+        const int col = nt * 16 + (lane & 15);
+        float o4[4];
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + (lane >> 4) * 4 + r;
+            const bool on = col < h_e && row < B && bf2f(t[(size_t)row * hep + col]) > 0.f;
+            o4[r] = on ? acc[r] : 0.f;
+            s += o4[r];
+        }
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(o4[0]) | ((uint32_t)f2bf(o4[1]) << 16);
+        pk.y = (uint32_t)f2bf(o4[2]) | ((uint32_t)f2bf(o4[3]) << 16);
+        *reinterpret_cast<uint2*>(dtT_out + (size_t)col * Bp + m0 + (lane >> 4) * 4) = pk;
+        s += __shfl_xor(s, 16, 64);                              // the 4 row groups of a column
+        s += __shfl_xor(s, 32, 64);
+        if (lane < 16 && col < h_e) atomicAdd(gb1 + col, s);
+    }
+}
+
+static size_t mid_fwd_smem(int Lp, int hep, int hdp) {
+    const int cmax = (hdp > 2 * Lp ? hdp : 2 * Lp) + 1;
+    const int ks2 = (MID_THREADS / 64) / ((2 * Lp) / 16);
+    return (size_t)MID_ROWS * (hep + 8) * 2 + (size_t)MID_ROWS * cmax * 4 + (size_t)MID_ROWS * (Lp + 8) * 2 +
+           (size_t)ks2 * MID_ROWS * (2 * Lp + 1) * 4;
+}
+static size_t mid_bwd_smem(int Lp, int hdp) {
+    const int ksz = (MID_THREADS / 64) / (Lp / 16);
+    return (size_t)MID_ROWS * (hdp + 8) * 2 + (size_t)ksz * MID_ROWS * (Lp + 1) * 4 + (size_t)MID_ROWS * (2 * Lp + 8) * 2 +
+           (size_t)MID_ROWS * 2 * Lp * 4;
+}
+
+int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int sample, uint64_t rng_off, int B,
+                            int Bp, hipStream_t s) {
+    const hlvae_dims& d = p->d;
+    HL_REQUIRE(Bp % MID_ROWS == 0 && d.hep % 64 == 0 && d.hdp % 64 == 0, HLVAE_ESHAPE, "mid_fwd_fused shapes");
+    const size_t smem = mid_fwd_smem(d.Lp, d.hep, d.hdp);
+    HL_REQUIRE(smem <= 150 * 1024, HLVAE_EINVAL, "hidden width too large for the fused middle kernel (%zu B of LDS)", smem);
+    HL_PROF("mid_fwd_fused", s);
+#define HL_MF(LPv)                                                                                                     \
+    {                                                                                                                  \
+        static size_t attr_max = 48 * 1024;                                                                            \
+        if (smem > attr_max) {                                                                                         \
+            HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mid_fwd_fused<LPv>),                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                      \
+            attr_max = smem;                                                                                           \
+        }                                                                                                              \
+        k_mid_fwd_fused<LPv><<<Bp / MID_ROWS, MID_THREADS, smem, s>>>(                                                    \
+            ws->slab, ws->splitk_enc, Bp, d.hep, d.h_e, ws->P + d.o_b1, ws->t, ws->tT, ws->wmls, ws->P + d.o_bmu,       \
+            ws->P + d.o_blv, sample ? eps : nullptr, ws->eps, sample ? ws->rng : nullptr, rng_off, ws->mu, ws->lv,     \
+            ws->z, ws->zb, ws->zbT, d.L, ws->klpart, ws->wds, d.hdp, d.h_d, ws->P + d.o_bd, ws->u, ws->uT, B);          \
+    }
+    if (d.Lp == 32) HL_MF(32) else if (d.Lp == 64) HL_MF(64) else HL_REQUIRE(false, HLVAE_EINVAL, "latent_dim > 64");
+#undef HL_MF
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hl_launch_mid_bwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_w,
+                            int B, int Bp, hipStream_t s) {
+    const hlvae_dims& d = p->d;
+    HL_REQUIRE(Bp % MID_ROWS == 0 && d.hep % 64 == 0 && d.hdp % 64 == 0, HLVAE_ESHAPE, "mid_bwd_fused shapes");
+    const size_t smem = mid_bwd_smem(d.Lp, d.hdp);
+    HL_REQUIRE(smem <= 150 * 1024, HLVAE_EINVAL, "hidden width too large for the fused middle kernel (%zu B of LDS)", smem);
+    HL_PROF("mid_bwd_fused", s);
+#define HL_MB(LPv)                                                                                                     \
+    {                                                                                                                  \
+        static size_t attr_max = 48 * 1024;                                                                            \
+        if (smem > attr_max) {                                                                                         \
+            HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mid_bwd_fused<LPv>),                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                      \
+            attr_max = smem;                                                                                           \
+        }                                                                                                              \
+        k_mid_bwd_fused<LPv><<<Bp / MID_ROWS, MID_THREADS, smem, s>>>(                                                    \
+            ws->slab, ws->splitk_dec, Bp, d.hdp, d.h_d, ws->u, ws->duT, ws->G + d.o_bd, ws->wdTs, ws->eps, ws->lv,     \
+            ws->mu, g_mu, g_lv, kl_w, d.L, ws->dmlT, ws->G + d.o_bmu, ws->G + d.o_blv, ws->wmlTs, d.hep, d.h_e, ws->t, \
+            ws->dtT, ws->G + d.o_b1, B);                                                                               \
+    }
+    if (d.Lp == 32) HL_MB(32) else if (d.Lp == 64) HL_MB(64) else HL_REQUIRE(false, HLVAE_EINVAL, "latent_dim > 64");
+#undef HL_MB
+    HL_LAUNCH_CHECK();
+    return 0;
+}

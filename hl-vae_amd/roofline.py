@@ -32,18 +32,17 @@ def algorithmic_work(model, B):
     w["colstats"] = (B * d.n_stat * 16, 0)
     w["normalize_pack"] = (B * (X + D) * 8 + 2 * B * Xp * 2 + B * D * 5, 0)
     w["enc1_splitk"] = ((B * Xp + hep * Xp) * 2 + S_e * B * hep * 4, 2 * B * X * he)
-    w["enc1_reduce_relu"] = (S_e * B * hep * 4 + 2 * B * hep * 2, 0)
-    w["enc_head_reparam"] = ((B * hep + 2 * Lp * hep) * 2 + B * L * 16 + 2 * B * Lp * 2, 2 * B * he * 2 * L)
+    w["mid_fwd_fused"] = (S_e * B * hep * 4 + 2 * B * hep * 2 + 2 * Lp * hep * 2 + B * L * 16 + hdp * Lp * 2 + 2 * B * hdp * 2,
+                          2 * B * he * 2 * L + 2 * B * L * hd)
     w["dec1_relu"] = ((B * Lp + hdp * Lp) * 2 + 2 * B * hdp * 2, 2 * B * L * hd)
     w["y_heads_loglik"] = ((B * hdp + NY * hdp) * 2 + B * D * 5 + 2 * B * NY * 2 + 2 * B * D * 4, 2 * B * NY * hd + 150 * B * D)
     w["elbo_finalize"] = (((D + 15) // 16) * B * 4, 0)
     w["dWy"] = ((NY * Bp + hdp * Bp) * 2 + NY * hd * 4, 2 * B * NY * hd)
     w["dU_splitk"] = ((B * d.NYp + hdp * d.NYp) * 2 + S_d * B * hdp * 4, 2 * B * NY * hd)
-    w["dU_reduce_relu_bwd"] = (S_d * B * hdp * 4 + 3 * B * hdp * 2, 0)
+    w["mid_bwd_fused"] = (S_d * B * hdp * 4 + 2 * B * hdp * 2 + B * L * 16 + 2 * B * 2 * Lp * 2 + 2 * B * hep * 2,
+                          2 * B * hd * L + 2 * B * 2 * L * he)
     w["dWd"] = ((hdp * Bp + Lp * Bp) * 2 + hd * L * 4, 2 * B * hd * L)
-    w["dz_reparam_bwd"] = ((B * hdp + Lp * hdp) * 2 + B * L * 16 + 2 * B * 2 * Lp * 2, 2 * B * hd * L)
     w["dWmu_dWlv"] = ((2 * Lp * Bp + hep * Bp) * 2 + 2 * L * he * 4, 2 * B * 2 * L * he)
-    w["dT_relu_bwd"] = ((B * 2 * Lp + hep * 2 * Lp) * 2 + 3 * B * hep * 2, 2 * B * 2 * L * he)
     w["dW1"] = ((hep * Bp + Xp * Bp) * 2 + he * X * 4, 2 * B * X * he)
     n_w = he * X + 2 * L * he + hd * L + NY * hd
     shadow_bytes = (he * X + 2 * (2 * L * he + hd * L + NY * hd)) * 2

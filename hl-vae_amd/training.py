@@ -82,7 +82,7 @@ class ELBOTrainer:
         _lib.check(lib.hlvae_encoder_fwd(m._plan_handle, ws, _lib.ptr(eps), 1, C.c_uint64(0), B, s), "encoder_fwd")
         if not m._grad_region_clean:     # normally the fused Adam leaves the atomically-accumulated region zeroed
             _lib.check(lib.hlvae_zero_grad(m._plan_handle, ws, s), "zero_grad")
-        _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 1, int(self.metrics), B, s), "decoder_fwd")
+        _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 1, int(self.metrics), 0, B, s), "decoder_fwd")
         g_mu = g_lv = None
         kl_w = 1.0 if self.kl == "normal" else 0.0
         if self.kl == "gp":

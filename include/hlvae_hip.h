@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 2
+#define HLVAE_ABI_VERSION 3
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -148,9 +148,11 @@ int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps,
  * g_logpx: upstream gradient of log_p_x, per element [B][D] fp32, or NULL -> the scalar g_scale.
  * Writes ws->dy = g * d log_p_x / d Y (zero where unobserved: stop-gradient of HLVAE.py:435-452) and
  * accumulates the head-parameter gradients into ws->G when want_grad != 0.
- * want_params != 0 additionally fills ws->pfull and ws->xhat (row M / p_params). */
+ * want_params != 0 additionally fills ws->pfull and ws->xhat (row M / p_params).
+ * trunk != 0 recomputes the decoder trunk U = relu(z Wd^T + bd) from ws->zb first (decode(z) with a caller-set z);
+ * hlvae_encoder_fwd already leaves U in the workspace (it is fused with the reparameterisation). */
 int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, float g_scale,
-                      int want_grad, int want_params, int B, hlvae_stream s);
+                      int want_grad, int want_params, int trunk, int B, hlvae_stream s);
 
 /* rescale ws->dy by a per-element upstream gradient after the fact (autograd path) */
 int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, int B, hlvae_stream s);
