@@ -398,7 +398,7 @@ class HLVAE(nn.Module):
         _lib.check(lib.hlvae_zero_grad(self._plan_handle, ws, s), "zero_grad")
         _lib.check(lib.hlvae_decoder_fwd(self._plan_handle, ws, _lib.ptr(g_lpx), C.c_float(0.0 if g_lpx is None else 1.0),
                                          1, 0, 0, B, s), "decoder_fwd(grad)")
-        _lib.check(lib.hlvae_backward(self._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(0.0), B, s), "backward")
+        _lib.check(lib.hlvae_backward(self._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(0.0), 0, B, s), "backward")
         self._grad_region_clean = False
 
     def _assign_grads(self):

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -55,7 +55,8 @@ _SIGS = {
     "hlvae_encoder_fwd": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, C.c_uint64, C.c_int, _vp]),
     "hlvae_decoder_fwd": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "hlvae_scale_dy": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, _vp]),
-    "hlvae_backward": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_float, C.c_int, _vp]),
+    "hlvae_backward": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_float, C.c_int, C.c_int, _vp]),
+    "hlvae_backward_wy": (C.c_int, [_vp, C.POINTER(HlvaeWs), C.c_int, _vp]),
     "hlvae_zero_grad": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp]),
     "hlvae_adam_step": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _vp]),

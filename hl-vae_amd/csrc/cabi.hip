@@ -229,8 +229,15 @@ int hlvae_zero_grad(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s) {
     return 0;
 }
 
+int hlvae_backward_wy(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stream s) {
+    CHECK_B();
+    // d Wy = dY^T U   [NY][h_d]: the largest gradient (55 % of the arena for D4) and the first one that is final, so a
+    // data-parallel host can start its all-reduce while hlvae_backward(skip_wy = 1) is still running
+    return hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", st);
+}
+
 int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
-                   int B, hlvae_stream s) {
+                   int skip_wy, int B, hlvae_stream s) {
     CHECK_B();
     int rc;
     HL_REQUIRE(ws->splitk_dec >= 1, HLVAE_EINVAL, "splitk_dec");
@@ -241,7 +248,8 @@ int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, c
     HL_CHECK(hipEventRecord(p->ev[0], st));
     HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
     // d Wy = dY^T U                                  [NY][h_d]
-    if ((rc = hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
+    if (!skip_wy)
+        if ((rc = hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
     // d U slabs = dY Wy (split-K), then the fused middle: dU -> dz -> d(mu, lv) -> dT, bias gradients
     if ((rc = hl_launch_gemm_splitk(ws->dy, d.NYp, ws->wyTs, d.NYp, ws->slab, d.hdp, Bp, d.hdp, d.NYp, ws->splitk_dec, "dU_splitk", st))) return rc;
     if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st))) return rc;

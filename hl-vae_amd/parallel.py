@@ -31,6 +31,11 @@ class DataParallel:
     def allreduce_grads(self, grad_arena: torch.Tensor):
         dist.all_reduce(grad_arena, op=dist.ReduceOp.SUM, group=self.group)
 
+    def allreduce_async(self, t: torch.Tensor):
+        """starts the collective on the backend's own stream (it first waits for the work already queued on the current
+        stream); ``.wait()`` on the returned handle makes the current stream wait for the result"""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def allreduce_(self, t: torch.Tensor):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t

@@ -87,10 +87,21 @@ class ELBOTrainer:
         kl_w = 1.0 if self.kl == "normal" else 0.0
         if self.kl == "gp":
             g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch)
-        _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), B, s), "backward")
+        if self.dp is None:
+            _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 0, B, s), "backward")
+        else:
+            # data parallel: the y_layer gradient (the largest slice of the arena) is final first; its all-reduce runs on
+            # RCCL's stream while the rest of the backward pass is still computing
+            d = m._dims
+            _lib.check(lib.hlvae_backward_wy(m._plan_handle, ws, B, s), "backward_wy")
+            G = m._grad_arena
+            lo, hi = int(d.o_wy), int(d.o_wy) + int(d.NY) * int(d.h_d)
+            pending = self.dp.allreduce_async(G[lo:hi])
+            _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 1, B, s), "backward")
+            self.dp.allreduce_(G[:lo])
+            self.dp.allreduce_(G[hi:])
+            pending.wait()
         m._fwd_token += 1
-        if self.dp is not None:
-            self.dp.allreduce_grads(m._grad_arena)
         self.opt.step()
         m._grad_region_clean = True
         if self.kl == "gp":

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 3
+#define HLVAE_ABI_VERSION 4
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -162,7 +162,10 @@ int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx
  * kl_std_weight != 0 adds the gradient of kl_std_weight * KL(q(z|x) || N(0,I)) in the same kernel
  * (closed form; NOT in the reference). */
 int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv,
-                   float kl_std_weight, int B, hlvae_stream s);
+                   float kl_std_weight, int skip_wy, int B, hlvae_stream s);
+/* only d Wy = dY^T U, on the given stream.  Data-parallel hosts call this first, start the all-reduce of that arena
+ * slice, then hlvae_backward(..., skip_wy = 1): the collective overlaps the rest of the backward pass. */
+int hlvae_backward_wy(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stream s);
 /* zero the atomically accumulated gradient region; call before hlvae_decoder_fwd(want_grad=1) */
 int hlvae_zero_grad(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s);
 

@@ -414,3 +414,32 @@ def test_tabular_config4_batch4096_against_oracle():
         e = rel_err(p.grad, st[k].grad)
         _report("tabular_b4096_grads", **{k: e})
         assert e < 3e-2, (k, e)
+
+
+def test_data_parallel_code_path_single_rank_rccl(golden_dir):
+    """the data-parallel step (statistics all-reduce, split backward with the overlapped y_layer all-reduce, the two
+    remaining arena slices) on a ONE-rank RCCL group must reproduce the plain step bit for bit (same kernels, the
+    collectives are identities): exercises the real nccl/RCCL code path that the multi-GPU bench uses."""
+    import torch.distributed as dist
+    from hlvae_amd.parallel import DataParallel
+    from hlvae_amd.training import ELBOTrainer
+    g, src, dims, state = load_mix_case(golden_dir, "mix_trained")
+    dev = _dev()
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1, device_id=dev)
+    try:
+        data, mask = torch.tensor(g["data"], device=dev), torch.tensor(g["mask"], device=dev)
+        eps = torch.tensor(g["eps"], device=dev).float()
+        results = []
+        for use_dp in (False, True):
+            model = _model_from_state(src, dims, state)
+            tr = ELBOTrainer(model, P_total=40, kl="normal", max_batch=128, dp=DataParallel(dist.group.WORLD) if use_dp else None)
+            for _ in range(2):
+                tr.step(data, mask, 4, eps=eps)
+            torch.cuda.synchronize()
+            results.append((float(tr.scalars()["nll_sum"]), model._arena.clone()))
+        assert results[0][0] == results[1][0]
+        # fp32 atomics in the small-gradient region may reorder between runs: allow rounding-level differences
+        assert rel_err(results[1][1], results[0][1]) < 1e-5
+    finally:
+        dist.destroy_process_group()
