@@ -7,8 +7,8 @@ batches at 1/2/4/8 MI355X).
         bench.py --gpus N --steps K --warmup W
 
 A "step" = one full pass of the hot path over one batch: normalise/pack -> encoder -> reparameterise ->
-decoder + heads + log-likelihoods (+ backward) -> KL -> dense backward -> [RCCL gradient all-reduce] ->
-Adam.  Workload at N=1 = BASELINE.json configs[1]: the 1k-sample synthetic D4 set (50 subjects x 20 rows,
+decoder + heads + log-likelihoods (+ backward) + imputed values -> per-variable reconstruction metrics -> KL ->
+dense backward -> [RCCL gradient all-reduce] -> Adam  (the training.py:70-137 sequence).  Workload at N=1 = BASELINE.json configs[1]: the 1k-sample synthetic D4 set (50 subjects x 20 rows,
 324 real + 972 five-class categorical variables, 25 % missing), MLP [5184,[500],32,[500],5], batch 512 rows
 (25 whole subjects + 12 rows of a 26th; whole-subject batching is the reference's sampler semantics),
 bf16 MFMA encoder/decoder with fp32 ELBO accumulation.  Inputs are the reference's fp64 [B,X]/[B,D] batch
@@ -135,7 +135,7 @@ def main():
     if kl == "gp":
         from hlvae_amd.elbo_functions import GPPrior
         gp = GPPrior.from_reference_config(model, src, P_total, dev)
-    trainer = ELBOTrainer(model, P_total=P_total, kl=kl, gp=gp, max_batch=a.batch, dp=dp)
+    trainer = ELBOTrainer(model, P_total=P_total, kl=kl, gp=gp, max_batch=a.batch, dp=dp, metrics=True)
     ring = build_batches(src, a.batch, 4, dev)
     use_graph = not a.no_graph and world == 1
     if use_graph:
@@ -175,6 +175,13 @@ def main():
         print(f"[bench] {world} GPU(s): {value:.0f} samples/s, {1e3 * dt / a.steps:.4f} ms/step", file=sys.stderr, flush=True)
     from hlvae_amd import roofline
     roof = roofline.measure_dominant_kernel(trainer, ring[0], a.steps) if rank == 0 else None
+    if roof is not None:      # HBM traffic from PMC counters is collected offline (separate rocprofv3 --pmc passes)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if pm["kernel"].startswith("k_adam_tiled") and roof["kernel"] == "adam_weights_shadows":
+                roof["traffic"] = pm["traffic_bytes_per_launch"]
+        except Exception:
+            pass
 
     if rank == 0:
         print(f"[bench] roofline: {json.dumps(roof)}", file=sys.stderr, flush=True)

@@ -323,6 +323,7 @@ class HLVAE(nn.Module):
             log_p_x=z(Bp, d.D, dt=f32), log_p_x_missing=z(Bp, d.D, dt=f32), rowpart=z(NT, Bp, dt=f32),
             nll=z(Bp, dt=f32), scal=z(8, dt=torch.float64), klpart=z(max(Bp // 64, 1), dt=torch.float64),
             eps=z(Bp, d.L, dt=f32), rng=z(2, dt=torch.int64), pfull=z(Bp, d.X, dt=f32), xhat=z(Bp, d.D, dt=f32),
+            metpart=z(16, 6, d.D, dt=f32),
             du=z(Bp, d.hdp), duT=z(d.hdp, Bp), dz=z(Bp, d.Lp, dt=f32), dml=z(Bp, 2 * d.Lp), dmlT=z(2 * d.Lp, Bp),
             dt=z(Bp, d.hep), dtT=z(d.hep, Bp))
         t["P"] = self._arena
@@ -463,6 +464,16 @@ class HLVAE(nn.Module):
                 idx = td.Categorical(logits=torch.log(torch.clamp(p, 1e-6, 1e20))).sample()
                 out.append((torch.arange(1, K + 1, device=p.device)[None, None, :] <= (1 + idx)[:, :, None]).to(torch.float64))
         return out
+
+    def step_metrics(self, B: int):
+        """Row M on the device: per-variable (error_observed, error_missing, error_all) of the last forward pass that
+        was run with parameters materialised (reference training.py:84-101 -> read_functions.error_computation with
+        true_miss_mask = 1).  Also returns the imputed values x_hat [B, D] (read_functions.statistics 'mean')."""
+        err = torch.empty(3, self.plan.D, dtype=torch.float32, device=self.device)
+        lib = _lib.load()
+        _lib.check(lib.hlvae_step_metrics(self._plan_handle, C.byref(self._ws), B, _lib.ptr(err), self._stream()), "step_metrics")
+        _lib.check(lib.hlvae_join(self._plan_handle, self._stream()), "join")
+        return err[0], err[1], err[2], self._ws_t["xhat"][:B]
 
     # ------------------------------------------------------------------ reference call surface
     def sample_latent(self, mu, log_var):                                            # HLVAE.py:351-362

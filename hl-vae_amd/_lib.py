@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 7
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -29,7 +29,7 @@ class HlvaeDims(C.Structure):
 
 WS_POINTERS = ("P", "G", "w1s", "wmls", "wmlTs", "wds", "wdTs", "wys", "wyTs", "sums", "norm", "xn", "xnT", "xt", "m8",
                "slab", "t", "tT", "mu", "lv", "z", "zb", "zbT", "u", "uT", "dy", "dyT", "log_p_x", "log_p_x_missing",
-               "rowpart", "nll", "scal", "klpart", "eps", "rng", "pfull", "xhat", "du", "duT", "dz", "dml", "dmlT", "dt", "dtT")
+               "rowpart", "nll", "scal", "klpart", "eps", "rng", "pfull", "xhat", "metpart", "du", "duT", "dz", "dml", "dmlT", "dt", "dtT")
 
 
 class HlvaeWs(C.Structure):
@@ -54,6 +54,8 @@ _SIGS = {
     "hlvae_normalize_pack": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_int, _vp]),
     "hlvae_encoder_fwd": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, C.c_uint64, C.c_int, _vp]),
     "hlvae_decoder_fwd": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "hlvae_step_metrics": (C.c_int, [_vp, C.POINTER(HlvaeWs), C.c_int, _vp, _vp]),
+    "hlvae_join": (C.c_int, [_vp, _vp]),
     "hlvae_scale_dy": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, _vp]),
     "hlvae_backward": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_float, C.c_int, C.c_int, _vp]),
     "hlvae_backward_wy": (C.c_int, [_vp, C.POINTER(HlvaeWs), C.c_int, _vp]),

@@ -13,6 +13,7 @@ int hl_launch_gemm_act(int, const bf16_t*, int, const bf16_t*, int, int, int, in
                        bf16_t*, int, bf16_t*, int, int, float*, const char*, hipStream_t);
 int hl_launch_y_heads(const hlvae_plan*, const hlvae_ws*, const float*, float, int, int, int, int, hipStream_t);
 int hl_launch_scale_dy(const hlvae_plan*, const hlvae_ws*, const float*, int, int, hipStream_t);
+int hl_launch_step_metrics(const hlvae_plan*, const hlvae_ws*, int, float*, hipStream_t);
 int hl_launch_stats(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, hipStream_t);
 int hl_launch_pack(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, int, hipStream_t);
 int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
@@ -133,6 +134,7 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     p->d = d;
     p->vars_dev = nullptr; p->col2var_dev = nullptr; p->stat_var_dev = nullptr;
     p->kmax = 2;
+    p->metrics_pending = 0;
     for (int i = 0; i < d.D; ++i)
         if ((vars[i].kind == HLVAE_CAT || vars[i].kind == HLVAE_ORDINAL) && vars[i].ncls > p->kmax) p->kmax = vars[i].ncls;
     for (auto& st : p->side) st = nullptr;
@@ -223,6 +225,28 @@ int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx
     return hl_launch_scale_dy(p, ws, g_logpx, B, Bp, st);
 }
 
+int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* err, hlvae_stream s) {
+    CHECK_B();
+    // metrics only READ what the decoder left behind: they run on a side stream beside whatever the caller queues next
+    // (normally the backward pass); the caller's stream re-joins in hlvae_backward or hlvae_join
+    HL_CHECK(hipEventRecord(p->ev[5], st));
+    HL_CHECK(hipStreamWaitEvent(p->side[0], p->ev[5], 0));
+    int rc = hl_launch_step_metrics(p, ws, B, err, p->side[0]);
+    if (rc) return rc;
+    HL_CHECK(hipEventRecord(p->ev[5], p->side[0]));
+    p->metrics_pending = 1;          // joined by the next hlvae_backward / hlvae_join on this plan
+    return 0;
+}
+
+int hlvae_join(const hlvae_plan* p, hlvae_stream s) {
+    HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
+    if (p->metrics_pending) {
+        HL_CHECK(hipStreamWaitEvent((hipStream_t)s, p->ev[5], 0));
+        p->metrics_pending = 0;
+    }
+    return 0;
+}
+
 int hlvae_zero_grad(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s) {
     HL_REQUIRE(p && ws, HLVAE_EINVAL, "null plan/workspace");
     HL_CHECK(hipMemsetAsync(ws->G, 0, sizeof(float) * p->d.atomic_region, (hipStream_t)s));
@@ -265,7 +289,7 @@ int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, c
     HL_CHECK(hipEventRecord(p->ev[4], s1));
     HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
     HL_CHECK(hipStreamWaitEvent(st, p->ev[4], 0));
-    return 0;
+    return hlvae_join(p, s);
 }
 
 int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr,

@@ -53,6 +53,7 @@ struct hlvae_plan {
     // fork/join side streams: independent weight-gradient GEMMs run beside the critical path of the backward
     hipStream_t side[2];
     hipEvent_t ev[6];
+    mutable int metrics_pending;   // hlvae_step_metrics forked onto side[0] and has not been joined yet
 };
 
 void hl_set_error(const char* fmt, ...);

@@ -84,10 +84,8 @@ __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int 
                 dth = g * rr * inv_ev * sd;
                 acc[YD + 1] += g * (0.5f * rr * rr * inv_ev - 0.5f) * dp_fac;
             }
-            if (pfull != nullptr) {
-                pfull[(size_t)gr * X + var.xoff] = mean;         // loglik.py:64-67 (mean only)
-                xhat[o] = is_pos ? __expf(mean + 0.5f * pos_var) - 1.f : mean;   // read_functions.py:277,288
-            }
+            if (pfull != nullptr) pfull[(size_t)gr * X + var.xoff] = mean;      // loglik.py:64-67 (mean only)
+            if (xhat != nullptr) xhat[o] = is_pos ? __expf(mean + 0.5f * pos_var) - 1.f : mean;   // read_functions.py:277,288
         }
         lpo[i] = lp_obs;
         acc[YD] += dth;
@@ -137,10 +135,8 @@ __device__ __forceinline__ void proc_count(float* Cs, int v, int rg, int m0, int
                 lp_obs = lp;
                 if (sp >= 1e-6f && sp <= 1e20f) dth = g * (x / lam - 1.f) * sigmoid_f(th);
             }
-            if (pfull != nullptr) {
-                pfull[(size_t)gr * X + var.xoff] = lam;
-                xhat[o] = lam;                                   // read_functions.py:294
-            }
+            if (pfull != nullptr) pfull[(size_t)gr * X + var.xoff] = lam;
+            if (xhat != nullptr) xhat[o] = lam;                  // read_functions.py:294
         }
         lpo[i] = lp_obs;
         acc[YD] += dth;
@@ -217,14 +213,16 @@ __device__ __forceinline__ void proc_cat(float* Cs, int v, int rg, int m0, int B
             if (pfull != nullptr) {
                 float* pf = pfull + (size_t)gr * X + var.xoff;
                 pf[0] = -lse;                                    // params = normalised log_pi (:139)
+#pragma unroll
+                for (int j = 0; j < KM - 1; ++j)
+                    if (j < K - 1) pf[j + 1] = th[j] - lse;
+            }
+            if (xhat != nullptr) {
                 int am = 0;
                 float best = 0.f;
 #pragma unroll
                 for (int j = 0; j < KM - 1; ++j)
-                    if (j < K - 1) {
-                        pf[j + 1] = th[j] - lse;
-                        if (th[j] > best) { best = th[j]; am = j + 1; }
-                    }
+                    if (j < K - 1 && th[j] > best) { best = th[j]; am = j + 1; }
                 xhat[o] = (float)am;                             // read_functions.py:297-299 (first max)
             }
         }
@@ -343,14 +341,16 @@ __device__ __forceinline__ void proc_ord(float* Cs, int v, int rg, int m0, int B
             }
             if (pfull != nullptr) {
                 float* pf = pfull + (size_t)gr * X + var.xoff;
+#pragma unroll
+                for (int c = 0; c < KM; ++c)
+                    if (c < K) pf[c] = pc[c] * invS;             // params = normalised mean_probs (:183)
+            }
+            if (xhat != nullptr) {
                 int am = 0;
                 float best = pc[0];
 #pragma unroll
                 for (int c = 0; c < KM; ++c)
-                    if (c < K) {
-                        pf[c] = pc[c] * invS;                    // params = normalised mean_probs (:183)
-                        if (pc[c] > best) { best = pc[c]; am = c; }
-                    }
+                    if (c < K && pc[c] > best) { best = pc[c]; am = c; }
                 xhat[o] = (float)am;
             }
         }
@@ -569,6 +569,98 @@ __global__ __launch_bounds__(1024) void k_elbo_finalize(const float* __restrict_
     }
 }
 
+// Row M: per-variable reconstruction errors of the imputed values (reference read_functions.py:342-412 with
+// true_miss_mask = 1, conv False): categorical 0/1 mismatch, ordinal |x - x_hat| / K, continuous (x_hat - x)^2 / range^2
+// (range = max - min of the batch column, 1 if zero), averaged over observed / missing / all rows, sqrt for continuous.
+// The range is a per-column constant, so ONE pass accumulates the un-normalised sums together with max / min:
+//   k_metrics_partial  grid (D/64, 16 row chunks): part[chunk][6][D] = {max, min, sum_obs, sum_miss, n_obs, n_miss}
+//   k_metrics_finish   combines the 16 partials -> err[3][D] = observed, missing, all
+#define HL_MET_CHUNKS 16
+__global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict__ xt, const uint8_t* __restrict__ m8,
+                                                         const float* __restrict__ xhat, const hlvae_var* __restrict__ vars,
+                                                         int B, int D, float* __restrict__ part) {
+    __shared__ float red[6][4][64];
+    const int d = blockIdx.x * 64 + threadIdx.x, g = threadIdx.y;
+    const int rpc = (B + HL_MET_CHUNKS - 1) / HL_MET_CHUNKS;
+    const int b_lo = blockIdx.y * rpc, b_hi = min(B, b_lo + rpc);
+    int kind = -1, K = 1;
+    if (d < D) { kind = vars[d].kind; K = vars[d].ncls; }
+    float mx = -3.4e38f, mn = 3.4e38f, so = 0.f, sm = 0.f, no = 0.f, nm = 0.f;
+    if (d < D)
+        for (int b = b_lo + g; b < b_hi; b += 4) {
+            const size_t o = (size_t)b * D + d;
+            float x = xt[o];
+            const float xh = xhat[o];
+            float e;
+            if (kind == HLVAE_CAT) {
+                e = (fmaxf(x, 0.f) != xh) ? 1.f : 0.f;           // argmax of an all-zero one-hot row is class 0
+            } else if (kind == HLVAE_ORDINAL) {
+                e = fabsf(x - xh) / (float)K;
+            } else {
+                if (kind == HLVAE_POS) x = expm1f(x);            // the target buffer holds log1p(x) for pos
+                mx = fmaxf(mx, x);
+                mn = fminf(mn, x);
+                e = (xh - x) * (xh - x);
+            }
+            if (m8[o]) { so += e; no += 1.f; } else { sm += e; nm += 1.f; }
+        }
+    red[0][g][threadIdx.x] = mx; red[1][g][threadIdx.x] = mn; red[2][g][threadIdx.x] = so;
+    red[3][g][threadIdx.x] = sm; red[4][g][threadIdx.x] = no; red[5][g][threadIdx.x] = nm;
+    __syncthreads();
+    if (g == 0 && d < D) {
+        float* out = part + (size_t)blockIdx.y * 6 * D + d;
+        out[0] = fmaxf(fmaxf(red[0][0][threadIdx.x], red[0][1][threadIdx.x]), fmaxf(red[0][2][threadIdx.x], red[0][3][threadIdx.x]));
+        out[D] = fminf(fminf(red[1][0][threadIdx.x], red[1][1][threadIdx.x]), fminf(red[1][2][threadIdx.x], red[1][3][threadIdx.x]));
+#pragma unroll
+        for (int k = 2; k < 6; ++k)
+            out[(size_t)k * D] = red[k][0][threadIdx.x] + red[k][1][threadIdx.x] + red[k][2][threadIdx.x] + red[k][3][threadIdx.x];
+    }
+}
+
+__global__ void k_metrics_finish(const float* __restrict__ part, const hlvae_var* __restrict__ vars, int B, int D,
+                                 float* __restrict__ err) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float mx = -3.4e38f, mn = 3.4e38f, s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < HL_MET_CHUNKS; ++c) {
+        const float* p = part + (size_t)c * 6 * D + d;
+        mx = fmaxf(mx, p[0]);
+        mn = fminf(mn, p[D]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += p[(size_t)(k + 2) * D];
+    }
+    const int kind = vars[d].kind;
+    const bool disc = kind == HLVAE_CAT || kind == HLVAE_ORDINAL;
+    float inv2 = 1.f;
+    if (!disc) {
+        float nt = mx - mn;
+        if (nt == 0.f) nt = 1.f;                                 // read_functions.py:372
+        inv2 = 1.f / (nt * nt);
+    }
+    float eo = s[0] * inv2 / fmaxf(s[2], 1.f), em = s[1] * inv2 / fmaxf(s[3], 1.f), ea = (s[0] + s[1]) * inv2 / fmaxf((float)B, 1.f);
+    if (!disc) { eo = sqrtf(eo); em = sqrtf(em); ea = sqrtf(ea); }           // RMSE (read_functions.py:390-393)
+    err[d] = eo;
+    err[D + d] = em;
+    err[2 * D + d] = ea;
+}
+
+int hl_launch_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* err, hipStream_t s) {
+    const hlvae_dims& d = p->d;
+    HL_REQUIRE(ws->xhat != nullptr && err != nullptr && ws->metpart != nullptr, HLVAE_EINVAL,
+               "step_metrics: needs ws->xhat (decoder_fwd with want_params), ws->metpart and err");
+    {
+        HL_PROF("metrics_partial", s);
+        k_metrics_partial<<<dim3((d.D + 63) / 64, HL_MET_CHUNKS), dim3(64, 4), 0, s>>>(ws->xt, ws->m8, ws->xhat, p->vars_dev, B,
+                                                                                      d.D, ws->metpart);
+    }
+    HL_LAUNCH_CHECK();
+    HL_PROF("metrics_finish", s);
+    k_metrics_finish<<<(d.D + 255) / 256, 256, 0, s>>>(ws->metpart, p->vars_dev, B, d.D, err);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
 // dY *= g[b][d] after the fact (autograd path with a non-uniform upstream gradient)
 __global__ void k_scale_dy(bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dyT, int Bp,
                            const float* __restrict__ g, int B, int D, int YD) {
@@ -589,9 +681,9 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
     const hlvae_dims& d = p->d;
     HL_REQUIRE(d.y_dim == 5, HLVAE_EINVAL, "y_dim=%d: only y_dim=5 (the reference configuration) is instantiated", d.y_dim);
     const int NT = (d.D + 15) / 16;
-    float* pf = want_params ? ws->pfull : nullptr;
+    float* pf = want_params == 1 ? ws->pfull : nullptr;      // 1: p_params + x_hat, 2: x_hat only (training metrics)
     float* xh = want_params ? ws->xhat : nullptr;
-    HL_REQUIRE(!want_params || (ws->pfull && ws->xhat), HLVAE_EINVAL, "want_params without pfull/xhat buffers");
+    HL_REQUIRE(!want_params || (ws->xhat && (want_params != 1 || ws->pfull)), HLVAE_EINVAL, "want_params without pfull/xhat buffers");
     {
         HL_PROF("y_heads_loglik", s);
         const bool big = (long)(Bp / 128) * NT >= 512;

@@ -36,6 +36,8 @@ def algorithmic_work(model, B):
                           2 * B * he * 2 * L + 2 * B * L * hd)
     w["dec1_relu"] = ((B * Lp + hdp * Lp) * 2 + 2 * B * hdp * 2, 2 * B * L * hd)
     w["y_heads_loglik"] = ((B * hdp + NY * hdp) * 2 + B * D * 5 + 2 * B * NY * 2 + 2 * B * D * 4, 2 * B * NY * hd + 150 * B * D)
+    w["metrics_partial"] = (B * D * 9, 0)
+    w["metrics_finish"] = (16 * 6 * D * 4, 0)
     w["elbo_finalize"] = (((D + 15) // 16) * B * 4, 0)
     w["dWy"] = ((NY * Bp + hdp * Bp) * 2 + NY * hd * 4, 2 * B * NY * hd)
     w["dU_splitk"] = ((B * d.NYp + hdp * d.NYp) * 2 + S_d * B * hdp * 4, 2 * B * NY * hd)

@@ -64,6 +64,7 @@ class ELBOTrainer:
         self.opt = FusedAdam(model, lr=lr)
         dev, L = model.device, model.z_dim
         self._graphs = {}
+        self.err = torch.zeros(3, model.plan.D, dtype=torch.float32, device=dev)     # error_observed / missing / all
 
     # -- the step, eager ------------------------------------------------------------------------
     def step(self, data: torch.Tensor, mask: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None,
@@ -82,7 +83,9 @@ class ELBOTrainer:
         _lib.check(lib.hlvae_encoder_fwd(m._plan_handle, ws, _lib.ptr(eps), 1, C.c_uint64(0), B, s), "encoder_fwd")
         if not m._grad_region_clean:     # normally the fused Adam leaves the atomically-accumulated region zeroed
             _lib.check(lib.hlvae_zero_grad(m._plan_handle, ws, s), "zero_grad")
-        _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 1, int(self.metrics), 0, B, s), "decoder_fwd")
+        _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 1, 2 if self.metrics else 0, 0, B, s), "decoder_fwd")
+        if self.metrics:     # row M: imputed values + per-variable errors (training.py:84-101), device resident
+            _lib.check(lib.hlvae_step_metrics(m._plan_handle, ws, B, _lib.ptr(self.err), s), "step_metrics")
         g_mu = g_lv = None
         kl_w = 1.0 if self.kl == "normal" else 0.0
         if self.kl == "gp":

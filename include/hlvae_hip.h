@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 4
+#define HLVAE_ABI_VERSION 7
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -106,6 +106,7 @@ typedef struct {
     uint64_t* rng;       /* [2]: Philox seed, offset (advanced by one per step on device)    */
     float* pfull;        /* [Bp][X]  likelihood parameters concatenated by key (row M), optional */
     float* xhat;         /* [Bp][D]  per-variable imputed value (statistics mean), optional */
+    float* metpart;      /* [16][6][D] partials of the row-M metrics kernel                  */
     /* backward activations */
     uint16_t* du; uint16_t* duT;     /* [Bp][hdp], [hdp][Bp]                                */
     float* dz;                       /* [Bp][Lp]                                            */
@@ -148,11 +149,19 @@ int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps,
  * g_logpx: upstream gradient of log_p_x, per element [B][D] fp32, or NULL -> the scalar g_scale.
  * Writes ws->dy = g * d log_p_x / d Y (zero where unobserved: stop-gradient of HLVAE.py:435-452) and
  * accumulates the head-parameter gradients into ws->G when want_grad != 0.
- * want_params != 0 additionally fills ws->pfull and ws->xhat (row M / p_params).
+ * want_params = 1 additionally fills ws->pfull and ws->xhat (p_params / row M); 2 = ws->xhat only (training metrics).
  * trunk != 0 recomputes the decoder trunk U = relu(z Wd^T + bd) from ws->zb first (decode(z) with a caller-set z);
  * hlvae_encoder_fwd already leaves U in the workspace (it is fused with the reparameterisation). */
 int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, float g_scale,
                       int want_grad, int want_params, int trunk, int B, hlvae_stream s);
+
+/* row M -- per-step reconstruction metrics (training.py:84-101 -> read_functions.py:342-412, true_miss_mask = 1):
+ * err [3][D] fp32 = per-variable error over observed / missing / all rows (0/1 mismatch for cat, |dx|/K for ordinal,
+ * range-normalised RMSE otherwise) from ws->xhat (decoder_fwd with want_params != 0), ws->xt and ws->m8. */
+int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* err, hlvae_stream s);
+/* hlvae_step_metrics runs on a library-owned side stream (forked from s); `err` is ordered before later work on a stream
+ * only after that stream called hlvae_backward or hlvae_join. */
+int hlvae_join(const hlvae_plan* p, hlvae_stream s);
 
 /* rescale ws->dy by a per-element upstream gradient after the fact (autograd path) */
 int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, int B, hlvae_stream s);

@@ -443,3 +443,24 @@ def test_data_parallel_code_path_single_rank_rccl(golden_dir):
         assert rel_err(results[1][1], results[0][1]) < 1e-5
     finally:
         dist.destroy_process_group()
+
+
+def test_step_metrics_against_reference_fixture(golden_dir):
+    """row M: error_observed / error_missing per variable from the device kernel against the values the reference's
+    read_functions.error_computation produced for the same batch (fixture), up to bf16-induced argmax flips."""
+    g, src, dims, state = load_mix_case(golden_dir, "mix_trained")
+    dev = _dev()
+    model = _model_from_state(src, dims, state)
+    data, mask = torch.tensor(g["data"], device=dev), torch.tensor(g["mask"], device=dev)
+    with torch.no_grad():
+        model(data, mask, None, src.types_info, eps=torch.tensor(g["eps"], device=dev))
+    e_obs, e_mis, e_all, xhat = model.step_metrics(24)
+    disc = np.isin(model.plan.kind, [3, 4])
+    xh, xr = xhat.cpu().numpy(), g["x_hat_mean"]
+    assert np.mean(xh[:, disc] == xr[:, disc]) > 0.97
+    assert np.allclose(xh[:, ~disc], xr[:, ~disc], rtol=3e-2, atol=3e-2)
+    # continuous variables: RMSE agrees to bf16 accuracy; discrete ones: at most one flipped row out of 24
+    eo, em = e_obs.cpu().numpy(), e_mis.cpu().numpy()
+    assert np.allclose(eo[~disc], g["err_observed"][~disc], rtol=5e-2, atol=5e-3)
+    assert np.allclose(em[~disc], g["err_missing"][~disc], rtol=5e-2, atol=5e-3)
+    assert np.all(np.abs(eo[disc] - g["err_observed"][disc]) <= 1.0 / 8) and np.all(np.abs(em[disc] - g["err_missing"][disc]) <= 1.0 / 4)
