@@ -133,8 +133,8 @@ def main():
     kl = None if a.kl == "none" else a.kl
     gp = None
     if kl == "gp":
-        from hlvae_amd.elbo_functions import GPPrior
-        gp = GPPrior.from_reference_config(model, src, P_total, dev)
+        from hlvae_amd.elbo_functions import GPPriorHIP
+        gp = GPPriorHIP.from_reference_config(model, src, P_total, dev)       # shipped kernels, M = 120 inducing points
     trainer = ELBOTrainer(model, P_total=P_total, kl=kl, gp=gp, max_batch=a.batch, dp=dp, metrics=True)
     ring = build_batches(src, a.batch, 4, dev)
     use_graph = not a.no_graph and world == 1

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -34,6 +34,16 @@ WS_POINTERS = ("P", "G", "w1s", "wmls", "wmlTs", "wds", "wdTs", "wys", "wyTs", "
 
 class HlvaeWs(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("Bp_max", "splitk_enc", "splitk_dec")] + [(n, _vp) for n in WS_POINTERS])
+
+
+GP_MAX_TERMS, GP_MAX_FACTORS = 8, 4
+GP_CAT, GP_BIN, GP_RBF = 0, 1, 2
+
+
+class HlvaeGpKernel(C.Structure):
+    _fields_ = [("n_terms", C.c_int32), ("scale_slot", C.c_int32 * GP_MAX_TERMS), ("n_factors", C.c_int32 * GP_MAX_TERMS),
+                ("kind", (C.c_int32 * GP_MAX_FACTORS) * GP_MAX_TERMS), ("dim", (C.c_int32 * GP_MAX_FACTORS) * GP_MAX_TERMS),
+                ("ls_slot", (C.c_int32 * GP_MAX_FACTORS) * GP_MAX_TERMS)]
 
 
 class HlvaeError(RuntimeError):
@@ -62,6 +72,17 @@ _SIGS = {
     "hlvae_zero_grad": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp]),
     "hlvae_adam_step": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _vp]),
+    "hlvae_gp_kernel_matrix": (C.c_int, [C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp,
+                                         C.c_int, C.c_int, C.c_double, _vp, _vp]),
+    "hlvae_gp_chol_inv": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "hlvae_gp_subject_fwd": (C.c_int, [C.POINTER(HlvaeGpKernel), C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp,
+                                       _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, _vp, _vp, _vp,
+                                       _vp, _vp, _vp, _vp, _vp]),
+    "hlvae_gp_subject_bwd": (C.c_int, [C.POINTER(HlvaeGpKernel), C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp,
+                                       _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp,
+                                       _vp]),
+    "hlvae_gp_param_grad": (C.c_int, [C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp,
+                                      C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "hlvae_prof_enable": (None, [C.c_int]),
     "hlvae_prof_report": (C.c_int, [C.c_char_p, C.c_int]),
     "hlvae_gemm_nt_f32": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

@@ -7,10 +7,17 @@ over subjects: the subjects of the batch are padded to a common T and every per-
 partials) is ONE batched fp64 operation over [S, L, T, T] / [S, L, T, M].  Padded rows/columns are
 turned into an identity block of B_st and masked out of every sum, which leaves the value unchanged.
 
-Round-1 status: the batched linear algebra runs through PyTorch-ROCm (rocBLAS / rocSOLVER) in fp64, with
-autograd for the kernel hyper-parameters and inducing points; it is NOT yet hand-written HIP (DESIGN.md
-section 7).  The gradients with respect to the VAE outputs (mu, log_var) are returned as fp32 tensors and
-enter the hand-written backward kernels through ``hlvae_backward(g_mu, g_lv)``.
+Two implementations of the same mathematics live here:
+
+* ``minibatch_KLD_upper_bound_iter`` / ``GPPrior``: batched fp64 PyTorch ops with autograd (device independent; the
+  readable statement, pinned to the reference fixture on CPU and used as the cross-check of the HIP path).
+* ``GPPriorHIP``: the structured pieces as hand-written fp64 HIP kernels behind the C ABI (csrc/gp.hip: kernel
+  matrices, LDS-resident Cholesky/inverse, the fused per-(subject, latent) block kernel, the chain rule into
+  hyper-parameters and inducing points) with ANALYTIC gradients -- no autograd graph -- and plain library GEMMs
+  (torch.matmul -> rocBLAS) for the [L,M,M] / [L,B,M] products in between.
+
+The gradients with respect to the VAE outputs (mu, log_var) are returned as fp32 [B, L] tensors and enter the
+hand-written backward kernels through ``hlvae_backward(g_mu, g_lv)``.
 
 ``GPPrior`` bundles what reference HLVAE_main.py:208-278 sets up: the two additive kernels, the inducing
 points ``zt_list``, the variational parameters (m, H), Adam over kernels + inducing points, and the
@@ -171,3 +178,201 @@ class GPPrior:
                                       "all-reduced before the non-linear terms (SURVEY.md section 8(e) caveat 2): next round")
         self.opt.step()
         self.m, self.H = natural_gradient_step(self.m, self.H, self._grad_m, self._grad_H, self.ng_lr)
+
+
+# ======================================================================================================================
+#  HIP path
+# ======================================================================================================================
+import ctypes as _C
+
+from . import _lib
+
+
+def _spec_from_config(cat_kernel, bin_kernel, sqexp_kernel, cat_int_kernel, bin_int_kernel, covariate_missing_val, id_covariate):
+    """(terms without id covariate, terms with it) as lists of factor lists [(kind, dim), ...], in the term order of
+    GP_model.generate_kernel_batched."""
+    miss = {d["covariate"]: d["mask"] for d in covariate_missing_val}
+
+    def wm(f, idx):
+        return f + ([(_lib.GP_BIN, miss[idx])] if idx in miss else [])
+
+    k0, k1 = [], []
+    for idx in cat_kernel:
+        (k1 if idx == id_covariate else k0).append(wm([(_lib.GP_CAT, idx)], idx))
+    for idx in sqexp_kernel:
+        k0.append(wm([(_lib.GP_RBF, idx)], idx))
+    for idx in bin_kernel:
+        k0.append(wm([(_lib.GP_BIN, idx)], idx))
+    for d in cat_int_kernel:
+        f = wm([(_lib.GP_CAT, d["cat_covariate"])], d["cat_covariate"]) + wm([(_lib.GP_RBF, d["cont_covariate"])], d["cont_covariate"])
+        (k1 if d["cat_covariate"] == id_covariate else k0).append(f)
+    for d in bin_int_kernel:
+        k0.append(wm([(_lib.GP_BIN, d["bin_covariate"])], d["bin_covariate"]) + wm([(_lib.GP_RBF, d["cont_covariate"])], d["cont_covariate"]))
+    return k0, k1
+
+
+def _pack_spec(terms, slot0):
+    """list of factor lists -> (HlvaeGpKernel, names of the hyper-parameter rows it introduced, next free row)"""
+    k = _lib.HlvaeGpKernel()
+    assert len(terms) <= _lib.GP_MAX_TERMS
+    k.n_terms = len(terms)
+    names, slot = [], slot0
+    for t, fac in enumerate(terms):
+        assert len(fac) <= _lib.GP_MAX_FACTORS
+        k.scale_slot[t] = slot
+        names.append((t, None))
+        slot += 1
+        k.n_factors[t] = len(fac)
+        for f, (kind, dim) in enumerate(fac):
+            k.kind[t][f], k.dim[t][f], k.ls_slot[t][f] = kind, dim, -1
+            if kind == _lib.GP_RBF:
+                k.ls_slot[t][f] = slot
+                names.append((t, f))
+                slot += 1
+    return k, names, slot
+
+
+class GPPriorHIP:
+    """GP prior with hand-written HIP kernels and analytic gradients (see module docstring).  Same state and update
+    rules as ``GPPrior``; hyper-parameters are one fp64 tensor ``prm`` [rows, L] of RAW values (row order: terms of the
+    id-free kernel then of the id kernel, each: scale, then its RBF lengthscales)."""
+
+    def __init__(self, latent_dim, train_x, M, id_covariate, N_total, cat_kernel=(2,), bin_kernel=(), sqexp_kernel=(0,),
+                 cat_int_kernel=({"cont_covariate": 0, "cat_covariate": 2}, {"cont_covariate": 0, "cat_covariate": 3},
+                                 {"cont_covariate": 1, "cat_covariate": 4}),
+                 bin_int_kernel=(), covariate_missing_val=(), natural_gradient_lr=0.01, lr=1e-3, eps=1e-6, seed=0):
+        import math
+        dev = train_x.device
+        if dev.type != "cuda":
+            raise RuntimeError("GPPriorHIP runs on the GPU only (no CPU fallback); GPPrior is the device-independent statement")
+        self.L, self.M, self.id_covariate, self.N_total, self.eps, self.ng_lr = latent_dim, M, id_covariate, N_total, eps, natural_gradient_lr
+        self.Q = train_x.shape[1]
+        t0, t1 = _spec_from_config(list(cat_kernel), list(bin_kernel), list(sqexp_kernel), list(cat_int_kernel),
+                                   list(bin_int_kernel), list(covariate_missing_val), id_covariate)
+        self.k0, names0, n = _pack_spec(t0, 0)
+        self.k1, names1, n = _pack_spec(t1, n)
+        self.n_slots = n
+        self.slot_names = [("k0",) + x for x in names0] + [("k1",) + x for x in names1]
+        raw = lambda v: math.log(v - math.exp(-16.0))
+        init = [raw(math.log(2)) if f is None else raw(2.5) for (_, _, f) in self.slot_names]        # GP_model.py:44,72
+        self.prm = torch.tensor(init, dtype=torch.float64, device=dev)[:, None].repeat(1, latent_dim).contiguous().requires_grad_(True)
+        g = torch.Generator().manual_seed(seed)
+        Ntr = train_x.shape[0]
+        zt = torch.stack([train_x[torch.randperm(Ntr, generator=g)[:M].to(dev)] for _ in range(latent_dim)])
+        self.zt_list = zt.clone().to(torch.float64).contiguous().requires_grad_(True)
+        self.m = torch.randn(latent_dim, M, 1, generator=g, dtype=torch.float64).to(dev)
+        Hh = (torch.randn(latent_dim, M, M, generator=g, dtype=torch.float64) / 10).to(dev)
+        self.H = (Hh @ Hh.transpose(-1, -2) + 1e-6 * torch.eye(M, dtype=torch.float64, device=dev)).contiguous()
+        self.noise = torch.ones(latent_dim, dtype=torch.float64, device=dev)                        # HLVAE_main.py:211-213
+        self.opt = torch.optim.Adam([self.prm, self.zt_list], lr=lr)
+        self.fail = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.last_kld = None
+        self._groups = {}
+        self._grad_m = self._grad_H = None
+
+    @classmethod
+    def from_reference_config(cls, model, src, P_total, dev, M=120):
+        train_x = torch.tensor(src.labels, dtype=torch.float64, device=dev)
+        return cls(model.z_dim, train_x, min(M, train_x.shape[0]), src.id_covariate, N_total=train_x.shape[0])
+
+    # ---- thin wrappers over the C ABI ---------------------------------------------------------------------------
+    def _stream(self):
+        return _C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def kernel_matrix(self, k, x1, x2, jitter=0.0):
+        L, Q = self.L, self.Q
+        pl1, pl2 = int(x1.dim() == 3), int(x2.dim() == 3)
+        n1, n2 = x1.shape[-2], x2.shape[-2]
+        out = torch.empty(L, n1, n2, dtype=torch.float64, device=x1.device)
+        _lib.check(_lib.load().hlvae_gp_kernel_matrix(_C.byref(k), _lib.ptr(self.prm), self.n_slots, L, Q, _lib.ptr(x1), n1, pl1,
+                                                      _lib.ptr(x2), n2, pl2, _C.c_double(jitter), _lib.ptr(out), self._stream()),
+                   "gp_kernel_matrix")
+        return out
+
+    def chol_inv(self, A):
+        n, N = A.shape[0], A.shape[-1]
+        inv = torch.empty_like(A)
+        logdet = torch.empty(n, dtype=torch.float64, device=A.device)
+        _lib.check(_lib.load().hlvae_gp_chol_inv(_lib.ptr(A), n, N, _lib.ptr(inv), _lib.ptr(logdet), _lib.ptr(self.fail),
+                                                 self._stream()), "gp_chol_inv")
+        return inv, logdet
+
+    def _group(self, train_x):
+        key = (train_x.data_ptr(), train_x.shape[0])
+        if key not in self._groups:
+            idx, valid = subject_groups(train_x[:, self.id_covariate])
+            idx32 = torch.where(valid > 0, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
+            self._groups[key] = idx32
+        return self._groups[key]
+
+    # ---- the KL bound, its gradients, the natural-gradient terms ------------------------------------------------
+    def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None):
+        """mu, log_v: fp32 [B, L] (the workspace tensors of the VAE); returns fp32 [B, L] gradients.  Hyper-parameter
+        and inducing-point gradients are left in ``prm.grad`` / ``zt_list.grad``."""
+        lib, st = _lib.load(), self._stream()
+        L, M, Q, B = self.L, self.M, self.Q, mu.shape[0]
+        dev = mu.device
+        c = float(P_total) / float(P_batch)
+        x = train_x.contiguous()
+        idx = self._group(x)
+        S, T = idx.shape
+        k0, k1, prm, z = self.k0, self.k1, self.prm.detach(), self.zt_list.detach()
+        f64 = dict(dtype=torch.float64, device=dev)
+        # kernel matrices and the two M x M factorizations (both in ONE batched launch)
+        Kzz = self.kernel_matrix(k0, z, z, jitter=self.eps)
+        Kxz = self.kernel_matrix(k0, x, z)
+        inv, logdet = self.chol_inv(torch.cat([Kzz, self.H]))
+        iK, iH, ldK, ldH = inv[:L], inv[L:], logdet[:L], logdet[L:]
+        iKm = iK @ self.m                                                    # [L,M,1]
+        resid = (Kxz @ iKm).squeeze(2) - mu.to(torch.float64).t()            # [L,B]
+        lv32 = log_v.to(torch.float32).contiguous()
+        iB = torch.empty(S, L, T, T, **f64); K0s = torch.empty(S, L, T, T, **f64)
+        V = torch.zeros(L, B, M, **f64); v = torch.zeros(L, B, **f64); part = torch.empty(S, L, 4, **f64)
+        g_mu = torch.empty(B, L, dtype=torch.float32, device=dev); g_lv = torch.empty(B, L, dtype=torch.float32, device=dev)
+        _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(prm), self.n_slots, L, Q, _lib.ptr(x),
+                                            _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(Kxz), B, M, _lib.ptr(resid.contiguous()),
+                                            _lib.ptr(lv32), _C.c_double(c), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
+                                            _lib.ptr(part), _lib.ptr(g_mu), _lib.ptr(g_lv), st), "gp_subject_fwd")
+        KxzT = Kxz.transpose(1, 2)
+        W = KxzT @ V                                                         # sum_s Ks^T iB Ks   [L,M,M]
+        HiK = self.H @ iK
+        Qm = iK @ HiK                                                        # iK H iK
+        ps = part.sum(dim=(0, 1))
+        A, Bt, Cc, D1 = ps[0], ps[1], ps[2], ps[3]
+        D = D1 - torch.sum(W * iK)
+        E = torch.sum(Qm * W)
+        Fq = torch.sum(log_v.to(torch.float64))
+        kl_u = 0.5 * (torch.sum(iK * self.H) + torch.sum(self.m * iKm) - L * M + ldK.sum() - ldH.sum())
+        self.last_kld = (c * 0.5 * (A + Bt + Cc + D + E - Fq) + kl_u - L * self.N_total / 2.0).reshape(1)
+        # natural-gradient terms (elbo_functions.py:262-266, 279-283)
+        P1 = torch.einsum("lbm,bl->lm", V, mu.to(torch.float64)).unsqueeze(-1)
+        Bm = iK @ W @ iK + iK
+        self._grad_m = -(iK @ P1) + Bm @ self.m
+        self._grad_H = 0.5 * (Bm - iH)
+        # analytic gradients w.r.t. kernel matrices, chained into hyper-parameters / inducing points by the HIP kernels
+        gprm = torch.zeros_like(prm)
+        gz = torch.zeros_like(z)
+        Y = V @ (iK - Qm)                                                    # [L,B,M]
+        G_Kxz = c * (v.unsqueeze(2) * iKm.transpose(1, 2) - Y)               # c [ v (iK m)^T + V (Q - iK) ]
+        u = (KxzT @ v.unsqueeze(2))                                          # [L,M,1]
+        HiKW = HiK @ W
+        R = c * 0.5 * (2.0 * u @ self.m.transpose(1, 2) - W + HiKW + HiKW.transpose(1, 2)) + 0.5 * (self.H + self.m @ self.m.transpose(1, 2))
+        G_Kzz = -(iK @ R @ iK) + 0.5 * iK
+        _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(prm), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
+                                            S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y.contiguous()),
+                                            _lib.ptr(lv32), _C.c_double(c), _lib.ptr(gprm), st), "gp_subject_bwd")
+        _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(prm), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
+                                           _lib.ptr(G_Kxz.contiguous()), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kxz)")
+        _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(prm), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
+                                           _lib.ptr(G_Kzz.contiguous()), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
+        self.prm.grad, self.zt_list.grad = gprm, gz
+        return g_mu, g_lv
+
+    def optimizer_step(self):
+        self.opt.step()
+        # natural-gradient update of (m, H), training.py:130-137, with the LDS Cholesky/inverse kernel
+        iH, _ = self.chol_inv(self.H)
+        iH_new = (iH + self.ng_lr * (self._grad_H + self._grad_H.transpose(-1, -2))).contiguous()
+        H_new, _ = self.chol_inv(iH_new)
+        self.m = H_new @ (iH @ self.m - self.ng_lr * (self._grad_m - 2.0 * (self._grad_H @ self.m)))
+        self.H = H_new

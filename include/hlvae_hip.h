@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 7
+#define HLVAE_ABI_VERSION 8
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -183,6 +183,51 @@ int hlvae_zero_grad(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s);
  * The small-parameter gradient region [0, atomic_region) is zeroed after it is consumed. */
 int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count,
                     float lr, float beta1, float beta2, float eps, float grad_scale, hlvae_stream s);
+
+/* ---- GP-prior KL (row K): reference elbo_functions.py:196-285 with the kernels of GP_model.py:27-116, fp64 ----------
+ * An additive kernel = sum over terms of  scale_t[l] * prod_f factor_f(x[dim], x'[dim]);  factors: categorical equality,
+ * binary AND, RBF with its own lengthscale per latent dimension.  Hyper-parameters live in prm [n_slots][L] as RAW values
+ * (positive value = exp(-16 + softplus(raw + 16)), GP_model.py:57,85). */
+#define HLVAE_GP_MAX_TERMS 8
+#define HLVAE_GP_MAX_FACTORS 4
+enum { HLVAE_GP_CAT = 0, HLVAE_GP_BIN = 1, HLVAE_GP_RBF = 2 };
+typedef struct {
+    int32_t n_terms;
+    int32_t scale_slot[HLVAE_GP_MAX_TERMS];                        /* row of prm with the raw scale              */
+    int32_t n_factors[HLVAE_GP_MAX_TERMS];
+    int32_t kind[HLVAE_GP_MAX_TERMS][HLVAE_GP_MAX_FACTORS];
+    int32_t dim[HLVAE_GP_MAX_TERMS][HLVAE_GP_MAX_FACTORS];         /* covariate column                            */
+    int32_t ls_slot[HLVAE_GP_MAX_TERMS][HLVAE_GP_MAX_FACTORS];     /* row of prm with the raw lengthscale, or -1  */
+} hlvae_gp_kernel;
+
+/* out [L][n1][n2] = K(x1_i, x2_j) (+ jitter on i == j).  x1 / x2: [n][Q] shared by all latents, or [L][n][Q] when the
+ * per_latent flag is set (inducing points zt_list).  Replaces covar_module(x1, x2).evaluate() (elbo_functions.py:222-223). */
+int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* prm, int n_slots, int L, int Q, const double* x1, int n1,
+                           int per_latent1, const double* x2, int n2, int per_latent2, double jitter, double* out,
+                           hlvae_stream s);
+/* batched SPD inverse + log-determinant via Cholesky, N <= 128, one workgroup per matrix, matrix resident in LDS
+ * (replaces torch.cholesky + cholesky_solve(eye), elbo_functions.py:225-228, training.py:131-135).
+ * *fail (device int, may be NULL) is set to 1 if a pivot is not positive. */
+int hlvae_gp_chol_inv(const double* A, int n, int N, double* inv, double* logdet, int* fail, hlvae_stream s);
+/* the per-subject loop of elbo_functions.py:243-266 as one workgroup per (subject, latent).  idx [S][T]: batch row of the
+ * t-th observation of subject s, -1 = padding (T <= 32).  resid [L][B] = K0xz iK0zz m - mu^T.  Outputs: iB, K0s [S][L][T][T];
+ * V [L][B][M] = iB_s K0xz_s (row-indexed by batch row); v [L][B] = iB_s resid_s; part [S][L][4] = {A, B, C, sum(iB*K0)}
+ * contributions; g_mu, g_lv [B][L] fp32 = d(KL bound)/d(mu, log_var) with c = P / P_batch. */
+int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* prm, int n_slots, int L, int Q,
+                         const double* x, const double* noise, const int32_t* idx, int S, int T, const double* Kxz, int B,
+                         int M, const double* resid, const float* lv, double c, double* iB, double* K0s, double* V,
+                         double* v, double* part, float* g_mu, float* g_lv, hlvae_stream s);
+/* gradients of the bound w.r.t. B_st and K0_st chained into the hyper-parameters (accumulates into gprm [n_slots][L]).
+ * Y [L][B][M] = V (iK0zz - iK0zz H iK0zz). */
+int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* prm, int n_slots, int L, int Q,
+                         const double* x, const int32_t* idx, int S, int T, int B, int M, const double* iB, const double* K0s,
+                         const double* V, const double* v, const double* Y, const float* lv, double c, double* gprm,
+                         hlvae_stream s);
+/* chain rule from G [L][n1][n2] = dL/dK(x1_i, x2_j) into gprm [n_slots][L] and gx2 [L][n2][Q] (points of the second
+ * argument, always per latent).  both_args != 0: x1 == x2 (K0zz), the points receive both argument positions. */
+int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* prm, int n_slots, int L, int Q, const double* x1, int n1,
+                        int per_latent1, const double* x2, int n2, int both_args, const double* G, double* gprm, double* gx2,
+                        hlvae_stream s);
 
 /* Per-kernel HIP-event timing (bench.py's roofline leg): while enabled every kernel launch of this library is
  * bracketed by hipEventRecord on its own stream.  hlvae_prof_report synchronises the device and writes one line

@@ -304,12 +304,13 @@ def test_inkernel_noise_statistics():
     assert abs(float((e1 * e2).mean())) < 0.03
 
 
-def test_gp_prior_training_step_against_oracle(golden_dir):
+@pytest.mark.parametrize("impl", ["torch", "hip"])
+def test_gp_prior_training_step_against_oracle(golden_dir, impl):
     """row K on the device: one fused step with the GP-prior KL (batched fp64 torch-ROCm ops feeding g_mu / g_lv into the
     HIP backward) against the oracles: NLL, KL value, and the direction of the first Adam update."""
     import hlvae_oracle as orc
     import gp_oracle as gpo
-    from hlvae_amd.elbo_functions import GPPrior
+    from hlvae_amd.elbo_functions import GPPrior, GPPriorHIP
     from hlvae_amd.training import ELBOTrainer
     dev = _dev()
     src = synthetic.make_tabular(n_rows=48, T=6, seed=7, spec=MIX_SPEC)
@@ -317,7 +318,7 @@ def test_gp_prior_training_step_against_oracle(golden_dir):
     state = orc.init_state(dims, src.types_info, src.n_variables, seed=5, std=0.2)
     model = _model_from_state(src, dims, state)
     labels = torch.tensor(src.labels, device=dev)
-    gp = GPPrior(dims[2], labels, M=10, id_covariate=2, N_total=480, seed=3)
+    gp = (GPPriorHIP if impl == "hip" else GPPrior)(dims[2], labels, M=10, id_covariate=2, N_total=480, seed=3)
     m0, H0, z0 = gp.m.clone(), gp.H.clone(), gp.zt_list.detach().clone()
     tr = ELBOTrainer(model, P_total=80, kl="gp", gp=gp, max_batch=128)
     eps = torch.randn(48, dims[2], generator=torch.Generator().manual_seed(9))
@@ -464,3 +465,66 @@ def test_step_metrics_against_reference_fixture(golden_dir):
     assert np.allclose(eo[~disc], g["err_observed"][~disc], rtol=5e-2, atol=5e-3)
     assert np.allclose(em[~disc], g["err_missing"][~disc], rtol=5e-2, atol=5e-3)
     assert np.all(np.abs(eo[disc] - g["err_observed"][disc]) <= 1.0 / 8) and np.all(np.abs(em[disc] - g["err_missing"][disc]) <= 1.0 / 4)
+
+
+def _copy_hip_params_to_torch_gp(hip, ref):
+    """hyper-parameter rows of GPPriorHIP -> the GP_model kernel modules of GPPrior (same term order)"""
+    from hlvae_amd import GP_model
+    with torch.no_grad():
+        for row, (which, t, f) in enumerate(hip.slot_names):
+            sk = (ref.k0 if which == "k0" else ref.k1).kernels[t]
+            if f is None:
+                sk._log_scale.copy_(hip.prm[row])
+            else:
+                facs = list(sk.kernel.factors) if isinstance(sk.kernel, GP_model.ProductKernel) else [sk.kernel]
+                facs[f]._log_lengthscale.copy_(hip.prm[row])
+        ref.zt_list.copy_(hip.zt_list)
+        ref.m, ref.H = hip.m.clone(), hip.H.clone()
+
+
+@pytest.mark.parametrize("varying_T", [False, True])
+def test_gp_prior_hip_against_autograd_statement(varying_T):
+    """row K, hand-written path: kernel matrices, LDS Cholesky/inverse, the per-(subject, latent) block kernel and the
+    analytic chain rule into hyper-parameters / inducing points (csrc/gp.hip) against the batched torch + autograd
+    statement of the same bound (which is pinned to the reference fixture in tests/test_gp_prior.py).  fp64: 1e-9."""
+    from hlvae_amd.elbo_functions import GPPrior, GPPriorHIP
+    dev = _dev()
+    torch.manual_seed(0)
+    L, Q, M = 6, 6, 20
+    Ts = [5, 7, 3, 6, 7, 4, 7, 2] if varying_T else [6] * 8
+    rows = []
+    for s_, T in enumerate(Ts):
+        for t in range(T):
+            rows.append([float(t), float(t - 2) if s_ % 2 else 0.0, float(s_ + 3), float(s_ % 2), float(s_ % 2), float((s_ // 2) % 2)])
+    x = torch.tensor(rows, dtype=torch.float64)
+    x = x[torch.randperm(x.shape[0])].to(dev)          # rows of a subject are not contiguous
+    B = x.shape[0]
+    hip = GPPriorHIP(L, x, M, 2, N_total=777, seed=4)
+    ref = GPPrior(L, x, M, 2, N_total=777, seed=4)
+    with torch.no_grad():
+        hip.prm.add_(0.3 * torch.randn_like(hip.prm))
+        hip.zt_list.add_(0.05 * torch.randn_like(hip.zt_list))
+    _copy_hip_params_to_torch_gp(hip, ref)
+    mu = torch.randn(B, L, device=dev)
+    lv = (0.5 * torch.randn(B, L, device=dev) - 1.0)
+    g_mu_r, g_lv_r = ref.kl_and_grads(mu, lv, x, 40, len(Ts))
+    g_mu_h, g_lv_h = hip.kl_and_grads(mu, lv, x, 40, len(Ts))
+    torch.cuda.synchronize()
+    assert int(hip.fail.item()) == 0
+    assert rel_err(hip.last_kld, ref.last_kld) < 1e-10
+    assert rel_err(g_mu_h, g_mu_r) < 1e-6 and rel_err(g_lv_h, g_lv_r) < 1e-6          # fp32 outputs
+    assert rel_err(hip._grad_m, ref._grad_m) < 1e-9 and rel_err(hip._grad_H, ref._grad_H) < 1e-9
+    assert rel_err(hip.zt_list.grad, ref.zt_list.grad) < 1e-8
+    from hlvae_amd import GP_model
+    for row, (which, t, f) in enumerate(hip.slot_names):
+        sk = (ref.k0 if which == "k0" else ref.k1).kernels[t]
+        if f is None:
+            gr = sk._log_scale.grad
+        else:
+            facs = list(sk.kernel.factors) if isinstance(sk.kernel, GP_model.ProductKernel) else [sk.kernel]
+            gr = facs[f]._log_lengthscale.grad
+        assert rel_err(hip.prm.grad[row], gr) < 1e-8, (row, which, t, f)
+    hip.optimizer_step()
+    ref.optimizer_step()
+    assert rel_err(hip.m, ref.m) < 1e-8 and rel_err(hip.H, ref.H) < 1e-8
+    assert rel_err(hip.zt_list, ref.zt_list) < 1e-9
