@@ -2,260 +2,357 @@
 // GP_model.py:27-116), fp64 throughout: the structured / fused pieces are hand-written here, the plain batched
 // [L,M,M] x [L,M,M] and [L,B,M] x [L,M,M] products in between stay library GEMMs on the host side.
 //
+//   k_gp_transform       hyper-parameter planes from the raw values, once per step: pos = exp(-16 + softplus(raw + 16))
+//                        (GP_model.py:57,85), dpos = sigmoid(raw + 16) (d pos / d raw = pos * dpos), il2 = 1 / pos^2
 //   k_gp_kernel_matrix   additive product kernels for all latent dimensions: K[l][i][j] (+ jitter on the diagonal)
-//   k_gp_chol_inv        batched Cholesky + inverse + log-determinant of SPD matrices up to 128 x 128, in LDS
+//   k_gp_spd_inv         batched SPD inverse + log-determinant up to 128 x 128: in-place Gauss-Jordan with the whole
+//                        matrix in REGISTERS (8 x 8 elements per lane of a 16 x 16 thread grid); only the pivot row and
+//                        column travel through (double-buffered) LDS, one barrier per pivot
 //   k_gp_subject_fwd     one workgroup per (subject, latent): K0_st, B_st = K1_st + sigma^2 I (padded subjects get an
-//                        identity block), Cholesky, inverse, the partial sums A, B, C, D1 of the bound, iB*Ks, iB*a,
-//                        and the gradients of the bound w.r.t. the encoder outputs (mu, log_var) as fp32 [B, L]
+//                        identity block), its inverse by the same register Gauss-Jordan, the partial sums A, B, C, D1 of
+//                        the bound, iB*Ks, iB*a, and the gradients of the bound w.r.t. the encoder outputs (mu, log_var)
 //   k_gp_subject_bwd     gradients of the bound w.r.t. B_st and K0_st, chained into the kernel hyper-parameters
 //   k_gp_param_grad      chain rule from a gradient matrix dL/dK[l][i][j] into scales, lengthscales and the second
 //                        argument's (inducing) points
+//   k_gp_bound           every scalar reduction of the bound (elbo_functions.py:268-285) in one launch
+//   k_gp_adam            torch.optim.Adam on the flat fp64 arena [hyper-parameters | inducing points]
 #include "common.h"
 
-#define GP_MIN_LOG (-16.0)
+#define GP_TMAX 32
+#define GP_MMAX 128
+#define GP_MAX_RBF 2                                        // RBF factors per term (validated by the launchers)
 
-__device__ __forceinline__ double gp_softplus(double t) { return t > 30.0 ? t : log1p(exp(t)); }
-__device__ __forceinline__ double gp_sigmoid(double t) { return 1.0 / (1.0 + exp(-t)); }
-__device__ __forceinline__ double gp_positive(double raw) { return exp(GP_MIN_LOG + gp_softplus(raw - GP_MIN_LOG)); }   // GP_model.py:57,85
+// ------------------------------------------------------------------------------------------------------------
+// covariance terms.  Hyper-parameters of one latent dimension are hoisted into registers once per thread.
+// ------------------------------------------------------------------------------------------------------------
+struct GpHyp {
+    double sc[HLVAE_GP_MAX_TERMS];
+    double il2[HLVAE_GP_MAX_TERMS][GP_MAX_RBF];
+};
+struct GpAcc {                                              // per-lane gradient accumulators of one additive kernel
+    double ts[HLVAE_GP_MAX_TERMS];                          // d / d scale      (x scale)
+    double tl[HLVAE_GP_MAX_TERMS][GP_MAX_RBF];              // d / d lengthscale (x lengthscale)
+};
 
-// value of one term (without / with its scale) between covariate rows xa and xb, for latent dimension l
-__device__ __forceinline__ double gp_term_value(const hlvae_gp_kernel& k, int t, const double* __restrict__ prm, int L, int l,
-                                                const double* xa, const double* xb, bool with_scale) {
-    double v = 1.0;
-    for (int f = 0; f < k.n_factors[t]; ++f) {
-        const int dim = k.dim[t][f];
-        const double a = xa[dim], b = xb[dim];
-        if (k.kind[t][f] == HLVAE_GP_CAT) v *= (a == b) ? 1.0 : 0.0;                  // GP_model.py:40-41
-        else if (k.kind[t][f] == HLVAE_GP_BIN) v *= (a + b == 2.0) ? 1.0 : 0.0;       // :32-33
-        else {
-            const double ls = gp_positive(prm[(size_t)k.ls_slot[t][f] * L + l]);
-            const double d = a - b;
-            v *= exp(-d * d / (2.0 * ls * ls));                                       // :64-69
+__device__ __forceinline__ void gp_hoist(const hlvae_gp_kernel& k, const double* __restrict__ hyp, int n_slots, int L, int l,
+                                         GpHyp& h) {
+    const double* pos = hyp;
+    const double* il2 = hyp + (size_t)2 * n_slots * L;
+#pragma unroll
+    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+        h.sc[t] = 0.0;
+        h.il2[t][0] = h.il2[t][1] = 0.0;
+        if (t < k.n_terms) {
+            h.sc[t] = pos[(size_t)k.scale_slot[t] * L + l];
+            int r = 0;
+            for (int f = 0; f < k.n_factors[t]; ++f)
+                if (k.kind[t][f] == HLVAE_GP_RBF) {
+                    const double v = il2[(size_t)k.ls_slot[t][f] * L + l];
+                    if (r == 0) h.il2[t][0] = v; else h.il2[t][1] = v;
+                    ++r;
+                }
         }
     }
-    return with_scale ? v * gp_positive(prm[(size_t)k.scale_slot[t] * L + l]) : v;
 }
-__device__ __forceinline__ double gp_kernel_value(const hlvae_gp_kernel& k, const double* __restrict__ prm, int L, int l,
-                                                  const double* xa, const double* xb) {
-    double s = 0.0;
-    for (int t = 0; t < k.n_terms; ++t) s += gp_term_value(k, t, prm, L, l, xa, xb, true);
+__device__ __forceinline__ void gp_acc_zero(GpAcc& a) {
+#pragma unroll
+    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) a.ts[t] = a.tl[t][0] = a.tl[t][1] = 0.0;
+}
+
+// term t (compile-time index after unrolling) between covariate rows xa and xb: value with its scale, 0 when an
+// indicator factor is off; d0/d1 = differences of the (up to two) RBF factors, e0/e1 = d^2 / ls^2
+__device__ __forceinline__ double gp_term(const hlvae_gp_kernel& k, int t, double sc, double il20, double il21,
+                                          const double* xa, const double* xb, double& d0, double& d1, double& e0, double& e1) {
+    d0 = d1 = 0.0;
+    int r = 0;
+    bool on = true;
+    for (int f = 0; f < k.n_factors[t]; ++f) {
+        const int dim = k.dim[t][f], kind = k.kind[t][f];
+        const double a = xa[dim], b = xb[dim];
+        if (kind == HLVAE_GP_CAT) on = on && (a == b);                    // GP_model.py:40-41
+        else if (kind == HLVAE_GP_BIN) on = on && (a + b == 2.0);         // :32-33
+        else {
+            if (r == 0) d0 = a - b; else d1 = a - b;
+            ++r;
+        }
+    }
+    e0 = d0 * d0 * il20;
+    e1 = d1 * d1 * il21;
+    if (!on) return 0.0;
+    return r == 0 ? sc : sc * exp(-0.5 * (e0 + e1));                      // :64-69 (product of RBFs = exp of the sum)
+}
+__device__ __forceinline__ double gp_value(const hlvae_gp_kernel& k, const GpHyp& h, const double* xa, const double* xb) {
+    double s = 0.0, d0, d1, e0, e1;
+#pragma unroll
+    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+        if (t >= k.n_terms) break;
+        s += gp_term(k, t, h.sc[t], h.il2[t][0], h.il2[t][1], xa, xb, d0, d1, e0, e1);
+    }
     return s;
 }
+// accumulate g * d k / d (hyper-parameters) of one pair
+__device__ __forceinline__ void gp_pair_grad(const hlvae_gp_kernel& k, const GpHyp& h, const double* xa, const double* xb,
+                                             double g, GpAcc& a) {
+    double d0, d1, e0, e1;
+#pragma unroll
+    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+        if (t >= k.n_terms) break;
+        const double tv = gp_term(k, t, h.sc[t], h.il2[t][0], h.il2[t][1], xa, xb, d0, d1, e0, e1);
+        const double gt = g * tv;
+        a.ts[t] += gt;
+        a.tl[t][0] += gt * e0;
+        a.tl[t][1] += gt * e1;
+    }
+}
+// wave reduction of the accumulators, lane 0 adds (x d pos / d raw / pos) into the block's LDS rows gacc[slot]
+__device__ __forceinline__ void gp_flush(const hlvae_gp_kernel& k, const GpAcc& a, const double* __restrict__ dpos_l, int L,
+                                         double* gacc, int lane) {
+#pragma unroll
+    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+        if (t >= k.n_terms) break;
+        const double s = wave_sum_d(a.ts[t]);
+        if (lane == 0 && s != 0.0) atomicAdd(&gacc[k.scale_slot[t]], s * dpos_l[(size_t)k.scale_slot[t] * L]);
+        int r = 0;
+        for (int f = 0; f < k.n_factors[t]; ++f)
+            if (k.kind[t][f] == HLVAE_GP_RBF) {
+                const double v = wave_sum_d(r == 0 ? a.tl[t][0] : a.tl[t][1]);
+                if (lane == 0 && v != 0.0) atomicAdd(&gacc[k.ls_slot[t][f]], v * dpos_l[(size_t)k.ls_slot[t][f] * L]);
+                ++r;
+            }
+    }
+}
 
-__global__ void k_gp_kernel_matrix(hlvae_gp_kernel k, const double* __restrict__ prm, int L, int Q,
-                                   const double* __restrict__ x1, int n1, int per_latent1, const double* __restrict__ x2,
-                                   int n2, int per_latent2, double jitter, double* __restrict__ out) {
-    const long total = (long)L * n1 * n2;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(e % n2), i = (int)((e / n2) % n1), l = (int)(e / ((long)n1 * n2));
+__global__ void k_gp_transform(const double* __restrict__ raw, int n, double* __restrict__ hyp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = raw[i] + 16.0;
+    const double sp = x > 20.0 ? x : log1p(exp(x));          // torch softplus (beta 1, threshold 20)
+    const double p = exp(sp - 16.0);
+    hyp[i] = p;
+    hyp[(size_t)n + i] = 1.0 / (1.0 + exp(-x));
+    hyp[(size_t)2 * n + i] = 1.0 / (p * p);
+}
+
+__global__ __launch_bounds__(256) void k_gp_kernel_matrix(hlvae_gp_kernel k, const double* __restrict__ hyp, int n_slots, int L,
+                                                          int Q, const double* __restrict__ x1, int n1, int per_latent1,
+                                                          const double* __restrict__ x2, int n2, int per_latent2,
+                                                          double jitter, double* __restrict__ out) {
+    // grid (chunks of n1 * n2, L)
+    const int l = blockIdx.y;
+    GpHyp h;
+    gp_hoist(k, hyp, n_slots, L, l, h);
+    const int total = n1 * n2;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int i = e / n2, j = e - i * n2;
         const double* xa = x1 + ((size_t)(per_latent1 ? l : 0) * n1 + i) * Q;
         const double* xb = x2 + ((size_t)(per_latent2 ? l : 0) * n2 + j) * Q;
-        double v = gp_kernel_value(k, prm, L, l, xa, xb);
+        double v = gp_value(k, h, xa, xb);
         if (i == j) v += jitter;
-        out[e] = v;
+        out[(size_t)l * total + e] = v;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// batched Cholesky / inverse / logdet, one workgroup per matrix, matrix resident in LDS (row stride N + 1)
+// SPD inverse + logdet: Gauss-Jordan without pivoting, matrix in registers.
+// lane (ti, tj) of the 16 x 16 grid owns elements (ti + 16 ii, tj + 16 jj), ii, jj < NB; the matrix is padded with an
+// identity block, which the elimination never touches.  One call handles 16 pivots with a compile-time register-block
+// index KB (no dynamic register indexing); pivot row / column are published through double-buffered LDS vectors, so
+// one barrier per pivot is enough.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gp_chol_inv(const double* __restrict__ A, int N, double* __restrict__ inv,
-                                                     double* __restrict__ logdet, int* __restrict__ fail) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* a = reinterpret_cast<double*>(smem);          // [N][N+1]: lower = L, strict upper (transposed) = L^-1
-    double* dinv = a + (size_t)N * (N + 1);               // [N] diagonal of L^-1
-    const int ld = N + 1, tid = threadIdx.x;
+__device__ __forceinline__ double gp_rcp(double p) {
+    double r = __builtin_amdgcn_rcp(p);                      // v_rcp_f64 + two Newton steps (full fp64 precision)
+    r = fma(fma(-p, r, 1.0), r, r);
+    r = fma(fma(-p, r, 1.0), r, r);
+    return r;
+}
+template <int NB, int KB>
+__device__ __forceinline__ void gj_pivots(double (&a)[NB][NB], double* row, double* col, double* pv, int N, int ti, int tj) {
+    constexpr int W = 16 * NB;
+    for (int kr = 0; kr < 16; ++kr) {
+        const int k = KB * 16 + kr;
+        if (k >= N) return;
+        double* rw = row + (k & 1) * W;
+        double* cl = col + (k & 1) * W;
+        const bool ik = ti == kr, jk = tj == kr;
+        if (ik) {
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) rw[tj + 16 * jj] = a[KB][jj];
+        }
+        if (jk) {
+#pragma unroll
+            for (int ii = 0; ii < NB; ++ii) cl[ti + 16 * ii] = a[ii][KB];
+        }
+        __syncthreads();
+        const double piv = rw[k];
+        const double pk = gp_rcp(piv);
+        if (ik && jk) pv[k] = piv;
+        double cr[NB], rc[NB], cz[NB], rz[NB];
+#pragma unroll
+        for (int ii = 0; ii < NB; ++ii) cz[ii] = cr[ii] = cl[ti + 16 * ii];
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) rz[jj] = rc[jj] = rw[tj + 16 * jj] * pk;
+        if (ik) cz[KB] = 0.0;                              // the generic update leaves pivot row and column alone
+        if (jk) rz[KB] = 0.0;
+#pragma unroll
+        for (int ii = 0; ii < NB; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) a[ii][jj] = fma(-cz[ii], rz[jj], a[ii][jj]);
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) a[KB][jj] = ik ? rc[jj] : a[KB][jj];            // pivot row:    a[k][j] / p
+#pragma unroll
+        for (int ii = 0; ii < NB; ++ii) a[ii][KB] = jk ? -cr[ii] * pk : a[ii][KB];      // pivot column: -a[i][k] / p
+        if (ik && jk) a[KB][KB] = pk;                                                  // pivot:        1 / p
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gp_spd_inv(const double* __restrict__ A, int N, double* __restrict__ inv,
+                                                    double* __restrict__ logdet, int* __restrict__ fail) {
+    __shared__ double row[2 * GP_MMAX], col[2 * GP_MMAX];
+    __shared__ double pv[GP_MMAX];
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
     const double* src = A + (size_t)blockIdx.x * N * N;
-    for (int e = tid; e < N * N; e += 256) a[(e / N) * ld + e % N] = src[e];
-    __syncthreads();
-    // right-looking Cholesky on the lower triangle
-    for (int k = 0; k < N; ++k) {
-        if (tid == 0) {
-            const double d = a[k * ld + k];
-            if (!(d > 0.0) && fail != nullptr) atomicExch(fail, 1);
-            a[k * ld + k] = sqrt(d);
+    double a[8][8];
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            a[ii][jj] = (i < N && j < N) ? src[(size_t)i * N + j] : (i == j ? 1.0 : 0.0);
         }
-        __syncthreads();
-        const double dk = a[k * ld + k];
-        for (int i = k + 1 + tid; i < N; i += 256) a[i * ld + k] /= dk;
-        __syncthreads();
-        const int n = N - k - 1;
-        for (int e = tid; e < n * n; e += 256) {
-            const int i = k + 1 + e / n, j = k + 1 + e % n;
-            if (j <= i) a[i * ld + j] -= a[i * ld + k] * a[j * ld + k];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        double s = 0.0;
-        for (int k = 0; k < N; ++k) s += log(a[k * ld + k]);
-        logdet[blockIdx.x] = 2.0 * s;
-    }
-    // L^-1 by forward substitution, column j by thread j: x_i stored at a[j][i] (i > j), x_j in dinv[j]
-    for (int j = tid; j < N; j += 256) {
-        const double xj = 1.0 / a[j * ld + j];
-        dinv[j] = xj;
-        for (int i = j + 1; i < N; ++i) {
-            double s = a[i * ld + j] * xj;
-            for (int k = j + 1; k < i; ++k) s += a[i * ld + k] * a[j * ld + k];
-            a[j * ld + i] = -s / a[i * ld + i];
-        }
-    }
-    __syncthreads();
-    // A^-1 = L^-T L^-1:  inv[i][j] = sum_{k >= max(i,j)} Linv[k][i] Linv[k][j]
+    gj_pivots<8, 0>(a, row, col, pv, N, ti, tj);
+    gj_pivots<8, 1>(a, row, col, pv, N, ti, tj);
+    gj_pivots<8, 2>(a, row, col, pv, N, ti, tj);
+    gj_pivots<8, 3>(a, row, col, pv, N, ti, tj);
+    gj_pivots<8, 4>(a, row, col, pv, N, ti, tj);
+    gj_pivots<8, 5>(a, row, col, pv, N, ti, tj);
+    gj_pivots<8, 6>(a, row, col, pv, N, ti, tj);
+    gj_pivots<8, 7>(a, row, col, pv, N, ti, tj);
     double* dst = inv + (size_t)blockIdx.x * N * N;
-    for (int e = tid; e < N * N; e += 256) {
-        const int i = e / N, j = e % N;
-        if (j > i) continue;
-        double s = 0.0;
-        for (int k = i; k < N; ++k) {
-            const double li = (k == i) ? dinv[i] : a[i * ld + k];
-            const double lj = (k == j) ? dinv[j] : a[j * ld + k];
-            s += li * lj;
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            if (i < N && j < N) dst[(size_t)i * N + j] = a[ii][jj];
         }
-        dst[i * N + j] = s;
-        dst[j * N + i] = s;
+    __syncthreads();
+    if (tid < 64) {                                        // log-determinant = sum of log pivots
+        double ld = 0.0;
+        bool bad = false;
+        for (int k = tid; k < N; k += 64) {
+            const double p = pv[k];
+            bad |= !(p > 0.0);
+            ld += log(p);
+        }
+        ld = wave_sum_d(ld);
+        if (bad && fail != nullptr) atomicExch(fail, 1);
+        if (tid == 0) logdet[blockIdx.x] = ld;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// per (subject, latent) block.  T <= 32 rows per subject (padded), 256 threads.
-// LDS: xs [T][Q], B [T][T+1], iB [T][T+1], K0 [T][T+1], tmp [T][T+1]
+// per (subject, latent) block.  T <= 32 rows per subject (padded), M <= 128 inducing points, 256 threads as a
+// 16 x 16 grid: lane (ti, tj) owns the 2 x 2 elements (ti + 16 ii, tj + 16 jj) of the T x T blocks.
 // ------------------------------------------------------------------------------------------------------------
-#define GP_TMAX 32
-
-__device__ __forceinline__ void gp_chol_inv_small(double* b, double* ib, int T, int ld, int tid, double* logdet_out) {
-    // Cholesky of b (lower, in place) then ib = b^-1 (full, symmetric); T <= 32, block of 256 threads
-    for (int k = 0; k < T; ++k) {
-        if (tid == 0) b[k * ld + k] = sqrt(b[k * ld + k]);
-        __syncthreads();
-        const double dk = b[k * ld + k];
-        if (tid > k && tid < T) b[tid * ld + k] /= dk;
-        __syncthreads();
-        const int n = T - k - 1;
-        for (int e = tid; e < n * n; e += 256) {
-            const int i = k + 1 + e / n, j = k + 1 + e % n;
-            if (j <= i) b[i * ld + j] -= b[i * ld + k] * b[j * ld + k];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        double s = 0.0;
-        for (int k = 0; k < T; ++k) s += log(b[k * ld + k]);
-        *logdet_out = 2.0 * s;
-    }
-    // L^-1 column j by thread j into the strict upper triangle of b (transposed), diagonal kept in ib's diagonal for now
-    if (tid < T) {
-        const int j = tid;
-        const double xj = 1.0 / b[j * ld + j];
-        ib[j * ld + j] = xj;
-        for (int i = j + 1; i < T; ++i) {
-            double s = b[i * ld + j] * xj;
-            for (int k = j + 1; k < i; ++k) s += b[i * ld + k] * b[j * ld + k];
-            b[j * ld + i] = -s / b[i * ld + i];
-        }
-    }
-    __syncthreads();
-    double r[4];
-    int cnt = 0;
-    for (int e = tid; e < T * T; e += 256, ++cnt) {           // T*T <= 1024 -> at most 4 per thread
-        const int i = e / T, j = e % T;
-        const int hi = i > j ? i : j;
-        double s = 0.0;
-        for (int k = hi; k < T; ++k) {
-            const double li = (k == i) ? ib[i * ld + i] : b[i * ld + k];
-            const double lj = (k == j) ? ib[j * ld + j] : b[j * ld + k];
-            s += li * lj;
-        }
-        r[cnt] = s;
-    }
-    __syncthreads();
-    cnt = 0;
-    for (int e = tid; e < T * T; e += 256, ++cnt) ib[(e / T) * ld + e % T] = r[cnt];
-    __syncthreads();
-}
+#define GP_XS 9                                             // padded covariate row in LDS
+#define GP_TS (GP_TMAX + 1)
 
 __global__ __launch_bounds__(256) void k_gp_subject_fwd(
-    hlvae_gp_kernel k0, hlvae_gp_kernel k1, const double* __restrict__ prm, int L, int Q, const double* __restrict__ x,
-    const double* __restrict__ noise, const int32_t* __restrict__ idx, int T, const double* __restrict__ Kxz, int Bn, int M,
-    const double* __restrict__ resid, const float* __restrict__ lv, double c,
+    hlvae_gp_kernel k0, hlvae_gp_kernel k1, const double* __restrict__ hyp, int n_slots, int L, int Q,
+    const double* __restrict__ x, const double* __restrict__ noise, const int32_t* __restrict__ idx, int T,
+    const double* __restrict__ Kxz, int Bn, int M, const double* __restrict__ resid, const float* __restrict__ lv, double c,
     double* __restrict__ iB_out, double* __restrict__ K0_out, double* __restrict__ V_out, double* __restrict__ v_out,
     double* __restrict__ part, float* __restrict__ g_mu, float* __restrict__ g_lv) {
-    __shared__ double xs[GP_TMAX * 8];
-    __shared__ double bm[GP_TMAX * (GP_TMAX + 1)], ib[GP_TMAX * (GP_TMAX + 1)], k0m[GP_TMAX * (GP_TMAX + 1)];
+    __shared__ double xs[GP_TMAX * GP_XS];
+    __shared__ double ib[GP_TMAX * GP_TS];
+    __shared__ double ks[GP_TMAX * GP_MMAX];              // the subject's rows of K0xz
+    __shared__ double gjrow[2 * GP_TMAX], gjcol[2 * GP_TMAX], pv[GP_TMAX], rs[GP_TMAX];
     __shared__ int rows[GP_TMAX];
-    __shared__ double red[4][4];
-    __shared__ double ldet;
-    const int s = blockIdx.x, l = blockIdx.y, tid = threadIdx.x, ld = T + 1;
-    if (tid < T) rows[tid] = idx[(size_t)s * T + tid];
+    __shared__ double red[3][4];
+    const int s = blockIdx.x, l = blockIdx.y, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    if (tid < GP_TMAX) rows[tid] = tid < T ? idx[(size_t)s * T + tid] : -1;
     __syncthreads();
     for (int e = tid; e < T * Q; e += 256) {
         const int t = e / Q, r = rows[t];
-        xs[e] = r >= 0 ? x[(size_t)r * Q + e % Q] : 0.0;
+        xs[t * GP_XS + e % Q] = r >= 0 ? x[(size_t)r * Q + e % Q] : 0.0;
     }
+    for (int e = tid; e < T * M; e += 256) {              // stage Ks (coalesced along M), zero rows for padding
+        const int t = e / M, r = rows[t];
+        ks[e] = r >= 0 ? Kxz[((size_t)l * Bn + r) * M + e % M] : 0.0;
+    }
+    if (tid < T) rs[tid] = rows[tid] >= 0 ? resid[(size_t)l * Bn + rows[tid]] : 0.0;
+    GpHyp h0, h1;
+    gp_hoist(k0, hyp, n_slots, L, l, h0);
+    gp_hoist(k1, hyp, n_slots, L, l, h1);
     __syncthreads();
     const double nz = noise[l];
-    for (int e = tid; e < T * T; e += 256) {
-        const int i = e / T, j = e % T;
-        const bool ok = rows[i] >= 0 && rows[j] >= 0;
-        double kb = 0.0, k0v = 0.0;
-        if (ok) {
-            kb = gp_kernel_value(k1, prm, L, l, xs + i * Q, xs + j * Q) + (i == j ? nz : 0.0);     // elbo_functions.py:249-250
-            k0v = gp_kernel_value(k0, prm, L, l, xs + i * Q, xs + j * Q);                           // :248
-        } else if (i == j) {
-            kb = 1.0;                                             // padded row: identity block
+    double a[2][2], k0v[2][2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            double kb = i == j ? 1.0 : 0.0, kz = 0.0;             // padded rows: identity block
+            if (i < T && j < T && rows[i] >= 0 && rows[j] >= 0) {
+                kb = gp_value(k1, h1, xs + i * GP_XS, xs + j * GP_XS) + (i == j ? nz : 0.0);       // elbo_functions.py:249-250
+                kz = gp_value(k0, h0, xs + i * GP_XS, xs + j * GP_XS);                              // :248
+            }
+            a[ii][jj] = kb;
+            k0v[ii][jj] = kz;
         }
-        bm[i * ld + j] = kb;
-        k0m[i * ld + j] = k0v;
-    }
-    __syncthreads();
-    gp_chol_inv_small(bm, ib, T, ld, tid, &ldet);
+    gj_pivots<2, 0>(a, gjrow, gjcol, pv, T, ti, tj);
+    gj_pivots<2, 1>(a, gjrow, gjcol, pv, T, ti, tj);
     // mask the inverse to the valid block, write iB and K0_st
     double d1 = 0.0;
-    for (int e = tid; e < T * T; e += 256) {
-        const int i = e / T, j = e % T;
-        const bool ok = rows[i] >= 0 && rows[j] >= 0;
-        const double v = ok ? ib[i * ld + j] : 0.0;
-        ib[i * ld + j] = v;
-        const size_t o = (((size_t)s * L + l) * T + i) * T + j;
-        iB_out[o] = v;
-        K0_out[o] = k0m[i * ld + j];
-        d1 += v * k0m[i * ld + j];                                // sum(iB * K0_st)  (:259)
-    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            if (i < T && j < T) {
+                const bool ok = rows[i] >= 0 && rows[j] >= 0;
+                const double v = ok ? a[ii][jj] : 0.0;
+                ib[i * GP_TS + j] = v;
+                const size_t o = (((size_t)s * L + l) * T + i) * T + j;
+                iB_out[o] = v;
+                K0_out[o] = k0v[ii][jj];
+                d1 += v * k0v[ii][jj];                            // sum(iB * K0_st)  (:259)
+            }
+        }
     __syncthreads();
     // v = iB a, A = a.v, Bt = sum diag(iB) e^lv, g_mu, g_lv
-    double pa = 0.0, pb = 0.0;
-    if (tid < T && rows[tid] >= 0) {
-        const int i = tid, r = rows[i];
-        double acc = 0.0;
-        for (int j = 0; j < T; ++j)
-            if (rows[j] >= 0) acc += ib[i * ld + j] * resid[(size_t)l * Bn + rows[j]];
-        const double ai = resid[(size_t)l * Bn + r];
-        const double e = exp((double)lv[(size_t)r * L + l]);
-        v_out[(size_t)l * Bn + r] = acc;
-        pa = ai * acc;                                            // (:256)
-        pb = ib[i * ld + i] * e;                                  // (:257)
-        g_mu[(size_t)r * L + l] = (float)(-c * acc);             // d/dmu  of  c/2 a^T iB a  with a = pred - mu
-        g_lv[(size_t)r * L + l] = (float)(c * 0.5 * (ib[i * ld + i] * e - 1.0));
+    double pa = 0.0, pb = 0.0, pc = 0.0;
+    if (tid < T) {
+        if (rows[tid] >= 0) {
+            const int i = tid, r = rows[i];
+            double acc = 0.0;
+            for (int j = 0; j < T; ++j) acc += ib[i * GP_TS + j] * rs[j];
+            const double e = exp((double)lv[(size_t)r * L + l]);
+            v_out[(size_t)l * Bn + r] = acc;
+            pa = rs[i] * acc;                                     // (:256)
+            pb = ib[i * GP_TS + i] * e;                           // (:257)
+            g_mu[(size_t)r * L + l] = (float)(-c * acc);         // d/dmu  of  c/2 a^T iB a  with a = pred - mu
+            g_lv[(size_t)r * L + l] = (float)(c * 0.5 * (ib[i * GP_TS + i] * e - 1.0));
+        }
+        pc = log(pv[tid]);                                        // log det B_st = sum of log pivots (:258)
     }
     // V = iB Ks  [T][M] -> V_out[l][row][:]
     for (int e = tid; e < T * M; e += 256) {
-        const int i = e / M, mcol = e % M;
+        const int i = e / M, mcol = e - i * M;
         if (rows[i] < 0) continue;
         double acc = 0.0;
-        for (int j = 0; j < T; ++j)
-            if (rows[j] >= 0) acc += ib[i * ld + j] * Kxz[((size_t)l * Bn + rows[j]) * M + mcol];
+        for (int j = 0; j < T; ++j) acc += ib[i * GP_TS + j] * ks[j * M + mcol];
         V_out[((size_t)l * Bn + rows[i]) * M + mcol] = acc;
     }
-    // block reduction of the three partial sums
-    pa = wave_sum_d(pa); pb = wave_sum_d(pb); d1 = wave_sum_d(d1);
+    // block reduction of the partial sums
+    pa = wave_sum_d(pa); pb = wave_sum_d(pb); d1 = wave_sum_d(d1); pc = wave_sum_d(pc);
     if ((tid & 63) == 0) { red[0][tid >> 6] = pa; red[1][tid >> 6] = pb; red[2][tid >> 6] = d1; }
     __syncthreads();
     if (tid == 0) {
         double* p = part + ((size_t)s * L + l) * 4;
         p[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         p[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        p[2] = ldet;                                              // C contribution: log det B_st  (:258)
+        p[2] = pc;                                                // wave 0 holds all T <= 32 pivots
         p[3] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
     }
 }
@@ -263,155 +360,235 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
 // gradient of the bound w.r.t. B_st and K0_st of one (subject, latent), chained into the hyper-parameters:
 //   G_K0 = c/2 iB ;   G_B = c/2 [ iB - v v^T - iB diag(e^lv) iB - iB K0 iB + Y V^T ],  Y = V (iK - Q)
 __global__ __launch_bounds__(256) void k_gp_subject_bwd(
-    hlvae_gp_kernel k0, hlvae_gp_kernel k1, const double* __restrict__ prm, int L, int Q, const double* __restrict__ x,
-    const int32_t* __restrict__ idx, int T, int Bn, int M, const double* __restrict__ iB_in, const double* __restrict__ K0_in,
-    const double* __restrict__ V, const double* __restrict__ v, const double* __restrict__ Y, const float* __restrict__ lv,
-    double c, int n_slots, double* __restrict__ gprm) {
-    __shared__ double xs[GP_TMAX * 8];
-    __shared__ double ib[GP_TMAX * (GP_TMAX + 1)], k0m[GP_TMAX * (GP_TMAX + 1)], w[GP_TMAX * (GP_TMAX + 1)],
-        gb[GP_TMAX * (GP_TMAX + 1)];
+    hlvae_gp_kernel k0, hlvae_gp_kernel k1, const double* __restrict__ hyp, int n_slots, int L, int Q,
+    const double* __restrict__ x, const int32_t* __restrict__ idx, int T, int Bn, int M, const double* __restrict__ iB_in,
+    const double* __restrict__ K0_in, const double* __restrict__ V, const double* __restrict__ v, const double* __restrict__ Y,
+    const float* __restrict__ lv, double c, double* __restrict__ gprm) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int MS = M + 1;                                         // padded: lanes walk different rows at the same m
+    double* vs = reinterpret_cast<double*>(dsm);                  // V_s [T][MS]
+    double* ys = vs + (size_t)T * MS;                             // Y_s [T][MS]
+    __shared__ double xs[GP_TMAX * GP_XS];
+    __shared__ double ib[GP_TMAX * GP_TS], w[GP_TMAX * GP_TS];
     __shared__ int rows[GP_TMAX];
     __shared__ double vv[GP_TMAX], ee[GP_TMAX];
-    __shared__ double gacc[32];                                   // per-slot gradient accumulators of this block
-    const int s = blockIdx.x, l = blockIdx.y, tid = threadIdx.x, ld = T + 1;
-    if (tid < T) rows[tid] = idx[(size_t)s * T + tid];
+    __shared__ double gacc[32];                                   // per-row gradient accumulators of this block
+    const int s = blockIdx.x, l = blockIdx.y, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    if (tid < GP_TMAX) rows[tid] = tid < T ? idx[(size_t)s * T + tid] : -1;
     if (tid < 32) gacc[tid] = 0.0;
     __syncthreads();
     for (int e = tid; e < T * Q; e += 256) {
         const int t = e / Q, r = rows[t];
-        xs[e] = r >= 0 ? x[(size_t)r * Q + e % Q] : 0.0;
+        xs[t * GP_XS + e % Q] = r >= 0 ? x[(size_t)r * Q + e % Q] : 0.0;
+    }
+    for (int e = tid; e < T * M; e += 256) {
+        const int t = e / M, m = e - t * M, r = rows[t];
+        const size_t o = ((size_t)l * Bn + (r >= 0 ? r : 0)) * M + m;
+        vs[t * MS + m] = r >= 0 ? V[o] : 0.0;
+        ys[t * MS + m] = r >= 0 ? Y[o] : 0.0;
     }
     if (tid < T) {
         const int r = rows[tid];
         vv[tid] = r >= 0 ? v[(size_t)l * Bn + r] : 0.0;
         ee[tid] = r >= 0 ? exp((double)lv[(size_t)r * L + l]) : 0.0;
     }
-    for (int e = tid; e < T * T; e += 256) {
-        const size_t o = (((size_t)s * L + l) * T + e / T) * T + e % T;
-        ib[(e / T) * ld + e % T] = iB_in[o];
-        k0m[(e / T) * ld + e % T] = K0_in[o];
-    }
     __syncthreads();
-    // w = diag(e) + K0   then  gb = iB w iB
-    for (int e = tid; e < T * T; e += 256) {
-        const int i = e / T, j = e % T;
-        w[i * ld + j] = k0m[i * ld + j] + (i == j ? ee[i] : 0.0);
-    }
-    __syncthreads();
-    double tmp[4];
-    int cnt = 0;
-    for (int e = tid; e < T * T; e += 256, ++cnt) {               // tmp = iB w
-        const int i = e / T, j = e % T;
-        double a = 0.0;
-        for (int k = 0; k < T; ++k) a += ib[i * ld + k] * w[k * ld + j];
-        tmp[cnt] = a;
-    }
-    __syncthreads();
-    cnt = 0;
-    for (int e = tid; e < T * T; e += 256, ++cnt) w[(e / T) * ld + e % T] = tmp[cnt];
-    __syncthreads();
-    for (int e = tid; e < T * T; e += 256) {
-        const int i = e / T, j = e % T;
-        double a = 0.0;
-        for (int k = 0; k < T; ++k) a += w[i * ld + k] * ib[k * ld + j];          // (iB w iB)[i][j]
-        double yv = 0.0;                                                          // (Y V^T)[i][j]
-        if (rows[i] >= 0 && rows[j] >= 0) {
-            const double* yi = Y + ((size_t)l * Bn + rows[i]) * M;
-            const double* vj = V + ((size_t)l * Bn + rows[j]) * M;
-            for (int m = 0; m < M; ++m) yv += yi[m] * vj[m];
-        }
-        gb[i * ld + j] = 0.5 * c * (ib[i * ld + j] - vv[i] * vv[j] - a + yv);
-    }
-    __syncthreads();
-    // chain rule into scales / lengthscales: G_B with the k1 terms, G_K0 = c/2 iB with the k0 terms
-    for (int e = tid; e < T * T; e += 256) {
-        const int i = e / T, j = e % T;
-        if (rows[i] < 0 || rows[j] < 0) continue;
-        for (int pass = 0; pass < 2; ++pass) {
-            const hlvae_gp_kernel& kk = pass == 0 ? k1 : k0;
-            const double g = pass == 0 ? gb[i * ld + j] : 0.5 * c * ib[i * ld + j];
-            if (g == 0.0) continue;
-            for (int t = 0; t < kk.n_terms; ++t) {
-                const double tv = gp_term_value(kk, t, prm, L, l, xs + i * Q, xs + j * Q, true);
-                if (tv == 0.0) continue;
-                const int ss = kk.scale_slot[t];
-                atomicAdd(&gacc[ss], g * tv * gp_sigmoid(prm[(size_t)ss * L + l] - GP_MIN_LOG));
-                for (int f = 0; f < kk.n_factors[t]; ++f)
-                    if (kk.kind[t][f] == HLVAE_GP_RBF) {
-                        const int sl = kk.ls_slot[t][f];
-                        const double raw = prm[(size_t)sl * L + l], ls = gp_positive(raw);
-                        const double d = xs[i * Q + kk.dim[t][f]] - xs[j * Q + kk.dim[t][f]];
-                        atomicAdd(&gacc[sl], g * tv * d * d / (ls * ls) * gp_sigmoid(raw - GP_MIN_LOG));
-                    }
+    // w = diag(e) + K0
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            if (i < T && j < T) {
+                const size_t o = (((size_t)s * L + l) * T + i) * T + j;
+                ib[i * GP_TS + j] = iB_in[o];
+                w[i * GP_TS + j] = K0_in[o] + (i == j ? ee[i] : 0.0);
             }
         }
-    }
+    __syncthreads();
+    double tmp[2][2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {                           // tmp = iB w
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            double acc = 0.0;
+            if (i < T && j < T)
+                for (int k = 0; k < T; ++k) acc += ib[i * GP_TS + k] * w[k * GP_TS + j];
+            tmp[ii][jj] = acc;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            if (i < T && j < T) w[i * GP_TS + j] = tmp[ii][jj];
+        }
+    __syncthreads();
+    GpHyp h0, h1;
+    gp_hoist(k0, hyp, n_slots, L, l, h0);
+    gp_hoist(k1, hyp, n_slots, L, l, h1);
+    GpAcc a0, a1;
+    gp_acc_zero(a0);
+    gp_acc_zero(a1);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            if (i < T && j < T && rows[i] >= 0 && rows[j] >= 0) {
+                double acc = 0.0;                                                 // (iB w iB)[i][j]
+                for (int k = 0; k < T; ++k) acc += w[i * GP_TS + k] * ib[k * GP_TS + j];
+                double yv = 0.0;                                                  // (Y V^T)[i][j]
+                for (int m = 0; m < M; ++m) yv += ys[i * MS + m] * vs[j * MS + m];
+                const double ibv = ib[i * GP_TS + j];
+                const double g1 = 0.5 * c * (ibv - vv[i] * vv[j] - acc + yv);     // dL / dB_st
+                const double g0 = 0.5 * c * ibv;                                  // dL / dK0_st
+                gp_pair_grad(k1, h1, xs + i * GP_XS, xs + j * GP_XS, g1, a1);
+                gp_pair_grad(k0, h0, xs + i * GP_XS, xs + j * GP_XS, g0, a0);
+            }
+        }
+    const double* dpos_l = hyp + (size_t)n_slots * L + l;
+    gp_flush(k1, a1, dpos_l, L, gacc, tid & 63);
+    gp_flush(k0, a0, dpos_l, L, gacc, tid & 63);
     __syncthreads();
     if (tid < n_slots && gacc[tid] != 0.0) atomicAdd(gprm + (size_t)tid * L + l, gacc[tid]);
 }
 
 // chain rule from G[l][i][j] = dL/dK(x1_i, x2_j) into the hyper-parameters and the points of the SECOND argument.
-// both_args != 0: x1 and x2 are the same per-latent point set (K0zz): G is used as given for the hyper-parameters and
-// as G + G^T for the points.  One workgroup per (latent, column j).
-__global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const double* __restrict__ prm, int L, int Q,
-                                                       const double* __restrict__ x1, int n1, int per_latent1,
+// both_args != 0: x1 and x2 are the same per-latent point set (K0zz) and G arrives symmetrised (G + G^T): half of it
+// drives the hyper-parameters, all of it the points (which sit in both argument positions).
+// grid (ceil(n2 / 64), row chunks of 64, L), block 256 = 4 waves x 64 columns: a lane owns one column j and walks 16
+// rows; covariates of the row chunk and of the 64 columns are staged in LDS.
+#define GP_PG_ROWS 64
+__global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const double* __restrict__ hyp, int n_slots, int L,
+                                                       int Q, const double* __restrict__ x1, int n1, int per_latent1,
                                                        const double* __restrict__ x2, int n2, int both_args,
-                                                       const double* __restrict__ G, int n_slots,
-                                                       double* __restrict__ gprm, double* __restrict__ gx2) {
+                                                       const double* __restrict__ G, double* __restrict__ gprm,
+                                                       double* __restrict__ gx2) {
     __shared__ double gacc[32];
-    __shared__ double gz[8];
-    const int j = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+    __shared__ double xs[GP_PG_ROWS * GP_XS], xbs[64 * GP_XS];
+    __shared__ double zred[4][64][GP_XS];
+    const int tid = threadIdx.x, lane = tid & 63, sub = tid >> 6;
+    const int j = blockIdx.x * 64 + lane, l = blockIdx.z;
+    const int row0 = blockIdx.y * GP_PG_ROWS, nrow = min(GP_PG_ROWS, n1 - row0);
     if (tid < 32) gacc[tid] = 0.0;
-    if (tid < 8) gz[tid] = 0.0;
+    for (int e = tid; e < nrow * Q; e += 256)
+        xs[(e / Q) * GP_XS + e % Q] = x1[((size_t)(per_latent1 ? l : 0) * n1 + row0) * Q + e];
+    for (int e = tid; e < 64 * Q; e += 256) {
+        const int col = blockIdx.x * 64 + e / Q;
+        xbs[(e / Q) * GP_XS + e % Q] = col < n2 ? x2[((size_t)l * n2 + col) * Q + e % Q] : 0.0;
+    }
+    for (int q = 0; q < GP_XS; ++q) zred[sub][lane][q] = 0.0;
+    GpHyp h;
+    gp_hoist(k, hyp, n_slots, L, l, h);
+    GpAcc a;
+    gp_acc_zero(a);
+    double tz[HLVAE_GP_MAX_TERMS][GP_MAX_RBF];
+#pragma unroll
+    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) tz[t][0] = tz[t][1] = 0.0;
     __syncthreads();
-    const double* xb = x2 + ((size_t)l * n2 + j) * Q;
-    double lacc[32];
+    const int i_lo = sub * (GP_PG_ROWS / 4);
+    const int jc = min(j, n2 - 1);
+    const double gs = both_args ? 0.5 : 1.0;
+    double gv[GP_PG_ROWS / 4];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) lacc[q] = 0.0;
-    double lz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < n1; i += 256) {
-        const double* xa = x1 + ((size_t)(per_latent1 ? l : 0) * n1 + i) * Q;
-        const double g = G[((size_t)l * n1 + i) * n2 + j];
-        const double gsym = both_args ? g + G[((size_t)l * n1 + j) * n2 + i] : g;
-        for (int t = 0; t < k.n_terms; ++t) {
-            const double tv = gp_term_value(k, t, prm, L, l, xa, xb, true);
-            if (tv == 0.0) continue;
-            const int ss = k.scale_slot[t];
-            const double sg = gp_sigmoid(prm[(size_t)ss * L + l] - GP_MIN_LOG);
+    for (int r = 0; r < GP_PG_ROWS / 4; ++r) {                    // all loads of this lane in flight before the arithmetic
+        const int i = min(i_lo + r, nrow - 1);
+        gv[r] = G[((size_t)l * n1 + row0 + i) * n2 + jc];
+    }
+    const double* xb = xbs + lane * GP_XS;
 #pragma unroll
-            for (int q = 0; q < 32; ++q)
-                if (q == ss) lacc[q] += g * tv * sg;
-            for (int f = 0; f < k.n_factors[t]; ++f)
-                if (k.kind[t][f] == HLVAE_GP_RBF) {
-                    const int sl = k.ls_slot[t][f], dim = k.dim[t][f];
-                    const double raw = prm[(size_t)sl * L + l], ls = gp_positive(raw);
-                    const double d = xa[dim] - xb[dim];
-                    const double gl = g * tv * d * d / (ls * ls) * gp_sigmoid(raw - GP_MIN_LOG);
+    for (int r = 0; r < GP_PG_ROWS / 4; ++r) {
+        const int i = i_lo + r;
+        if (i >= nrow || j >= n2) continue;
+        const double* xa = xs + i * GP_XS;
+        const double gsym = gv[r], g = gs * gsym;
+        double d0, d1, e0, e1;
 #pragma unroll
-                    for (int q = 0; q < 32; ++q)
-                        if (q == sl) lacc[q] += gl;
-                    const double gzq = gsym * tv * d / (ls * ls);                      // d k / d x2[dim]
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (q == dim) lz[q] += gzq;
-                }
+        for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+            if (t >= k.n_terms) break;
+            const double tv = gp_term(k, t, h.sc[t], h.il2[t][0], h.il2[t][1], xa, xb, d0, d1, e0, e1);
+            const double gt = g * tv, gz = gsym * tv;
+            a.ts[t] += gt;
+            a.tl[t][0] += gt * e0;
+            a.tl[t][1] += gt * e1;
+            tz[t][0] += gz * d0 * h.il2[t][0];                    // d k / d x2[dim] = k (xa - xb) / ls^2
+            tz[t][1] += gz * d1 * h.il2[t][1];
         }
     }
+    gp_flush(k, a, hyp + (size_t)n_slots * L + l, L, gacc, lane);
+    // inducing points: per-lane LDS row indexed by covariate, summed over the 4 row sub-chunks
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        if (q >= n_slots) break;
-        const double sum = wave_sum_d(lacc[q]);
-        if ((tid & 63) == 0 && sum != 0.0) atomicAdd(&gacc[q], sum);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        if (q >= Q) break;
-        const double sum = wave_sum_d(lz[q]);
-        if ((tid & 63) == 0 && sum != 0.0) atomicAdd(&gz[q], sum);
+    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+        if (t >= k.n_terms) break;
+        int r = 0;
+        for (int f = 0; f < k.n_factors[t]; ++f)
+            if (k.kind[t][f] == HLVAE_GP_RBF) {
+                zred[sub][lane][k.dim[t][f]] += r == 0 ? tz[t][0] : tz[t][1];
+                ++r;
+            }
     }
     __syncthreads();
     if (tid < n_slots && gacc[tid] != 0.0) atomicAdd(gprm + (size_t)tid * L + l, gacc[tid]);
-    if (tid < Q && gx2 != nullptr && gz[tid] != 0.0) atomicAdd(gx2 + ((size_t)l * n2 + j) * Q + tid, gz[tid]);
+    if (gx2 != nullptr && sub == 0 && j < n2) {
+        for (int q = 0; q < Q; ++q) {
+            const double sum = zred[0][lane][q] + zred[1][lane][q] + zred[2][lane][q] + zred[3][lane][q];
+            if (sum != 0.0) atomicAdd(gx2 + ((size_t)l * n2 + j) * Q + q, sum);
+        }
+    }
+}
+
+// every scalar of the bound in one launch (elbo_functions.py:268-285):
+//   out += c/2 [ sum(part) - sum(W o iK) + sum(Qm o W) - sum(log_var) ]
+//        + 1/2 [ sum(iK o H) + sum(m o iKm) + sum(ldK) - sum(ldH) ]          (+ konst from block 0)
+__global__ __launch_bounds__(256) void k_gp_bound(const double* __restrict__ part, int n_part, const double* __restrict__ W,
+                                                  const double* __restrict__ iK, const double* __restrict__ Qm,
+                                                  const double* __restrict__ H, int LMM, const double* __restrict__ m,
+                                                  const double* __restrict__ iKm, int LM, const double* __restrict__ ldK,
+                                                  const double* __restrict__ ldH, int L, const float* __restrict__ lv, int BL,
+                                                  double c, double konst, double* __restrict__ out) {
+    __shared__ double red[2][4];
+    const int g = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    double ac = 0.0, au = 0.0;
+    for (int e = g; e < LMM; e += stride) {
+        const double w = W[e], ik = iK[e];
+        ac += (Qm[e] - ik) * w;
+        au += ik * H[e];
+    }
+    for (int e = g; e < n_part; e += stride) ac += part[e];
+    for (int e = g; e < BL; e += stride) ac -= (double)lv[e];
+    for (int e = g; e < LM; e += stride) au += m[e] * iKm[e];
+    for (int e = g; e < L; e += stride) au += ldK[e] - ldH[e];
+    ac = wave_sum_d(ac);
+    au = wave_sum_d(au);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ac; red[1][threadIdx.x >> 6] = au; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sc = red[0][0] + red[0][1] + red[0][2] + red[0][3], su = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        atomicAdd(out, 0.5 * c * sc + 0.5 * su + (blockIdx.x == 0 ? konst : 0.0));
+    }
+}
+
+// torch.optim.Adam (HLVAE_main.py:277-278) on the flat fp64 arena, ONE workgroup (the arena is ~20 k values): the step
+// counter lives on the device (HIP-graph safe) and the consumed gradients are zeroed for the next step's atomics
+__global__ __launch_bounds__(1024) void k_gp_adam(double* __restrict__ p, double* __restrict__ g, double* __restrict__ m1,
+                                                  double* __restrict__ m2, int n, int64_t* __restrict__ step, double lr,
+                                                  double b1, double b2, double eps) {
+    const double t = (double)(step[0] + 1);
+    const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+    const double step_size = lr / bc1, rs = 1.0 / sqrt(bc2);
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double gi = g[i];
+        const double a = b1 * m1[i] + (1.0 - b1) * gi, v = b2 * m2[i] + (1.0 - b2) * gi * gi;
+        m1[i] = a;
+        m2[i] = v;
+        p[i] -= step_size * a / (sqrt(v) * rs + eps);
+        g[i] = 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) step[0] += 1;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -423,82 +600,119 @@ static int gp_check_kernel(const hlvae_gp_kernel* k, int n_slots, int Q) {
     for (int t = 0; t < k->n_terms; ++t) {
         HL_REQUIRE(k->n_factors[t] >= 1 && k->n_factors[t] <= HLVAE_GP_MAX_FACTORS && k->scale_slot[t] >= 0 &&
                        k->scale_slot[t] < n_slots, HLVAE_EINVAL, "gp kernel: term %d", t);
+        int n_rbf = 0;
         for (int f = 0; f < k->n_factors[t]; ++f) {
             HL_REQUIRE(k->dim[t][f] >= 0 && k->dim[t][f] < Q, HLVAE_EINVAL, "gp kernel: covariate index");
-            if (k->kind[t][f] == HLVAE_GP_RBF)
+            if (k->kind[t][f] == HLVAE_GP_RBF) {
                 HL_REQUIRE(k->ls_slot[t][f] >= 0 && k->ls_slot[t][f] < n_slots, HLVAE_EINVAL, "gp kernel: lengthscale row");
+                ++n_rbf;
+            }
         }
+        HL_REQUIRE(n_rbf <= GP_MAX_RBF, HLVAE_EINVAL, "gp kernel: at most 2 RBF factors per term");
     }
     return 0;
 }
 
 extern "C" {
 
-int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* prm, int n_slots, int L, int Q, const double* x1, int n1,
+int hlvae_gp_transform(const double* raw, int n_slots, int L, double* hyp, hlvae_stream s) {
+    HL_REQUIRE(raw && hyp && n_slots > 0 && L > 0, HLVAE_EINVAL, "gp_transform: bad arguments");
+    const int n = n_slots * L;
+    HL_PROF("gp_transform", (hipStream_t)s);
+    k_gp_transform<<<(n + 255) / 256, 256, 0, (hipStream_t)s>>>(raw, n, hyp);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* hyp, int n_slots, int L, int Q, const double* x1, int n1,
                            int per_latent1, const double* x2, int n2, int per_latent2, double jitter, double* out,
                            hlvae_stream s) {
     if (int rc = gp_check_kernel(k, n_slots, Q)) return rc;
-    HL_REQUIRE(prm && x1 && x2 && out && L > 0 && n1 > 0 && n2 > 0, HLVAE_EINVAL, "gp_kernel_matrix: bad arguments");
-    const long total = (long)L * n1 * n2;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
+    HL_REQUIRE(hyp && x1 && x2 && out && L > 0 && n1 > 0 && n2 > 0, HLVAE_EINVAL, "gp_kernel_matrix: bad arguments");
+    int chunks = (n1 * n2 + 255) / 256;
+    if (chunks > 64) chunks = 64;
     HL_PROF("gp_kernel_matrix", (hipStream_t)s);
-    k_gp_kernel_matrix<<<blocks, 256, 0, (hipStream_t)s>>>(*k, prm, L, Q, x1, n1, per_latent1, x2, n2, per_latent2, jitter, out);
+    k_gp_kernel_matrix<<<dim3(chunks, L), 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2,
+                                                                  per_latent2, jitter, out);
     HL_LAUNCH_CHECK();
     return 0;
 }
 
 int hlvae_gp_chol_inv(const double* A, int n, int N, double* inv, double* logdet, int* fail, hlvae_stream s) {
-    HL_REQUIRE(A && inv && logdet && n > 0 && N > 0 && N <= 128, HLVAE_EINVAL, "gp_chol_inv: N=%d (max 128)", N);
-    const size_t smem = ((size_t)N * (N + 1) + N) * sizeof(double);
-    static size_t attr_max = 48 * 1024;
-    if (smem > attr_max) {
-        HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_chol_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)smem));
-        attr_max = smem;
-    }
-    HL_PROF("gp_chol_inv", (hipStream_t)s);
-    k_gp_chol_inv<<<n, 256, smem, (hipStream_t)s>>>(A, N, inv, logdet, fail);
+    HL_REQUIRE(A && inv && logdet && n > 0 && N > 0 && N <= GP_MMAX, HLVAE_EINVAL, "gp_chol_inv: N=%d (max %d)", N, GP_MMAX);
+    HL_PROF("gp_spd_inv", (hipStream_t)s);
+    k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail);
     HL_LAUNCH_CHECK();
     return 0;
 }
 
-int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* prm, int n_slots, int L, int Q,
+int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* hyp, int n_slots, int L, int Q,
                          const double* x, const double* noise, const int32_t* idx, int S, int T, const double* Kxz, int B,
                          int M, const double* resid, const float* lv, double c, double* iB, double* K0s, double* V,
                          double* v, double* part, float* g_mu, float* g_lv, hlvae_stream s) {
     if (int rc = gp_check_kernel(k0, n_slots, Q)) return rc;
     if (int rc = gp_check_kernel(k1, n_slots, Q)) return rc;
-    HL_REQUIRE(T >= 1 && T <= GP_TMAX && S >= 1 && Q <= 8, HLVAE_ESHAPE, "gp_subject_fwd: T=%d (max %d)", T, GP_TMAX);
+    HL_REQUIRE(T >= 1 && T <= GP_TMAX && S >= 1 && Q <= 8 && M <= GP_MMAX, HLVAE_ESHAPE,
+               "gp_subject_fwd: T=%d (max %d), M=%d (max %d)", T, GP_TMAX, M, GP_MMAX);
     HL_PROF("gp_subject_fwd", (hipStream_t)s);
-    k_gp_subject_fwd<<<dim3(S, L), 256, 0, (hipStream_t)s>>>(*k0, *k1, prm, L, Q, x, noise, idx, T, Kxz, B, M, resid, lv, c, iB,
-                                                           K0s, V, v, part, g_mu, g_lv);
+    k_gp_subject_fwd<<<dim3(S, L), 256, 0, (hipStream_t)s>>>(*k0, *k1, hyp, n_slots, L, Q, x, noise, idx, T, Kxz, B, M, resid,
+                                                           lv, c, iB, K0s, V, v, part, g_mu, g_lv);
     HL_LAUNCH_CHECK();
     return 0;
 }
 
-int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* prm, int n_slots, int L, int Q,
+int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* hyp, int n_slots, int L, int Q,
                          const double* x, const int32_t* idx, int S, int T, int B, int M, const double* iB, const double* K0s,
                          const double* V, const double* v, const double* Y, const float* lv, double c, double* gprm,
                          hlvae_stream s) {
     if (int rc = gp_check_kernel(k0, n_slots, Q)) return rc;
     if (int rc = gp_check_kernel(k1, n_slots, Q)) return rc;
-    HL_REQUIRE(T >= 1 && T <= GP_TMAX && S >= 1, HLVAE_ESHAPE, "gp_subject_bwd: T=%d", T);
+    HL_REQUIRE(T >= 1 && T <= GP_TMAX && S >= 1 && M <= GP_MMAX, HLVAE_ESHAPE, "gp_subject_bwd: T=%d M=%d", T, M);
+    const size_t smem = (size_t)2 * T * (M + 1) * sizeof(double);
+    static size_t attr_max = 32 * 1024;
+    if (smem > attr_max) {
+        HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_subject_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)smem));
+        attr_max = smem;
+    }
     HL_PROF("gp_subject_bwd", (hipStream_t)s);
-    k_gp_subject_bwd<<<dim3(S, L), 256, 0, (hipStream_t)s>>>(*k0, *k1, prm, L, Q, x, idx, T, B, M, iB, K0s, V, v, Y, lv, c,
-                                                           n_slots, gprm);
+    k_gp_subject_bwd<<<dim3(S, L), 256, smem, (hipStream_t)s>>>(*k0, *k1, hyp, n_slots, L, Q, x, idx, T, B, M, iB, K0s, V, v, Y,
+                                                              lv, c, gprm);
     HL_LAUNCH_CHECK();
     return 0;
 }
 
-int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* prm, int n_slots, int L, int Q, const double* x1, int n1,
+int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots, int L, int Q, const double* x1, int n1,
                         int per_latent1, const double* x2, int n2, int both_args, const double* G, double* gprm, double* gx2,
                         hlvae_stream s) {
     if (int rc = gp_check_kernel(k, n_slots, Q)) return rc;
     HL_REQUIRE(!both_args || n1 == n2, HLVAE_ESHAPE, "gp_param_grad: both_args needs a square matrix");
     HL_PROF("gp_param_grad", (hipStream_t)s);
-    k_gp_param_grad<<<dim3(n2, L), 256, 0, (hipStream_t)s>>>(*k, prm, L, Q, x1, n1, per_latent1, x2, n2, both_args, G, n_slots,
-                                                            gprm, gx2);
+    dim3 grid((n2 + 63) / 64, (n1 + GP_PG_ROWS - 1) / GP_PG_ROWS, L);
+    k_gp_param_grad<<<grid, 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2, both_args, G, gprm,
+                                                     gx2);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_bound(const double* part, int S, const double* W, const double* iK, const double* Qm, const double* H,
+                   const double* m, const double* iKm, const double* ldK, const double* ldH, const float* lv, int B, int L,
+                   int M, double c, double n_total, double* out, hlvae_stream s) {
+    HL_REQUIRE(part && W && iK && Qm && H && m && iKm && ldK && ldH && lv && out, HLVAE_EINVAL, "gp_bound: null pointer");
+    HL_CHECK(hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)s));
+    const double konst = -0.5 * (double)L * M - 0.5 * (double)L * n_total;
+    HL_PROF("gp_bound", (hipStream_t)s);
+    k_gp_bound<<<128, 256, 0, (hipStream_t)s>>>(part, S * L * 4, W, iK, Qm, H, L * M * M, m, iKm, L * M, ldK, ldH, L, lv, B * L, c,
+                                              konst, out);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,
+                  double eps, hlvae_stream s) {
+    HL_REQUIRE(p && g && m1 && m2 && step && n > 0, HLVAE_EINVAL, "gp_adam: bad arguments");
+    HL_PROF("gp_adam", (hipStream_t)s);
+    k_gp_adam<<<1, 1024, 0, (hipStream_t)s>>>(p, g, m1, m2, n, step, lr, b1, b2, eps);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -235,7 +235,9 @@ def _pack_spec(terms, slot0):
 class GPPriorHIP:
     """GP prior with hand-written HIP kernels and analytic gradients (see module docstring).  Same state and update
     rules as ``GPPrior``; hyper-parameters are one fp64 tensor ``prm`` [rows, L] of RAW values (row order: terms of the
-    id-free kernel then of the id kernel, each: scale, then its RBF lengthscales)."""
+    id-free kernel then of the id kernel, each: scale, then its RBF lengthscales).  ``prm`` and ``zt_list`` are views of
+    one flat arena that a single fused Adam kernel updates; every buffer of a step is preallocated, so the step can be
+    captured in a HIP graph."""
 
     def __init__(self, latent_dim, train_x, M, id_covariate, N_total, cat_kernel=(2,), bin_kernel=(), sqexp_kernel=(0,),
                  cat_int_kernel=({"cont_covariate": 0, "cat_covariate": 2}, {"cont_covariate": 0, "cat_covariate": 3},
@@ -246,7 +248,9 @@ class GPPriorHIP:
         if dev.type != "cuda":
             raise RuntimeError("GPPriorHIP runs on the GPU only (no CPU fallback); GPPrior is the device-independent statement")
         self.L, self.M, self.id_covariate, self.N_total, self.eps, self.ng_lr = latent_dim, M, id_covariate, N_total, eps, natural_gradient_lr
-        self.Q = train_x.shape[1]
+        self.lr = lr
+        self.Q = Q = train_x.shape[1]
+        L = latent_dim
         t0, t1 = _spec_from_config(list(cat_kernel), list(bin_kernel), list(sqexp_kernel), list(cat_int_kernel),
                                    list(bin_int_kernel), list(covariate_missing_val), id_covariate)
         self.k0, names0, n = _pack_spec(t0, 0)
@@ -255,20 +259,32 @@ class GPPriorHIP:
         self.slot_names = [("k0",) + x for x in names0] + [("k1",) + x for x in names1]
         raw = lambda v: math.log(v - math.exp(-16.0))
         init = [raw(math.log(2)) if f is None else raw(2.5) for (_, _, f) in self.slot_names]        # GP_model.py:44,72
-        self.prm = torch.tensor(init, dtype=torch.float64, device=dev)[:, None].repeat(1, latent_dim).contiguous().requires_grad_(True)
+        f64 = dict(dtype=torch.float64, device=dev)
+        n_theta = n * L + L * M * Q
+        self._theta = torch.zeros(n_theta, **f64)                  # [hyper-parameters | inducing points]
+        self._gtheta = torch.zeros(n_theta, **f64)                 # gradients (zeroed by the Adam kernel after use)
+        self._adam_m, self._adam_v = torch.zeros(n_theta, **f64), torch.zeros(n_theta, **f64)
+        self._adam_step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.prm = self._theta[:n * L].view(n, L)
+        self.zt_list = self._theta[n * L:].view(L, M, Q)
+        self.prm.copy_(torch.tensor(init, **f64)[:, None].expand(n, L))
         g = torch.Generator().manual_seed(seed)
         Ntr = train_x.shape[0]
-        zt = torch.stack([train_x[torch.randperm(Ntr, generator=g)[:M].to(dev)] for _ in range(latent_dim)])
-        self.zt_list = zt.clone().to(torch.float64).contiguous().requires_grad_(True)
-        self.m = torch.randn(latent_dim, M, 1, generator=g, dtype=torch.float64).to(dev)
-        Hh = (torch.randn(latent_dim, M, M, generator=g, dtype=torch.float64) / 10).to(dev)
-        self.H = (Hh @ Hh.transpose(-1, -2) + 1e-6 * torch.eye(M, dtype=torch.float64, device=dev)).contiguous()
-        self.noise = torch.ones(latent_dim, dtype=torch.float64, device=dev)                        # HLVAE_main.py:211-213
-        self.opt = torch.optim.Adam([self.prm, self.zt_list], lr=lr)
+        self.zt_list.copy_(torch.stack([train_x[torch.randperm(Ntr, generator=g)[:M].to(dev)] for _ in range(L)]))
+        self.prm.grad = self._gtheta[:n * L].view(n, L)
+        self.zt_list.grad = self._gtheta[n * L:].view(L, M, Q)
+        self._hyp = torch.zeros(3, n, L, **f64)
+        self._KH = torch.zeros(2 * L, M, M, **f64)                 # [K0zz + jitter | H]: inverted in one batched launch
+        self.H = self._KH[L:]
+        self.m = torch.randn(L, M, 1, generator=g, dtype=torch.float64).to(dev)
+        Hh = (torch.randn(L, M, M, generator=g, dtype=torch.float64) / 10).to(dev)
+        self.H.copy_(Hh @ Hh.transpose(-1, -2) + 1e-6 * torch.eye(M, **f64))
+        self.noise = torch.ones(L, **f64)                                                           # HLVAE_main.py:211-213
         self.fail = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.last_kld = None
+        self.last_kld = torch.zeros(1, **f64)
         self._groups = {}
-        self._grad_m = self._grad_H = None
+        self._grad_m = self._grad_H = self._iH = None
+        self._transform()
 
     @classmethod
     def from_reference_config(cls, model, src, P_total, dev, M=120):
@@ -279,12 +295,19 @@ class GPPriorHIP:
     def _stream(self):
         return _C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def kernel_matrix(self, k, x1, x2, jitter=0.0):
+    def _transform(self):
+        """positive hyper-parameters, d pos / d raw / pos and 1 / pos^2, once per step (GP_model.py:57,85)"""
+        _lib.check(_lib.load().hlvae_gp_transform(_lib.ptr(self.prm), self.n_slots, self.L, _lib.ptr(self._hyp), self._stream()),
+                   "gp_transform")
+        return self._hyp
+
+    def kernel_matrix(self, k, x1, x2, jitter=0.0, out=None):
         L, Q = self.L, self.Q
         pl1, pl2 = int(x1.dim() == 3), int(x2.dim() == 3)
         n1, n2 = x1.shape[-2], x2.shape[-2]
-        out = torch.empty(L, n1, n2, dtype=torch.float64, device=x1.device)
-        _lib.check(_lib.load().hlvae_gp_kernel_matrix(_C.byref(k), _lib.ptr(self.prm), self.n_slots, L, Q, _lib.ptr(x1), n1, pl1,
+        if out is None:
+            out = torch.empty(L, n1, n2, dtype=torch.float64, device=x1.device)
+        _lib.check(_lib.load().hlvae_gp_kernel_matrix(_C.byref(k), _lib.ptr(self._hyp), self.n_slots, L, Q, _lib.ptr(x1), n1, pl1,
                                                       _lib.ptr(x2), n2, pl2, _C.c_double(jitter), _lib.ptr(out), self._stream()),
                    "gp_kernel_matrix")
         return out
@@ -316,63 +339,71 @@ class GPPriorHIP:
         x = train_x.contiguous()
         idx = self._group(x)
         S, T = idx.shape
-        k0, k1, prm, z = self.k0, self.k1, self.prm.detach(), self.zt_list.detach()
+        k0, k1, z = self.k0, self.k1, self.zt_list
+        hyp = self._transform()
         f64 = dict(dtype=torch.float64, device=dev)
-        # kernel matrices and the two M x M factorizations (both in ONE batched launch)
-        Kzz = self.kernel_matrix(k0, z, z, jitter=self.eps)
+        # kernel matrices and the two M x M inversions (both in ONE batched launch: K0zz is written next to H)
+        self.kernel_matrix(k0, z, z, jitter=self.eps, out=self._KH[:L])
         Kxz = self.kernel_matrix(k0, x, z)
-        inv, logdet = self.chol_inv(torch.cat([Kzz, self.H]))
+        inv, logdet = self.chol_inv(self._KH)
         iK, iH, ldK, ldH = inv[:L], inv[L:], logdet[:L], logdet[L:]
+        self._iH = iH
+        mu64 = mu.to(torch.float64)
         iKm = iK @ self.m                                                    # [L,M,1]
-        resid = (Kxz @ iKm).squeeze(2) - mu.to(torch.float64).t()            # [L,B]
+        resid = torch.baddbmm(mu64.t().unsqueeze(2), Kxz, iKm, beta=-1.0).squeeze(2)   # K0xz iK m - mu^T   [L,B]
         lv32 = log_v.to(torch.float32).contiguous()
         iB = torch.empty(S, L, T, T, **f64); K0s = torch.empty(S, L, T, T, **f64)
-        V = torch.zeros(L, B, M, **f64); v = torch.zeros(L, B, **f64); part = torch.empty(S, L, 4, **f64)
+        V = torch.empty(L, B, M, **f64); v = torch.empty(L, B, **f64); part = torch.empty(S, L, 4, **f64)
         g_mu = torch.empty(B, L, dtype=torch.float32, device=dev); g_lv = torch.empty(B, L, dtype=torch.float32, device=dev)
-        _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(prm), self.n_slots, L, Q, _lib.ptr(x),
-                                            _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(Kxz), B, M, _lib.ptr(resid.contiguous()),
+        _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x),
+                                            _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(Kxz), B, M, _lib.ptr(resid),
                                             _lib.ptr(lv32), _C.c_double(c), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
                                             _lib.ptr(part), _lib.ptr(g_mu), _lib.ptr(g_lv), st), "gp_subject_fwd")
         KxzT = Kxz.transpose(1, 2)
         W = KxzT @ V                                                         # sum_s Ks^T iB Ks   [L,M,M]
         HiK = self.H @ iK
         Qm = iK @ HiK                                                        # iK H iK
-        ps = part.sum(dim=(0, 1))
-        A, Bt, Cc, D1 = ps[0], ps[1], ps[2], ps[3]
-        D = D1 - torch.sum(W * iK)
-        E = torch.sum(Qm * W)
-        Fq = torch.sum(log_v.to(torch.float64))
-        kl_u = 0.5 * (torch.sum(iK * self.H) + torch.sum(self.m * iKm) - L * M + ldK.sum() - ldH.sum())
-        self.last_kld = (c * 0.5 * (A + Bt + Cc + D + E - Fq) + kl_u - L * self.N_total / 2.0).reshape(1)
+        _lib.check(lib.hlvae_gp_bound(_lib.ptr(part), S, _lib.ptr(W), _lib.ptr(iK), _lib.ptr(Qm), _lib.ptr(self.H), _lib.ptr(self.m),
+                                      _lib.ptr(iKm), _lib.ptr(ldK), _lib.ptr(ldH), _lib.ptr(lv32), B, L, M, _C.c_double(c),
+                                      _C.c_double(float(self.N_total)), _lib.ptr(self.last_kld), st), "gp_bound")
         # natural-gradient terms (elbo_functions.py:262-266, 279-283)
-        P1 = torch.einsum("lbm,bl->lm", V, mu.to(torch.float64)).unsqueeze(-1)
-        Bm = iK @ W @ iK + iK
-        self._grad_m = -(iK @ P1) + Bm @ self.m
+        P1 = V.transpose(1, 2) @ mu64.t().unsqueeze(2)                       # [L,M,1]
+        Bm = torch.baddbmm(iK, iK @ W, iK)                                   # iK W iK + iK
+        self._grad_m = torch.baddbmm(Bm @ self.m, iK, P1, alpha=-1.0)        # -(iK P1) + Bm m
         self._grad_H = 0.5 * (Bm - iH)
         # analytic gradients w.r.t. kernel matrices, chained into hyper-parameters / inducing points by the HIP kernels
-        gprm = torch.zeros_like(prm)
-        gz = torch.zeros_like(z)
+        gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
         Y = V @ (iK - Qm)                                                    # [L,B,M]
-        G_Kxz = c * (v.unsqueeze(2) * iKm.transpose(1, 2) - Y)               # c [ v (iK m)^T + V (Q - iK) ]
-        u = (KxzT @ v.unsqueeze(2))                                          # [L,M,1]
+        G_Kxz = torch.baddbmm(Y, v.unsqueeze(2), iKm.transpose(1, 2), beta=-c, alpha=c)   # c [ v (iK m)^T + V (Q - iK) ]
+        u = KxzT @ v.unsqueeze(2)                                            # [L,M,1]
         HiKW = HiK @ W
-        R = c * 0.5 * (2.0 * u @ self.m.transpose(1, 2) - W + HiKW + HiKW.transpose(1, 2)) + 0.5 * (self.H + self.m @ self.m.transpose(1, 2))
-        G_Kzz = -(iK @ R @ iK) + 0.5 * iK
-        _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(prm), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
-                                            S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y.contiguous()),
+        mT = self.m.transpose(1, 2)
+        # R + R^T with R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T): K0zz's gradient is needed symmetrised
+        um = u @ mT
+        Rs = c * (um + um.transpose(1, 2) - W + HiKW + HiKW.transpose(1, 2)) + torch.baddbmm(self.H, self.m, mT)
+        G_Kzz_s = torch.baddbmm(iK, iK @ Rs, iK, alpha=-1.0)                 # (G + G^T),  G = -(iK R iK) + iK / 2
+        _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
+                                            S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y),
                                             _lib.ptr(lv32), _C.c_double(c), _lib.ptr(gprm), st), "gp_subject_bwd")
-        _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(prm), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
-                                           _lib.ptr(G_Kxz.contiguous()), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kxz)")
-        _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(prm), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
-                                           _lib.ptr(G_Kzz.contiguous()), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
-        self.prm.grad, self.zt_list.grad = gprm, gz
+        _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
+                                           _lib.ptr(G_Kxz), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kxz)")
+        _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
+                                           _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
         return g_mu, g_lv
 
     def optimizer_step(self):
-        self.opt.step()
-        # natural-gradient update of (m, H), training.py:130-137, with the LDS Cholesky/inverse kernel
-        iH, _ = self.chol_inv(self.H)
-        iH_new = (iH + self.ng_lr * (self._grad_H + self._grad_H.transpose(-1, -2))).contiguous()
+        # Adam on [hyper-parameters | inducing points] (HLVAE_main.py:277-278), one fused kernel, device-side step counter
+        _lib.check(_lib.load().hlvae_gp_adam(_lib.ptr(self._theta), _lib.ptr(self._gtheta), _lib.ptr(self._adam_m),
+                                             _lib.ptr(self._adam_v), self._theta.numel(), _lib.ptr(self._adam_step),
+                                             _C.c_double(self.lr), _C.c_double(0.9), _C.c_double(0.999), _C.c_double(1e-8),
+                                             self._stream()), "gp_adam")
+        # natural-gradient update of (m, H), training.py:130-137, with the register Gauss-Jordan inverse kernel
+        iH = self._iH if self._iH is not None else self.chol_inv(self.H.contiguous())[0]
+        self._iH = None
+        gH = self._grad_H
+        iH_new = torch.add(iH, gH + gH.transpose(-1, -2), alpha=self.ng_lr)
         H_new, _ = self.chol_inv(iH_new)
-        self.m = H_new @ (iH @ self.m - self.ng_lr * (self._grad_m - 2.0 * (self._grad_H @ self.m)))
-        self.H = H_new
+        rhs = torch.baddbmm(self._grad_m, gH, self.m, alpha=-2.0)            # grad_m - 2 grad_H m
+        # in place: a captured HIP graph keeps reading the same buffers
+        self.m.copy_(H_new @ torch.baddbmm(rhs, iH, self.m, beta=-self.ng_lr))
+        self.H.copy_(H_new)

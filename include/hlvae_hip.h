@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 8
+#define HLVAE_ABI_VERSION 9
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -186,48 +186,62 @@ int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m
 
 /* ---- GP-prior KL (row K): reference elbo_functions.py:196-285 with the kernels of GP_model.py:27-116, fp64 ----------
  * An additive kernel = sum over terms of  scale_t[l] * prod_f factor_f(x[dim], x'[dim]);  factors: categorical equality,
- * binary AND, RBF with its own lengthscale per latent dimension.  Hyper-parameters live in prm [n_slots][L] as RAW values
- * (positive value = exp(-16 + softplus(raw + 16)), GP_model.py:57,85). */
+ * binary AND, RBF with its own lengthscale per latent dimension (at most 2 RBF factors per term).  Hyper-parameters are
+ * one array of RAW values raw [n_slots][L]; the kernels read the transformed planes hyp [3][n_slots][L] that
+ * hlvae_gp_transform writes once per step: pos = exp(-16 + softplus(raw + 16)) (GP_model.py:57,85),
+ * dpos = sigmoid(raw + 16) (d pos / d raw = pos * dpos), il2 = 1 / pos^2.  Gradients come back w.r.t. the RAW values. */
 #define HLVAE_GP_MAX_TERMS 8
 #define HLVAE_GP_MAX_FACTORS 4
 enum { HLVAE_GP_CAT = 0, HLVAE_GP_BIN = 1, HLVAE_GP_RBF = 2 };
 typedef struct {
     int32_t n_terms;
-    int32_t scale_slot[HLVAE_GP_MAX_TERMS];                        /* row of prm with the raw scale              */
+    int32_t scale_slot[HLVAE_GP_MAX_TERMS];                        /* row of raw/hyp with the scale               */
     int32_t n_factors[HLVAE_GP_MAX_TERMS];
     int32_t kind[HLVAE_GP_MAX_TERMS][HLVAE_GP_MAX_FACTORS];
     int32_t dim[HLVAE_GP_MAX_TERMS][HLVAE_GP_MAX_FACTORS];         /* covariate column                            */
-    int32_t ls_slot[HLVAE_GP_MAX_TERMS][HLVAE_GP_MAX_FACTORS];     /* row of prm with the raw lengthscale, or -1  */
+    int32_t ls_slot[HLVAE_GP_MAX_TERMS][HLVAE_GP_MAX_FACTORS];     /* row of raw/hyp with the lengthscale, or -1  */
 } hlvae_gp_kernel;
 
+int hlvae_gp_transform(const double* raw, int n_slots, int L, double* hyp, hlvae_stream s);
 /* out [L][n1][n2] = K(x1_i, x2_j) (+ jitter on i == j).  x1 / x2: [n][Q] shared by all latents, or [L][n][Q] when the
  * per_latent flag is set (inducing points zt_list).  Replaces covar_module(x1, x2).evaluate() (elbo_functions.py:222-223). */
-int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* prm, int n_slots, int L, int Q, const double* x1, int n1,
+int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* hyp, int n_slots, int L, int Q, const double* x1, int n1,
                            int per_latent1, const double* x2, int n2, int per_latent2, double jitter, double* out,
                            hlvae_stream s);
-/* batched SPD inverse + log-determinant via Cholesky, N <= 128, one workgroup per matrix, matrix resident in LDS
- * (replaces torch.cholesky + cholesky_solve(eye), elbo_functions.py:225-228, training.py:131-135).
+/* batched SPD inverse + log-determinant, N <= 128, one workgroup per matrix, Gauss-Jordan with the matrix resident in
+ * registers (replaces torch.cholesky + cholesky_solve(eye), elbo_functions.py:225-228, training.py:131-135).
  * *fail (device int, may be NULL) is set to 1 if a pivot is not positive. */
 int hlvae_gp_chol_inv(const double* A, int n, int N, double* inv, double* logdet, int* fail, hlvae_stream s);
 /* the per-subject loop of elbo_functions.py:243-266 as one workgroup per (subject, latent).  idx [S][T]: batch row of the
  * t-th observation of subject s, -1 = padding (T <= 32).  resid [L][B] = K0xz iK0zz m - mu^T.  Outputs: iB, K0s [S][L][T][T];
  * V [L][B][M] = iB_s K0xz_s (row-indexed by batch row); v [L][B] = iB_s resid_s; part [S][L][4] = {A, B, C, sum(iB*K0)}
  * contributions; g_mu, g_lv [B][L] fp32 = d(KL bound)/d(mu, log_var) with c = P / P_batch. */
-int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* prm, int n_slots, int L, int Q,
+int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* hyp, int n_slots, int L, int Q,
                          const double* x, const double* noise, const int32_t* idx, int S, int T, const double* Kxz, int B,
                          int M, const double* resid, const float* lv, double c, double* iB, double* K0s, double* V,
                          double* v, double* part, float* g_mu, float* g_lv, hlvae_stream s);
 /* gradients of the bound w.r.t. B_st and K0_st chained into the hyper-parameters (accumulates into gprm [n_slots][L]).
  * Y [L][B][M] = V (iK0zz - iK0zz H iK0zz). */
-int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* prm, int n_slots, int L, int Q,
+int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* hyp, int n_slots, int L, int Q,
                          const double* x, const int32_t* idx, int S, int T, int B, int M, const double* iB, const double* K0s,
                          const double* V, const double* v, const double* Y, const float* lv, double c, double* gprm,
                          hlvae_stream s);
 /* chain rule from G [L][n1][n2] = dL/dK(x1_i, x2_j) into gprm [n_slots][L] and gx2 [L][n2][Q] (points of the second
- * argument, always per latent).  both_args != 0: x1 == x2 (K0zz), the points receive both argument positions. */
-int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* prm, int n_slots, int L, int Q, const double* x1, int n1,
+ * argument, always per latent).  both_args != 0: x1 == x2 (K0zz) and G must arrive symmetrised (G + G^T): the points
+ * sit in both argument positions. */
+int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots, int L, int Q, const double* x1, int n1,
                         int per_latent1, const double* x2, int n2, int both_args, const double* G, double* gprm, double* gx2,
                         hlvae_stream s);
+/* all scalar reductions of the bound (elbo_functions.py:268-285) into *out (device double):
+ *   c/2 [sum(part) - sum(W o iK) + sum(Qm o W) - sum(log_var)] + 1/2 [sum(iK o H) + m.iKm - L M + sum ldK - sum ldH] - L N/2
+ * W = sum_s Ks^T iB Ks, Qm = iK H iK, all [L][M][M]; m, iKm [L][M]; ldK, ldH [L]; lv fp32 [B][L]. */
+int hlvae_gp_bound(const double* part, int S, const double* W, const double* iK, const double* Qm, const double* H,
+                   const double* m, const double* iKm, const double* ldK, const double* ldH, const float* lv, int B, int L,
+                   int M, double c, double n_total, double* out, hlvae_stream s);
+/* torch.optim.Adam step (HLVAE_main.py:277-278) on a flat fp64 arena (hyper-parameters + inducing points, n <= ~1e5);
+ * step: device int64 advanced by the kernel; the consumed gradients are zeroed. */
+int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,
+                  double eps, hlvae_stream s);
 
 /* Per-kernel HIP-event timing (bench.py's roofline leg): while enabled every kernel launch of this library is
  * bracketed by hipEventRecord on its own stream.  hlvae_prof_report synchronises the device and writes one line
