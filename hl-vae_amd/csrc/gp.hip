@@ -571,15 +571,17 @@ __global__ __launch_bounds__(256) void k_gp_bound(const double* __restrict__ par
     }
 }
 
-// torch.optim.Adam (HLVAE_main.py:277-278) on the flat fp64 arena, ONE workgroup (the arena is ~20 k values): the step
-// counter lives on the device (HIP-graph safe) and the consumed gradients are zeroed for the next step's atomics
-__global__ __launch_bounds__(1024) void k_gp_adam(double* __restrict__ p, double* __restrict__ g, double* __restrict__ m1,
-                                                  double* __restrict__ m2, int n, int64_t* __restrict__ step, double lr,
-                                                  double b1, double b2, double eps) {
+// torch.optim.Adam (HLVAE_main.py:277-278) on the flat fp64 arena: the step counter lives on the device (HIP-graph safe)
+// and the consumed gradients are zeroed for the next step's atomics.  step[0] = completed steps, step[1] = ticket: the
+// last workgroup to finish (every workgroup has read step[0] by then) advances the counter and resets the ticket.
+__global__ __launch_bounds__(256) void k_gp_adam(double* __restrict__ p, double* __restrict__ g, double* __restrict__ m1,
+                                                 double* __restrict__ m2, int n, int64_t* __restrict__ step, double lr,
+                                                 double b1, double b2, double eps) {
     const double t = (double)(step[0] + 1);
     const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
     const double step_size = lr / bc1, rs = 1.0 / sqrt(bc2);
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
         const double gi = g[i];
         const double a = b1 * m1[i] + (1.0 - b1) * gi, v = b2 * m2[i] + (1.0 - b2) * gi * gi;
         m1[i] = a;
@@ -588,7 +590,13 @@ __global__ __launch_bounds__(1024) void k_gp_adam(double* __restrict__ p, double
         g[i] = 0.0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) step[0] += 1;
+    if (threadIdx.x == 0) {
+        const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step + 1), 1ull);
+        if (done == gridDim.x - 1) {
+            step[1] = 0;
+            step[0] += 1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -712,7 +720,7 @@ int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* 
                   double eps, hlvae_stream s) {
     HL_REQUIRE(p && g && m1 && m2 && step && n > 0, HLVAE_EINVAL, "gp_adam: bad arguments");
     HL_PROF("gp_adam", (hipStream_t)s);
-    k_gp_adam<<<1, 1024, 0, (hipStream_t)s>>>(p, g, m1, m2, n, step, lr, b1, b2, eps);
+    k_gp_adam<<<(n + 255) / 256, 256, 0, (hipStream_t)s>>>(p, g, m1, m2, n, step, lr, b1, b2, eps);
     HL_LAUNCH_CHECK();
     return 0;
 }

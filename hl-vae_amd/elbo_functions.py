@@ -264,7 +264,7 @@ class GPPriorHIP:
         self._theta = torch.zeros(n_theta, **f64)                  # [hyper-parameters | inducing points]
         self._gtheta = torch.zeros(n_theta, **f64)                 # gradients (zeroed by the Adam kernel after use)
         self._adam_m, self._adam_v = torch.zeros(n_theta, **f64), torch.zeros(n_theta, **f64)
-        self._adam_step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._adam_step = torch.zeros(2, dtype=torch.int64, device=dev)    # {steps done, ticket}
         self.prm = self._theta[:n * L].view(n, L)
         self.zt_list = self._theta[n * L:].view(L, M, Q)
         self.prm.copy_(torch.tensor(init, **f64)[:, None].expand(n, L))

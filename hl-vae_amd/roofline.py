@@ -21,6 +21,24 @@ def _ru(v, m):
     return (v + m - 1) // m * m
 
 
+def gp_algorithmic_work(gp, B, S, T):
+    """fp64 GP-prior kernels (csrc/gp.hip): bytes per launch; their arithmetic is fp64 vector work, not MFMA, so only
+    the HBM side is priced.  spd_inv / kernel_matrix / param_grad are launched twice per step with different sizes:
+    the figure is the mean of the two launches."""
+    L, M, Q, n = gp.L, gp.M, gp.Q, gp.n_slots
+    f = 8
+    w = {}
+    w["gp_transform"] = (4 * n * L * f, 0)
+    w["gp_kernel_matrix"] = ((L * M * M + L * B * M + 2 * L * M * Q + B * Q) * f // 2, 0)
+    w["gp_spd_inv"] = ((2 * L + L) * M * M * 2 * f // 2, 0)
+    w["gp_subject_fwd"] = ((L * B * M * 2 + 2 * S * L * T * T + 3 * L * B) * f + 3 * B * L * 4, 0)
+    w["gp_subject_bwd"] = ((2 * L * B * M + 2 * S * L * T * T + L * B) * f + B * L * 4, 0)
+    w["gp_param_grad"] = ((L * B * M + L * M * M + 3 * L * M * Q + B * Q) * f // 2, 0)
+    w["gp_bound"] = ((4 * L * M * M + 2 * L * M + S * L * 4) * f + B * L * 4, 0)
+    w["gp_adam"] = ((n * L + L * M * Q) * 7 * f, 0)
+    return w
+
+
 def algorithmic_work(model, B):
     """label -> (bytes, flops) per launch (algorithmic: every operand read once, every result written once)."""
     d = model._dims
@@ -74,6 +92,9 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None):
     buf = C.create_string_buffer(1 << 16)
     _lib.check(lib.hlvae_prof_report(buf, len(buf)), "hlvae_prof_report")
     work = algorithmic_work(m, B)
+    if getattr(trainer, "gp", None) is not None and batch.get("labels") is not None and hasattr(trainer.gp, "_group"):
+        S, T = trainer.gp._group(batch["labels"].contiguous()).shape
+        work.update(gp_algorithmic_work(trainer.gp, B, S, T))
     table = {}
     for line in buf.value.decode().splitlines():
         name, cnt, tot = line.split()

@@ -239,7 +239,7 @@ int hlvae_gp_bound(const double* part, int S, const double* W, const double* iK,
                    const double* m, const double* iKm, const double* ldK, const double* ldH, const float* lv, int B, int L,
                    int M, double c, double n_total, double* out, hlvae_stream s);
 /* torch.optim.Adam step (HLVAE_main.py:277-278) on a flat fp64 arena (hyper-parameters + inducing points, n <= ~1e5);
- * step: device int64 advanced by the kernel; the consumed gradients are zeroed. */
+ * step: device int64[2] = {completed steps, 0}, advanced by the kernel; the consumed gradients are zeroed. */
 int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,
                   double eps, hlvae_stream s);
 
