@@ -27,6 +27,9 @@ from . import _lib
 from .layout import (KIND_CAT, KIND_COUNT, KIND_ORDINAL, KIND_POS, KIND_REAL, ColumnPlan, compile_plan)
 
 
+_INPUT_STAGE = ("sums", "norm", "xn", "xnT", "xt", "m8")
+
+
 def _ru(v, m):
     return (v + m - 1) // m * m
 
@@ -332,9 +335,24 @@ class HLVAE(nn.Module):
         ws.Bp_max, ws.splitk_enc, ws.splitk_dec = Bp, S_e, S_d
         for name in _lib.WS_POINTERS:
             setattr(ws, name, t[name].data_ptr())
+        # second set of the input-stage buffers (statistics + packed batch): the next batch can be normalised and packed
+        # on a side stream while this one trains (ELBOTrainer.step(prefetch=...)); everything else is shared
+        alt = {n: torch.zeros_like(t[n]) for n in _INPUT_STAGE}
+        ws2 = _lib.HlvaeWs()
+        C.memmove(C.byref(ws2), C.byref(ws), C.sizeof(ws))
+        for n in _INPUT_STAGE:
+            setattr(ws2, n, alt[n].data_ptr())
+        self._ws_alt, self._ws_t_alt = ws2, alt
+        self._packed_key = None
         self._ws, self._ws_t = ws, t
         self._grad_arena = t["G"]
         self._shadow_versions = None
+
+    def _swap_input_buffers(self):
+        """exchange the two sets of input-stage buffers (host-side pointer swap)"""
+        self._ws, self._ws_alt = self._ws_alt, self._ws
+        for n in _INPUT_STAGE:
+            self._ws_t[n], self._ws_t_alt[n] = self._ws_t_alt[n], self._ws_t[n]
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -363,6 +381,7 @@ class HLVAE(nn.Module):
 
     def _run_normalize(self, data, mask, B, stats_hook=None):
         lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
+        self._packed_key = None
         _lib.check(lib.hlvae_normalize_stats(self._plan_handle, ws, _lib.ptr(data), _lib.ptr(mask), B, s), "normalize_stats")
         if stats_hook is not None:
             stats_hook(self._ws_t["sums"])          # data-parallel: all-reduce the masked column sums

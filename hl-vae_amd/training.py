@@ -64,22 +64,51 @@ class ELBOTrainer:
         self.opt = FusedAdam(model, lr=lr)
         dev, L = model.device, model.z_dim
         self._graphs = {}
+        self._pf_stream = torch.cuda.Stream(device=dev)      # input stage of the NEXT batch (prefetch)
         self.err = torch.zeros(3, model.plan.D, dtype=torch.float32, device=dev)     # error_observed / missing / all
 
     # -- the step, eager ------------------------------------------------------------------------
+    @staticmethod
+    def _batch_key(data, mask):
+        return (data.data_ptr(), mask.data_ptr(), data._version, mask._version, tuple(data.shape))
+
+    def prime(self, data: torch.Tensor, mask: torch.Tensor):
+        """Run the input stage (statistics + normalise + pack, row A) of a batch now, so that the next
+        ``step(data, mask, ...)`` (or a graph captured with ``prepacked=True``) finds it done."""
+        m = self.model
+        B = data.shape[0]
+        m._ensure_device_state(B)
+        m._run_normalize(data, mask, B, self.dp.allreduce_stats if self.dp is not None else None)
+        m._packed_key = self._batch_key(data, mask)
+
     def step(self, data: torch.Tensor, mask: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None,
-             train_x: Optional[torch.Tensor] = None):
-        """data [B, X] fp64, mask [B, D] fp64 (already resident on the GPU), P_batch = subjects in the batch."""
+             train_x: Optional[torch.Tensor] = None, prefetch=None, prepacked: Optional[bool] = None):
+        """data [B, X] fp64, mask [B, D] fp64 (already resident on the GPU), P_batch = subjects in the batch.
+
+        prefetch = (next_data, next_mask): the input stage of the NEXT batch (it depends on the data only, not on the
+        weights) runs on a side stream into the second buffer set while this batch trains; the next ``step`` on those
+        tensors skips its own input stage.  prepacked: None = detect (same tensors, unmodified), True = trust the
+        caller (HIP-graph capture: the decision is baked into the graph)."""
         m = self.model
         lib = _lib.load()
         B = data.shape[0]
         m._ensure_device_state(B)
-        ws, s = C.byref(m._ws), m._stream()
         scale = float(self.P_total) / float(P_batch)
         hook = self.dp.allreduce_stats if self.dp is not None else None
+        if prepacked is None:
+            prepacked = m._packed_key is not None and m._packed_key == self._batch_key(data, mask)
+        if not prepacked:
+            m._run_normalize(data, mask, B, hook)
+        if prefetch is not None:
+            main = torch.cuda.current_stream(m.device)
+            self._pf_stream.wait_stream(main)
+            m._swap_input_buffers()
+            with torch.cuda.stream(self._pf_stream):
+                m._run_normalize(prefetch[0], prefetch[1], prefetch[0].shape[0], hook)
+            m._swap_input_buffers()
+        ws, s = C.byref(m._ws), m._stream()
         # forward (+ head backward in the same pass: upstream gradient of log_p_x is -scale).
         # eps None -> reparameterisation noise from the in-kernel Philox stream (device-side offset: graph safe)
-        m._run_normalize(data, mask, B, hook)
         _lib.check(lib.hlvae_encoder_fwd(m._plan_handle, ws, _lib.ptr(eps), 1, C.c_uint64(0), B, s), "encoder_fwd")
         if not m._grad_region_clean:     # normally the fused Adam leaves the atomically-accumulated region zeroed
             _lib.check(lib.hlvae_zero_grad(m._plan_handle, ws, s), "zero_grad")
@@ -109,10 +138,20 @@ class ELBOTrainer:
         m._grad_region_clean = True
         if self.kl == "gp":
             self.gp.optimizer_step()
+        if prefetch is not None:                 # join; the prefetched batch's buffers become the front set
+            torch.cuda.current_stream(m.device).wait_stream(self._pf_stream)
+            m._swap_input_buffers()
+            m._packed_key = self._batch_key(prefetch[0], prefetch[1])
+        else:
+            m._packed_key = None
 
     # -- captured -------------------------------------------------------------------------------
-    def capture(self, key, data: torch.Tensor, mask: torch.Tensor, P_batch: int, train_x=None):
-        """Capture one step reading the given (static) input tensors into a HIP graph."""
+    def capture(self, key, data: torch.Tensor, mask: torch.Tensor, P_batch: int, train_x=None, prefetch=None):
+        """Capture one step reading the given (static) input tensors into a HIP graph.
+
+        With ``prefetch=(next_data, next_mask)`` the graph does NOT contain this batch's own input stage: it expects it
+        done (by the previous graph of the chain, or by ``prime`` before the first replay) and runs the next batch's
+        input stage as a parallel branch.  Chains must have an even number of graphs (two buffer sets)."""
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -121,8 +160,11 @@ class ELBOTrainer:
                 self.step(data, mask, P_batch, train_x=train_x)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if prefetch is not None:
+            self.prime(data, mask)
+            torch.cuda.synchronize()
         with torch.cuda.graph(g):
-            self.step(data, mask, P_batch, train_x=train_x)
+            self.step(data, mask, P_batch, train_x=train_x, prefetch=prefetch, prepacked=(prefetch is not None) or None)
         self._graphs[key] = g
         return g
 
