@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--kl", default="normal", choices=["normal", "gp", "none"])
-    ap.add_argument("--no-prefetch", action="store_true", help="run each batch's input stage inside its own step")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="run the NEXT batch's input stage on a side stream inside each step (measured slower on MI355X: a forked "
+                         "branch in the HIP graph costs more than the 31 us it hides; DESIGN.md section 5)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
@@ -142,7 +144,7 @@ def main():
     # software pipeline of the input stage: while batch i trains, batch i+1 is normalised and packed on a side stream
     # (row A depends on the data only).  Every step still runs exactly one input stage inside the timed region.
     nxt = lambda i: (ring[(i + 1) % len(ring)]["data"], ring[(i + 1) % len(ring)]["mask"])
-    pipelined = not a.no_prefetch
+    pipelined = a.prefetch
     if use_graph:
         for i, b in enumerate(ring):
             trainer.capture(i, b["data"], b["mask"], b["P_batch"] * world, train_x=b["labels"],

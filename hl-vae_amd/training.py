@@ -99,17 +99,20 @@ class ELBOTrainer:
             prepacked = m._packed_key is not None and m._packed_key == self._batch_key(data, mask)
         if not prepacked:
             m._run_normalize(data, mask, B, hook)
+        ws, s = C.byref(m._ws), m._stream()
+        # forward (+ head backward in the same pass: upstream gradient of log_p_x is -scale).
+        # eps None -> reparameterisation noise from the in-kernel Philox stream (device-side offset: graph safe)
+        _lib.check(lib.hlvae_encoder_fwd(m._plan_handle, ws, _lib.ptr(eps), 1, C.c_uint64(0), B, s), "encoder_fwd")
         if prefetch is not None:
+            # forked HERE: the HBM-streaming input stage of the next batch shares the machine with the compute-heavy head
+            # kernel instead of the bandwidth/latency-bound first GEMM (measured: forking at the top of the step costs more
+            # than it saves)
             main = torch.cuda.current_stream(m.device)
             self._pf_stream.wait_stream(main)
             m._swap_input_buffers()
             with torch.cuda.stream(self._pf_stream):
                 m._run_normalize(prefetch[0], prefetch[1], prefetch[0].shape[0], hook)
             m._swap_input_buffers()
-        ws, s = C.byref(m._ws), m._stream()
-        # forward (+ head backward in the same pass: upstream gradient of log_p_x is -scale).
-        # eps None -> reparameterisation noise from the in-kernel Philox stream (device-side offset: graph safe)
-        _lib.check(lib.hlvae_encoder_fwd(m._plan_handle, ws, _lib.ptr(eps), 1, C.c_uint64(0), B, s), "encoder_fwd")
         if not m._grad_region_clean:     # normally the fused Adam leaves the atomically-accumulated region zeroed
             _lib.check(lib.hlvae_zero_grad(m._plan_handle, ws, s), "zero_grad")
         _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 1, 2 if self.metrics else 0, 0, B, s), "decoder_fwd")
