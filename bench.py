@@ -137,7 +137,7 @@ def main():
     gp = None
     if kl == "gp":
         from hlvae_amd.elbo_functions import GPPriorHIP
-        gp = GPPriorHIP.from_reference_config(model, src, P_total, dev)       # shipped kernels, M = 120 inducing points
+        gp = GPPriorHIP.from_reference_config(model, src, P_total, dev, dp=dp)       # shipped kernels, M = 120 inducing points
     trainer = ELBOTrainer(model, P_total=P_total, kl=kl, gp=gp, max_batch=a.batch, dp=dp, metrics=True)
     ring = build_batches(src, a.batch, 4, dev)
     use_graph = not a.no_graph and world == 1

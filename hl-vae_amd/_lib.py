@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -85,7 +85,7 @@ _SIGS = {
                                       C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "hlvae_gp_transform": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_bound": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
-                                 C.c_double, C.c_double, _vp, _vp]),
+                                 C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "hlvae_gp_adam": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
     "hlvae_prof_enable": (None, [C.c_int]),
     "hlvae_prof_report": (C.c_int, [C.c_char_p, C.c_int]),

@@ -542,13 +542,15 @@ __global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const 
 
 // every scalar of the bound in one launch (elbo_functions.py:268-285):
 //   out += c/2 [ sum(part) - sum(W o iK) + sum(Qm o W) - sum(log_var) ]
-//        + 1/2 [ sum(iK o H) + sum(m o iKm) + sum(ldK) - sum(ldH) ]          (+ konst from block 0)
+//        + rep { 1/2 [ sum(iK o H) + sum(m o iKm) + sum(ldK) - sum(ldH) ] + konst }
+// The first bracket is linear in per-subject sums: under data parallelism every rank passes its LOCAL part / W / lv and
+// rep = 1 / world for the replicated terms; the sum of the ranks' results is the bound of the global batch.
 __global__ __launch_bounds__(256) void k_gp_bound(const double* __restrict__ part, int n_part, const double* __restrict__ W,
                                                   const double* __restrict__ iK, const double* __restrict__ Qm,
                                                   const double* __restrict__ H, int LMM, const double* __restrict__ m,
                                                   const double* __restrict__ iKm, int LM, const double* __restrict__ ldK,
                                                   const double* __restrict__ ldH, int L, const float* __restrict__ lv, int BL,
-                                                  double c, double konst, double* __restrict__ out) {
+                                                  double c, double rep, double konst, double* __restrict__ out) {
     __shared__ double red[2][4];
     const int g = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
     double ac = 0.0, au = 0.0;
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(256) void k_gp_bound(const double* __restrict__ par
     __syncthreads();
     if (threadIdx.x == 0) {
         const double sc = red[0][0] + red[0][1] + red[0][2] + red[0][3], su = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        atomicAdd(out, 0.5 * c * sc + 0.5 * su + (blockIdx.x == 0 ? konst : 0.0));
+        atomicAdd(out, 0.5 * c * sc + rep * (0.5 * su + (blockIdx.x == 0 ? konst : 0.0)));
     }
 }
 
@@ -705,13 +707,13 @@ int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots
 
 int hlvae_gp_bound(const double* part, int S, const double* W, const double* iK, const double* Qm, const double* H,
                    const double* m, const double* iKm, const double* ldK, const double* ldH, const float* lv, int B, int L,
-                   int M, double c, double n_total, double* out, hlvae_stream s) {
+                   int M, double c, double n_total, double rep, double* out, hlvae_stream s) {
     HL_REQUIRE(part && W && iK && Qm && H && m && iKm && ldK && ldH && lv && out, HLVAE_EINVAL, "gp_bound: null pointer");
     HL_CHECK(hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)s));
     const double konst = -0.5 * (double)L * M - 0.5 * (double)L * n_total;
     HL_PROF("gp_bound", (hipStream_t)s);
     k_gp_bound<<<128, 256, 0, (hipStream_t)s>>>(part, S * L * 4, W, iK, Qm, H, L * M * M, m, iKm, L * M, ldK, ldH, L, lv, B * L, c,
-                                              konst, out);
+                                              rep, konst, out);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -700,7 +700,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
     }
     HL_LAUNCH_CHECK();
     HL_PROF("elbo_finalize", s);
-    k_elbo_finalize<<<1, 1024, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal, ws->klpart, Bp / 64, ws->rng);
+    k_elbo_finalize<<<1, 1024, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal, ws->klpart, Bp / 16, ws->rng);       // one partial per 16-row tile of k_mid_fwd_fused
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -174,8 +174,7 @@ class GPPrior:
 
     def optimizer_step(self):
         if self.dp is not None:
-            raise NotImplementedError("GP prior under data parallelism needs the per-subject partial sums (A..E, P1, W) "
-                                      "all-reduced before the non-linear terms (SURVEY.md section 8(e) caveat 2): next round")
+            raise NotImplementedError("the torch statement of the GP prior is single-process; data parallel: GPPriorHIP(dp=...)")
         self.opt.step()
         self.m, self.H = natural_gradient_step(self.m, self.H, self._grad_m, self._grad_H, self.ng_lr)
 
@@ -237,14 +236,21 @@ class GPPriorHIP:
     rules as ``GPPrior``; hyper-parameters are one fp64 tensor ``prm`` [rows, L] of RAW values (row order: terms of the
     id-free kernel then of the id kernel, each: scale, then its RBF lengthscales).  ``prm`` and ``zt_list`` are views of
     one flat arena that a single fused Adam kernel updates; every buffer of a step is preallocated, so the step can be
-    captured in a HIP graph."""
+    captured in a HIP graph.
+
+    Data parallel (``dp`` = hlvae_amd.parallel.DataParallel; whole subjects per rank, SURVEY.md section 8(e) caveat 2):
+    hyper-parameters, inducing points, m, H are replicated; each rank evaluates its subjects; the bound is linear in the
+    per-subject sums W = sum Ks^T iB Ks, P1 = sum Ks^T iB mu_s, u = sum Ks^T iB a_s, so ONE all-reduce of the packed
+    [W | P1 | u | bound] buffer (L M^2 fp64, 3.7 MB at L=32, M=120) before the non-linear terms, and one of the small
+    hyper-parameter gradient arena, reproduce the single-process step; the M x M inversions are replicated work."""
 
     def __init__(self, latent_dim, train_x, M, id_covariate, N_total, cat_kernel=(2,), bin_kernel=(), sqexp_kernel=(0,),
                  cat_int_kernel=({"cont_covariate": 0, "cat_covariate": 2}, {"cont_covariate": 0, "cat_covariate": 3},
                                  {"cont_covariate": 1, "cat_covariate": 4}),
-                 bin_int_kernel=(), covariate_missing_val=(), natural_gradient_lr=0.01, lr=1e-3, eps=1e-6, seed=0):
+                 bin_int_kernel=(), covariate_missing_val=(), natural_gradient_lr=0.01, lr=1e-3, eps=1e-6, seed=0, dp=None):
         import math
         dev = train_x.device
+        self.dp = dp
         if dev.type != "cuda":
             raise RuntimeError("GPPriorHIP runs on the GPU only (no CPU fallback); GPPrior is the device-independent statement")
         self.L, self.M, self.id_covariate, self.N_total, self.eps, self.ng_lr = latent_dim, M, id_covariate, N_total, eps, natural_gradient_lr
@@ -281,15 +287,19 @@ class GPPriorHIP:
         self.H.copy_(Hh @ Hh.transpose(-1, -2) + 1e-6 * torch.eye(M, **f64))
         self.noise = torch.ones(L, **f64)                                                           # HLVAE_main.py:211-213
         self.fail = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.last_kld = torch.zeros(1, **f64)
+        self._xchg = torch.zeros(L * M * M + 2 * L * M + 1, **f64)    # [W | P1 | u | bound]: the one DP exchange buffer
+        self.last_kld = self._xchg[-1:]
         self._groups = {}
         self._grad_m = self._grad_H = self._iH = None
+        if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
+            for t in (self._theta, self.m, self._KH):
+                dp.broadcast_(t)
         self._transform()
 
     @classmethod
-    def from_reference_config(cls, model, src, P_total, dev, M=120):
+    def from_reference_config(cls, model, src, P_total, dev, M=120, dp=None):
         train_x = torch.tensor(src.labels, dtype=torch.float64, device=dev)
-        return cls(model.z_dim, train_x, min(M, train_x.shape[0]), src.id_covariate, N_total=train_x.shape[0])
+        return cls(model.z_dim, train_x, min(M, train_x.shape[0]), src.id_covariate, N_total=train_x.shape[0], dp=dp)
 
     # ---- thin wrappers over the C ABI ---------------------------------------------------------------------------
     def _stream(self):
@@ -360,28 +370,39 @@ class GPPriorHIP:
                                             _lib.ptr(lv32), _C.c_double(c), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
                                             _lib.ptr(part), _lib.ptr(g_mu), _lib.ptr(g_lv), st), "gp_subject_fwd")
         KxzT = Kxz.transpose(1, 2)
-        W = KxzT @ V                                                         # sum_s Ks^T iB Ks   [L,M,M]
+        LMM, LM = L * M * M, L * M
+        W = self._xchg[:LMM].view(L, M, M)
+        P1 = self._xchg[LMM:LMM + LM].view(L, M, 1)
+        u = self._xchg[LMM + LM:LMM + 2 * LM].view(L, M, 1)
+        torch.bmm(KxzT, V, out=W)                                            # sum_s Ks^T iB Ks   [L,M,M]
+        torch.bmm(V.transpose(1, 2), mu64.t().unsqueeze(2), out=P1)          # natural-gradient term (elbo_functions.py:262-266)
+        torch.bmm(KxzT, v.unsqueeze(2), out=u)
         HiK = self.H @ iK
         Qm = iK @ HiK                                                        # iK H iK
+        world = 1 if self.dp is None else self.dp.world
         _lib.check(lib.hlvae_gp_bound(_lib.ptr(part), S, _lib.ptr(W), _lib.ptr(iK), _lib.ptr(Qm), _lib.ptr(self.H), _lib.ptr(self.m),
                                       _lib.ptr(iKm), _lib.ptr(ldK), _lib.ptr(ldH), _lib.ptr(lv32), B, L, M, _C.c_double(c),
-                                      _C.c_double(float(self.N_total)), _lib.ptr(self.last_kld), st), "gp_bound")
-        # natural-gradient terms (elbo_functions.py:262-266, 279-283)
-        P1 = V.transpose(1, 2) @ mu64.t().unsqueeze(2)                       # [L,M,1]
+                                      _C.c_double(float(self.N_total)), _C.c_double(1.0 / world), _lib.ptr(self.last_kld), st),
+                   "gp_bound")
+        if self.dp is not None:
+            self.dp.allreduce_(self._xchg)                                   # W, P1, u, bound of the GLOBAL batch
+        # natural-gradient terms (elbo_functions.py:279-283)
         Bm = torch.baddbmm(iK, iK @ W, iK)                                   # iK W iK + iK
         self._grad_m = torch.baddbmm(Bm @ self.m, iK, P1, alpha=-1.0)        # -(iK P1) + Bm m
         self._grad_H = 0.5 * (Bm - iH)
         # analytic gradients w.r.t. kernel matrices, chained into hyper-parameters / inducing points by the HIP kernels
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
-        Y = V @ (iK - Qm)                                                    # [L,B,M]
+        Y = V @ (iK - Qm)                                                    # [L,B,M]  (local rows)
         G_Kxz = torch.baddbmm(Y, v.unsqueeze(2), iKm.transpose(1, 2), beta=-c, alpha=c)   # c [ v (iK m)^T + V (Q - iK) ]
-        u = KxzT @ v.unsqueeze(2)                                            # [L,M,1]
         HiKW = HiK @ W
         mT = self.m.transpose(1, 2)
-        # R + R^T with R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T): K0zz's gradient is needed symmetrised
+        # R + R^T with R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T): K0zz's gradient is needed symmetrised.
+        # It is built from global sums only, i.e. replicated: each rank contributes 1 / world of it
         um = u @ mT
         Rs = c * (um + um.transpose(1, 2) - W + HiKW + HiKW.transpose(1, 2)) + torch.baddbmm(self.H, self.m, mT)
         G_Kzz_s = torch.baddbmm(iK, iK @ Rs, iK, alpha=-1.0)                 # (G + G^T),  G = -(iK R iK) + iK / 2
+        if world > 1:
+            G_Kzz_s = G_Kzz_s / world
         _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
                                             S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y),
                                             _lib.ptr(lv32), _C.c_double(c), _lib.ptr(gprm), st), "gp_subject_bwd")
@@ -389,6 +410,8 @@ class GPPriorHIP:
                                            _lib.ptr(G_Kxz), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kxz)")
         _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
                                            _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
+        if self.dp is not None:
+            self.dp.allreduce_(self._gtheta)
         return g_mu, g_lv
 
     def optimizer_step(self):

@@ -36,6 +36,11 @@ class DataParallel:
         stream); ``.wait()`` on the returned handle makes the current stream wait for the result"""
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def broadcast_(self, t: torch.Tensor, src: int = 0):
+        """replicated state (GP hyper-parameters, inducing points, m, H) starts identical on every rank"""
+        dist.broadcast(t, src=dist.get_global_rank(self.group, src) if self.group is not dist.group.WORLD else src, group=self.group)
+        return t
+
     def allreduce_(self, t: torch.Tensor):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 9
+#define HLVAE_ABI_VERSION 10
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -101,7 +101,7 @@ typedef struct {
     float* rowpart;      /* [ceil(D/16)][Bp] partial row sums of log_p_x                    */
     float* nll;          /* [Bp]  -sum_d log_p_x                                            */
     double* scal;        /* [8]: 0 = sum_b nll, 1 = KL(q || N(0,I)) of the batch (extension), 2.. reserved */
-    double* klpart;      /* [Bp/64] per-block KL partial sums                                */
+    double* klpart;      /* [Bp/16] per-tile KL partial sums (k_mid_fwd_fused)               */
     float* eps;          /* [Bp][L] reparameterisation noise actually used (kept for backward) */
     uint64_t* rng;       /* [2]: Philox seed, offset (advanced by one per step on device)    */
     float* pfull;        /* [Bp][X]  likelihood parameters concatenated by key (row M), optional */
@@ -234,10 +234,12 @@ int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots
                         hlvae_stream s);
 /* all scalar reductions of the bound (elbo_functions.py:268-285) into *out (device double):
  *   c/2 [sum(part) - sum(W o iK) + sum(Qm o W) - sum(log_var)] + 1/2 [sum(iK o H) + m.iKm - L M + sum ldK - sum ldH] - L N/2
- * W = sum_s Ks^T iB Ks, Qm = iK H iK, all [L][M][M]; m, iKm [L][M]; ldK, ldH [L]; lv fp32 [B][L]. */
+ * W = sum_s Ks^T iB Ks, Qm = iK H iK, all [L][M][M]; m, iKm [L][M]; ldK, ldH [L]; lv fp32 [B][L].
+ * rep scales the second bracket and the constant: 1 in a single process; 1 / world under data parallelism, where every
+ * rank passes its local part / W / lv and the bound of the global batch is the SUM of the ranks' results. */
 int hlvae_gp_bound(const double* part, int S, const double* W, const double* iK, const double* Qm, const double* H,
                    const double* m, const double* iKm, const double* ldK, const double* ldH, const float* lv, int B, int L,
-                   int M, double c, double n_total, double* out, hlvae_stream s);
+                   int M, double c, double n_total, double rep, double* out, hlvae_stream s);
 /* torch.optim.Adam step (HLVAE_main.py:277-278) on a flat fp64 arena (hyper-parameters + inducing points, n <= ~1e5);
  * step: device int64[2] = {completed steps, 0}, advanced by the kernel; the consumed gradients are zeroed. */
 int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,

@@ -442,6 +442,10 @@ def test_ragged_batch_sizes_against_oracle(B):
         return
     assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
     assert max_abs_err(out[1], ref["mu"]) < 3e-2
+    # the device-side KL(q || N(0, I)) scalar (one partial per 16-row tile) against the same sum over the device mu / log_var
+    kl_dev = float(model._ws_t["scal"][1])
+    kl_sum = float(-0.5 * torch.sum(1.0 + out[2].double() - out[1].double() ** 2 - torch.exp(out[2].double())))
+    assert abs(kl_dev - kl_sum) <= 1e-5 * abs(kl_sum) + 1e-6, (kl_dev, kl_sum)
     e = np.abs(out[3].detach().double().cpu().numpy() - ref["log_p_x"].detach().numpy())
     assert np.all(e <= 5e-2 + 3e-2 * np.abs(ref["log_p_x"].detach().numpy()))
     sd = dict(model.named_parameters())
