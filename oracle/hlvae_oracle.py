@@ -42,7 +42,10 @@ def block_indices(types_info):
     return out
 
 
-def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.05, dtype=DT) -> Dict[str, torch.Tensor]:
+CONV_FEATURES = 32 * 9 * 9                                               # HLVAE.py:155
+
+
+def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.05, dtype=DT, conv=False) -> Dict[str, torch.Tensor]:
     """Deterministic parameter set with the reference's shapes, key names and init
     distributions (row P: HLVAE.py:109-281 -- N(0, 0.05^2) everywhere, thresholds = 1,
     _log_vy = log(vy_init - e^-8), _disp_param = 1).  Uses its own generator, so the same
@@ -62,6 +65,17 @@ def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.
     st["_log_vy_pos"] = torch.log(vy_init[1] - torch.exp(min_log_vy)).to(dtype).repeat(pos_dim)
     st["_disp_param"] = torch.ones(1, dtype=dtype)
     n_in = x_dim
+    if conv:                                                             # HLVAE.py:139-155 (conv layers: torch default init
+        dti0 = np.asarray(types_info["data_types_indexes"])              #  in the reference; here N(0, 1/fan_in), own generator)
+        j = 0
+        for i, tpl in enumerate(types_info["set_of_types"]):
+            if tpl[0] in ("cat", "ordinal"):
+                n = int(np.sum(dti0 == i))
+                st[f"representation_layer.{j}.weight"], st[f"representation_layer.{j}.bias"] = nrm(n, int(tpl[1])), nrm(n)
+                j += 1
+        st["conv1.weight"], st["conv1.bias"] = nrm(16, 1, 3, 3) * (1 / 3.0 / std), nrm(16)
+        st["conv2.weight"], st["conv2.bias"] = nrm(32, 16, 3, 3) * (1 / 12.0 / std), nrm(32)
+        n_in = CONV_FEATURES
     for li, n_out in enumerate(h_e):                                     # HLVAE.py:128-135
         st[f"VAE_encoder_common_layers.{2 * li}.weight"] = nrm(n_out, n_in)
         st[f"VAE_encoder_common_layers.{2 * li}.bias"] = nrm(n_out)
@@ -74,7 +88,14 @@ def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.
         st[f"d_layers.{2 * li}.weight"], st[f"d_layers.{2 * li}.bias"] = w, b
         st[f"hidden.{2 * li}.weight"], st[f"hidden.{2 * li}.bias"] = w, b
         n_in = n_out
-    st["y_layer.0.weight"], st["y_layer.0.bias"] = nrm(y_dim * n_variables, n_in), nrm(y_dim * n_variables)
+    if conv:                                                             # HLVAE.py:244-259
+        st["y_layer.0.weight"], st["y_layer.0.bias"] = nrm(CONV_FEATURES, n_in), nrm(CONV_FEATURES)
+        w0, b0 = nrm(32, 16, 4, 4) * (1 / 16.0 / std), nrm(16)
+        w2, b2 = nrm(16, y_dim, 4, 4) * (1 / 8.0 / std), nrm(y_dim)
+        for pre in ("deconv_layer", "Decoder_Conv_layer"):               # the same modules registered twice
+            st[f"{pre}.0.weight"], st[f"{pre}.0.bias"], st[f"{pre}.2.weight"], st[f"{pre}.2.bias"] = w0, b0, w2, b2
+    else:
+        st["y_layer.0.weight"], st["y_layer.0.bias"] = nrm(y_dim * n_variables, n_in), nrm(y_dim * n_variables)
     dti = np.asarray(types_info["data_types_indexes"])
     for i, tpl in enumerate(types_info["set_of_types"]):                 # HLVAE.py:261-281
         n = int(np.sum(dti == i))
@@ -132,8 +153,9 @@ def batch_normalization(data, mask, blocks, conv=False, stats=None):
     return out, norm
 
 
-def heads(y_grouped, blocks, st, Theta):
-    """Row E value: theta = head(y) for EVERY entry (HLVAE.py:416-453; heads :11-89)."""
+def heads(y_grouped, blocks, st, Theta, conv=False):
+    """Row E value: theta = head(y) for EVERY entry (HLVAE.py:416-453; heads :11-89).
+    conv: the mean of a real variable goes through a sigmoid (HLVAE.py:271-273, 428-430)."""
     B = y_grouped.shape[0]
     theta = torch.zeros(B, Theta, dtype=y_grouped.dtype)
     for i, b in enumerate(blocks):
@@ -142,6 +164,8 @@ def heads(y_grouped, blocks, st, Theta):
             t = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight"]) + st[f"obs_layer.{i}.bias"]
         elif b["type"] in ("real", "pos"):
             t = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight_mean"]) + st[f"obs_layer.{i}.bias_mean"]
+            if conv and b["type"] == "real":
+                t = torch.sigmoid(t)
         elif b["type"] == "cat":
             t = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight"]) + st[f"obs_layer.{i}.bias"]
             t = torch.cat([torch.zeros(B, t.shape[1], 1, dtype=t.dtype), t], -1)        # HLVAE.py:66-67
@@ -153,8 +177,9 @@ def heads(y_grouped, blocks, st, Theta):
     return theta
 
 
-def loglik_blocks(theta, data, mask, blocks, st, norm, noise=None):
-    """Rows F-I + scatter of row J.  HL_VAE/loglik.py; HLVAE.py:381-414."""
+def loglik_blocks(theta, data, mask, blocks, st, norm, noise=None, conv=False):
+    """Rows F-I + scatter of row J.  HL_VAE/loglik.py; HLVAE.py:381-414.
+    conv: real data are scaled by 1/255 and carry no batch statistics (HLVAE.py:393-394; loglik.py:36-41)."""
     B, D = mask.shape
     log_p_x = torch.zeros(B, D, dtype=theta.dtype)
     log_p_x_missing = torch.zeros(B, D, dtype=theta.dtype)
@@ -165,7 +190,11 @@ def loglik_blocks(theta, data, mask, blocks, st, norm, noise=None):
         m = mask[:, b["var"]]
         K = b["K"]
         if b["type"] == "real":                                           # loglik.py:27-70
-            mean_d, var_d = norm[0]
+            if conv:
+                x = x / 255                                               # HLVAE.py:393-394
+                mean_d, var_d = torch.tensor(0.0, dtype=theta.dtype), torch.tensor(1.0, dtype=theta.dtype)   # loglik.py:40-41
+            else:
+                mean_d, var_d = norm[0]
             var_d = torch.clamp(var_d, 3e-4, np.inf)                      # :38
             log_vy = -8.0 + F.softplus(st["_log_vy_real"] + 8.0)          # :51
             est_var = var_d * torch.exp(log_vy)                           # :52,56
@@ -210,9 +239,10 @@ def loglik_blocks(theta, data, mask, blocks, st, norm, noise=None):
 
 
 class OracleHLVAE:
-    """Functional float64 restatement of reference HLVAE (conv=False, logvar_network=False)."""
+    """Functional float64 restatement of reference HLVAE (logvar_network=False; MLP or convolutional front/back end)."""
 
-    def __init__(self, dims, types_info, n_variables, state: Dict[str, torch.Tensor]):
+    def __init__(self, dims, types_info, n_variables, state: Dict[str, torch.Tensor], conv: bool = False):
+        self.conv = conv
         self.dims = dims
         self.x_dim, self.h_e, self.z_dim, h_d, self.y_dim = dims
         self.h_d = list(reversed(h_d))
@@ -223,8 +253,28 @@ class OracleHLVAE:
         self.st = state
 
     # ---- row B: HLVAE.py:311-324 (trunk evaluated once; the reference's two evaluations are identical)
-    def encode_params(self, X_list):
+    def conv_features(self, X_list, mask):
+        """HLVAE.py:293-308: learned one-number representation of every cat / ordinal variable, masked; the 1296 numbers
+        as a 36 x 36 image through 2 x (conv 3x3 + ReLU + max-pool 2)."""
+        one = torch.zeros_like(mask)
+        j = 0
+        for b in self.blocks:
+            if b["type"] in ("cat", "ordinal"):
+                rep = torch.einsum("bdc,dc->bd", X_list[:, b["exp"]].reshape(mask.shape[0], -1, b["K"]),
+                                   self.st[f"representation_layer.{j}.weight"]) + self.st[f"representation_layer.{j}.bias"]
+                j += 1
+            else:
+                rep = X_list[:, b["exp"]]
+            one[:, b["var"]] = rep * mask[:, b["var"]]
+        img = one.view(X_list.shape[0], 1, 36, 36)
+        z = F.max_pool2d(F.relu(F.conv2d(img, self.st["conv1.weight"], self.st["conv1.bias"], padding=1)), 2)
+        z = F.max_pool2d(F.relu(F.conv2d(z, self.st["conv2.weight"], self.st["conv2.bias"], padding=1)), 2)
+        return z.reshape(-1, CONV_FEATURES), img
+
+    def encode_params(self, X_list, mask=None):
         t = X_list
+        if self.conv:
+            t, _ = self.conv_features(X_list, mask)
         for li in range(len(self.h_e)):
             t = F.relu(F.linear(t, self.st[f"VAE_encoder_common_layers.{2 * li}.weight"],
                                 self.st[f"VAE_encoder_common_layers.{2 * li}.bias"]))
@@ -238,20 +288,26 @@ class OracleHLVAE:
         for li in range(len(self.h_d)):
             u = F.relu(F.linear(u, self.st[f"hidden.{2 * li}.weight"], self.st[f"hidden.{2 * li}.bias"]))
         y = F.linear(u, self.st["y_layer.0.weight"], self.st["y_layer.0.bias"])
-        y_grouped = y.reshape(y.shape[0], self.D, -1)                     # :343
-        theta = heads(y_grouped, self.blocks, self.st, self.Theta)
+        if self.conv:                                                     # :338-341
+            y = y.view(-1, 32, 9, 9)
+            y = F.relu(F.conv_transpose2d(y, self.st["deconv_layer.0.weight"], self.st["deconv_layer.0.bias"], stride=2, padding=1))
+            y = F.conv_transpose2d(y, self.st["deconv_layer.2.weight"], self.st["deconv_layer.2.bias"], stride=2, padding=1)
+            y_grouped = y.view(y.shape[0], y.shape[1], -1).permute(0, 2, 1)
+        else:
+            y_grouped = y.reshape(y.shape[0], self.D, -1)                 # :343
+        theta = heads(y_grouped, self.blocks, self.st, self.Theta, conv=self.conv)
         # stop-gradient through missing entries (HLVAE.py:435-452): same value, gradient only where observed
         pm = torch.zeros_like(theta)
         for b in self.blocks:
             pm[:, b["par"]] = mask[:, b["var"]].repeat_interleave(b["K"], dim=1)
         theta = pm * theta + (1.0 - pm) * theta.detach()
-        log_p_x, log_p_x_missing, params = loglik_blocks(theta, data, mask, self.blocks, self.st, norm)
+        log_p_x, log_p_x_missing, params = loglik_blocks(theta, data, mask, self.blocks, self.st, norm, conv=self.conv)
         return log_p_x, log_p_x_missing, params, theta
 
     def forward(self, data, mask, eps, stats=None):
         """HLVAE.forward (HLVAE.py:364-375) with explicit noise.  Returns a dict."""
-        X_list, norm = batch_normalization(data, mask, self.blocks, conv=False, stats=stats)
-        mu, lv = self.encode_params(X_list)
+        X_list, norm = batch_normalization(data, mask, self.blocks, conv=self.conv, stats=stats)
+        mu, lv = self.encode_params(X_list, mask)
         z = mu + eps * torch.exp(0.5 * lv)                                # row C: HLVAE.py:360-362
         log_p_x, log_p_x_missing, params, theta = self.decode(z, data, mask, norm)
         return dict(X_list=X_list, norm=norm, mu=mu, log_var=lv, z=z, log_p_x=log_p_x,
@@ -260,8 +316,8 @@ class OracleHLVAE:
     def test_samples(self, data, mask):
         """Row T: get_test_samples (HLVAE.py:455-475): deterministic encode -> decode(mu)."""
         with torch.no_grad():
-            X_list, norm = batch_normalization(data, mask, self.blocks, conv=False)
-            mu, lv = self.encode_params(X_list)
+            X_list, norm = batch_normalization(data, mask, self.blocks, conv=self.conv)
+            mu, lv = self.encode_params(X_list, mask)
             log_p_x, log_p_x_missing, params, theta = self.decode(mu, data, mask, norm)
         return dict(mu=mu, log_var=lv, log_p_x=log_p_x, log_p_x_missing=log_p_x_missing, p_params=params)
 

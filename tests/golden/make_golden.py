@@ -67,11 +67,11 @@ MIX_SPEC = [("real", 1), ("cat", 3), ("pos", 1), ("ordinal", 4), ("count", 1), (
             ("ordinal", 5), ("pos", 1), ("cat", 5), ("count", 1), ("cat", 3), ("real", 1), ("ordinal", 4)]
 
 
-def run_reference_model(src, rows, dims, state, seed, nll_scale):
+def run_reference_model(src, rows, dims, state, seed, nll_scale, conv=False):
     """reference forward + loss + backward; returns dict of arrays."""
-    info = src.types_info
+    info = dict(src.types_info, conv=conv)
     model = ref_hlvae.HLVAE(dims, info, src.n_variables, vy_init=[1.0, 0.5], logvar_network=False,
-                            conv=False).to(T64)
+                            conv=conv).to(T64)
     missing = model.load_state_dict(state, strict=True)
     model = model.double()
     data = torch.tensor(src.data[rows], dtype=T64)
@@ -157,6 +157,36 @@ def case_d4():
     out["dims"] = np.array([dims[0], 32, 8, 32, 5])
     np.savez_compressed(os.path.join(HERE, "d4_small.npz"), **out)
     print("d4_small loss", out["loss"])
+
+
+def case_d4_conv():
+    """the convolutional front/back end the shipped configuration selects (config/hlvae_config_file.txt:51; HLVAE.py:139-152,
+    253-259, 293-308, 338-341, 428-430; HL_VAE/utils.py:99-102; loglik.py:36-41)"""
+    src = synthetic.make_d4(n_subjects=2, T=4, seed=5)
+    dims = [src.cov_dim_ext, [32], 8, [32], 5]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=13, std=0.05, conv=True)
+    out, grads = run_reference_model(src, np.arange(8), dims, state, seed=23, nll_scale=2.5, conv=True)
+    out["data_argsum"] = np.array([out["data"].sum(), (out["data"] * np.arange(out["data"].shape[1])).sum()])
+    del out["data"]
+    out["state_checksum"] = state_checksum(state)
+    small = ("mean_layer.0.weight", "mean_layer.0.bias", "log_var_layer.0.bias", "d_layers.0.bias", "_log_vy_real",
+             "obs_layer.0.bias", "obs_layer.1.bias_mean", "obs_layer.1.weight_mean", "VAE_encoder_common_layers.0.bias",
+             "conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "deconv_layer.0.weight", "deconv_layer.0.bias",
+             "deconv_layer.2.weight", "deconv_layer.2.bias", "representation_layer.0.weight", "representation_layer.0.bias",
+             "y_layer.0.bias")
+    for k in small:
+        out["grad__" + k] = np64(grads[k])
+    out["grad_slice__y_layer.0.weight"] = np64(grads["y_layer.0.weight"][:40])
+    out["grad_slice__VAE_encoder_common_layers.0.weight"] = np64(grads["VAE_encoder_common_layers.0.weight"][:, :64])
+    out["grad_slice__obs_layer.0.weight"] = np64(grads["obs_layer.0.weight"][:50])
+    out["grad_norms"] = np.array([float(grads[k].norm()) for k in sorted(grads)])
+    out["grad_names"] = np.array(sorted(grads))
+    for k in list(out):
+        if k.startswith("p_params") or k.startswith("test_p_params") or k in ("p_params_full",):
+            out[k] = out[k][:, :200] if out[k].ndim == 2 else out[k][:, :40]
+    out["dims"] = np.array([dims[0], 32, 8, 32, 5])
+    np.savez_compressed(os.path.join(HERE, "d4_conv_small.npz"), **out)
+    print("d4_conv_small loss", out["loss"])
 
 
 def case_types_info():
@@ -293,4 +323,5 @@ if __name__ == "__main__":
     case_mix("mix_init", seed_state=1, std=0.05, nll_scale=1.7)
     case_mix("mix_trained", seed_state=2, std=0.3, nll_scale=0.4)
     case_d4()
+    case_d4_conv()
     case_gp()
