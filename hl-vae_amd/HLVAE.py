@@ -64,6 +64,13 @@ class Observation_Ordinal(nn.Module):                    # reference HLVAE.py:70
         self.weight_thresholds = nn.Parameter(torch.empty(n, nclass - 1))
 
 
+class Representation_One_Hot(nn.Module):                 # reference HLVAE.py:91-102 (conv encoder input)
+    def __init__(self, n, nclass):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, nclass))
+        self.bias = nn.Parameter(torch.empty(n))
+
+
 class _Anchor(torch.autograd.Function):
     """Connects the HIP forward/backward to autograd.  The only differentiable input is a dummy
     anchor; backward() runs the HIP backward and assigns ``p.grad`` views of the gradient arena."""
@@ -93,15 +100,15 @@ class _Anchor(torch.autograd.Function):
 
 
 class HLVAE(nn.Module):
-    """Heterogeneous longitudinal VAE, MLP encoder/decoder, HIP hot path (see module docstring)."""
+    """Heterogeneous longitudinal VAE, MLP or convolutional encoder/decoder, HIP hot path (see module docstring)."""
 
     def __init__(self, dims, types_info, n_variables, vy_init=[1., .5], vy_fixed=False, logvar_network=False,
                  conv=True, max_batch=512, materialize_samples=True):
         super().__init__()
         [x_dim, h_dim_e, z_dim, h_dim_d, y_dim] = dims
-        if conv:
-            raise NotImplementedError("conv=True (convolutional front/back end, reference HLVAE.py:139-152) is outside "
-                                      "the MLP hot path built here; construct with conv=False")
+        if conv and (n_variables != 36 * 36 or y_dim != 5):
+            raise ValueError("conv=True views the variables as one 36 x 36 image with y_dim = 5 output channels "
+                             "(reference HLVAE.py:305, 257-258)")
         if logvar_network:
             raise NotImplementedError("logvar_network=True is outside the hot path (SURVEY.md section 8)")
         if not (isinstance(h_dim_e, (list, tuple)) and len(h_dim_e) == 1 and isinstance(h_dim_d, (list, tuple))
@@ -123,7 +130,23 @@ class HLVAE(nn.Module):
         self.real_dim, self.pos_dim = pl.n_real, pl.n_pos
 
         # ---- modules with the reference's names (state_dict keys) ------------------------------
-        self.VAE_encoder_common_layers = nn.Sequential(nn.Linear(x_dim, self.h_e), nn.ReLU())
+        conv_params: List[nn.Parameter] = []
+        if conv:                                                                     # HLVAE.py:139-155
+            self.representation_layer = nn.ModuleList()
+            self._rep_of_block = {}
+            for bi_, b in enumerate(pl.blocks):
+                if b["type"] in ("cat", "ordinal"):
+                    self._rep_of_block[bi_] = len(self.representation_layer)
+                    self.representation_layer.append(Representation_One_Hot(b["n_vars"], b["nclass"]))
+            self.conv1 = nn.Conv2d(1, 16, kernel_size=3, stride=1, padding=1)        # parameter containers: the compute is
+            self.pool1 = nn.MaxPool2d(kernel_size=2, stride=2, padding=0)            # csrc/conv.hip
+            self.conv2 = nn.Conv2d(16, 32, kernel_size=3, stride=1, padding=1)
+            self.pool2 = nn.MaxPool2d(kernel_size=2, stride=2, padding=0)
+            conv_params += [self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias]
+            x_enc = _lib.CONV_FEATURES
+        else:
+            x_enc = x_dim
+        self.VAE_encoder_common_layers = nn.Sequential(nn.Linear(x_enc, self.h_e), nn.ReLU())
         self.mean_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
         self.log_var_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
         self._log_vy_real = nn.Parameter(torch.empty(pl.n_real))
@@ -131,7 +154,13 @@ class HLVAE(nn.Module):
         self._disp_param = nn.Parameter(torch.ones(1))
         self.d_layers = nn.ModuleList([nn.Linear(z_dim, self.h_d), nn.ReLU()])
         self.hidden = nn.Sequential(*self.d_layers)                                  # alias, HLVAE.py:242
-        self.y_layer = nn.Sequential(nn.Linear(self.h_d, y_dim * n_variables))
+        self.y_layer = nn.Sequential(nn.Linear(self.h_d, _lib.CONV_FEATURES if conv else y_dim * n_variables))   # HLVAE.py:244-248
+        if conv:                                                                     # HLVAE.py:253-259
+            self.deconv_layer = nn.ModuleList([nn.ConvTranspose2d(32, 16, kernel_size=4, stride=2, padding=1), nn.ReLU(),
+                                               nn.ConvTranspose2d(16, y_dim, kernel_size=4, stride=2, padding=1)])
+            self.Decoder_Conv_layer = nn.Sequential(*self.deconv_layer)
+            conv_params += [self.deconv_layer[0].weight, self.deconv_layer[0].bias, self.deconv_layer[2].weight,
+                            self.deconv_layer[2].bias]
         self.obs_layer = nn.ModuleList()
         for b in pl.blocks:
             n, K = b["n_vars"], b["nclass"]
@@ -143,11 +172,17 @@ class HLVAE(nn.Module):
                 self.obs_layer.append(Observation_Cat(n, y_dim, K))
             else:
                 self.obs_layer.append(Observation_Ordinal(n, y_dim, K))
+        if conv and pl.n_real:
+            self.obs_layer.append(nn.Sigmoid())                                      # HLVAE.py:271-273 ('real' sorts last)
 
         # ---- flat arena: [atomically accumulated grads | dense weights] -------------------------
         order: List[nn.Parameter] = [self._log_vy_real, self._log_vy_pos, self._disp_param]
         for m in self.obs_layer:
             order += list(m.parameters())
+        if conv:      # small tensors whose gradients are accumulated with atomics by the convolution kernels
+            for m in self.representation_layer:
+                order += [m.weight, m.bias]
+            order += conv_params
         order += [self.y_layer[0].bias, self.d_layers[0].bias, self.mean_layer[0].bias, self.log_var_layer[0].bias,
                   self.VAE_encoder_common_layers[0].bias]
         n_small = len(order)
@@ -163,8 +198,12 @@ class HLVAE(nn.Module):
         self._offsets = offs
         self._arena_size = _ru(o, 64)
         arena = torch.zeros(self._arena_size, dtype=torch.float32)
+        conv_init = [p.detach().clone() for p in conv_params]       # torch's default initialisation, as in the reference
         self._bind_arena(arena)
         self._init_parameters(vy_init)
+        with torch.no_grad():
+            for p_, v_ in zip(conv_params, conv_init):
+                p_.copy_(v_)
         if vy_fixed:
             self._log_vy_real.requires_grad_(False)
             self._log_vy_pos.requires_grad_(False)
@@ -249,7 +288,12 @@ class HLVAE(nn.Module):
         d = _lib.HlvaeDims()
         d.D, d.X, d.y_dim, d.h_e, d.h_d, d.L = pl.D, pl.X, self.y_dim, self.h_e, self.h_d, self.z_dim
         d.n_real, d.n_pos = pl.n_real, pl.n_pos
+        d.conv = int(bool(self.conv))
         ao = self.arena_offset
+        if self.conv:
+            d.o_c1w, d.o_c1b, d.o_c2w, d.o_c2b = ao(self.conv1.weight), ao(self.conv1.bias), ao(self.conv2.weight), ao(self.conv2.bias)
+            d.o_t1w, d.o_t1b = ao(self.deconv_layer[0].weight), ao(self.deconv_layer[0].bias)
+            d.o_t2w, d.o_t2b = ao(self.deconv_layer[2].weight), ao(self.deconv_layer[2].bias)
         d.o_w1, d.o_b1 = ao(self.VAE_encoder_common_layers[0].weight), ao(self.VAE_encoder_common_layers[0].bias)
         d.o_wmu, d.o_bmu = ao(self.mean_layer[0].weight), ao(self.mean_layer[0].bias)
         d.o_wlv, d.o_blv = ao(self.log_var_layer[0].weight), ao(self.log_var_layer[0].bias)
@@ -269,6 +313,10 @@ class HLVAE(nn.Module):
             kind, K, bi = int(pl.kind[d]), int(pl.ncls[d]), int(pl.bidx[d])
             m = self.obs_layer[int(pl.blk[d])]
             v.kind, v.ncls, v.xoff, v.sidx, v.e_off, v.pad = kind, K, int(pl.xoff[d]), -1, -1, 0
+            v.r_off = v.rb_off = -1
+            if self.conv and kind in (KIND_CAT, KIND_ORDINAL):
+                rep = self.representation_layer[self._rep_of_block[int(pl.blk[d])]]
+                v.r_off, v.rb_off = ao(rep.weight) + bi * K, ao(rep.bias) + bi
             if kind in (KIND_REAL, KIND_POS):
                 v.w_off, v.b_off = ao(m.weight_mean) + bi * self.y_dim, ao(m.bias_mean) + bi
                 si = int(pl.sidx[d])
@@ -302,7 +350,7 @@ class HLVAE(nn.Module):
         d, dev = self._dims, self.device
         bf, f32 = torch.bfloat16, torch.float32
         z = lambda *s, dt=bf: torch.zeros(*s, dtype=dt, device=dev)
-        ksteps_e, ksteps_d = d.Xp // 64, d.NYp // 64
+        ksteps_e, ksteps_d = d.Xep // 64, d.NYlp // 64
         # split-K: a multiple of 8 slices when K allows it (one K-slice per XCD: each slice of the operands is pulled
         # into exactly one L2), enough blocks for about two waves of the 256 CUs, and no empty split
         def pick(ksteps, tiles):
@@ -316,10 +364,10 @@ class HLVAE(nn.Module):
         NT = (d.D + 15) // 16
         t = dict(
             G=z(self._arena_size, dt=f32),
-            w1s=z(d.hep, d.Xp), wmls=z(2 * d.Lp, d.hep), wmlTs=z(d.hep, 2 * d.Lp), wds=z(d.hdp, d.Lp),
-            wdTs=z(d.Lp, d.hdp), wys=z(d.NY, d.hdp), wyTs=z(d.hdp, d.NYp),
+            w1s=z(d.hep, d.Xep), wmls=z(2 * d.Lp, d.hep), wmlTs=z(d.hep, 2 * d.Lp), wds=z(d.hdp, d.Lp),
+            wdTs=z(d.Lp, d.hdp), wys=z(d.NYlp if d.conv else d.NYl, d.hdp), wyTs=z(d.hdp, d.NYlp),
             sums=z(_lib.STAT_CHUNKS, 3, max(d.n_stat, 1), dt=torch.float64), norm=z(2, max(d.n_stat, 1), dt=f32),
-            xn=z(Bp, d.Xp), xnT=z(d.Xp, Bp), xt=z(Bp, d.D, dt=f32), m8=z(Bp, d.D, dt=torch.uint8),
+            xn=z(Bp, d.Xep), xnT=z(d.Xep, Bp), xt=z(Bp, d.D, dt=f32), m8=z(Bp, d.D, dt=torch.uint8),
             slab=z(max(S_e, S_d), Bp, max(d.hep, d.hdp), dt=f32),
             t=z(Bp, d.hep), tT=z(d.hep, Bp), mu=z(Bp, d.L, dt=f32), lv=z(Bp, d.L, dt=f32), z=z(Bp, d.L, dt=f32),
             zb=z(Bp, d.Lp), zbT=z(d.Lp, Bp), u=z(Bp, d.hdp), uT=z(d.hdp, Bp), dy=z(Bp, d.NYp), dyT=z(d.NY, Bp),
@@ -329,18 +377,23 @@ class HLVAE(nn.Module):
             metpart=z(16, 6, d.D, dt=f32),
             du=z(Bp, d.hdp), duT=z(d.hdp, Bp), dz=z(Bp, d.Lp, dt=f32), dml=z(Bp, 2 * d.Lp), dmlT=z(2 * d.Lp, Bp),
             dt=z(Bp, d.hep), dtT=z(d.hep, Bp))
+        if d.conv:          # convolutional front / back end (csrc/conv.hip)
+            t.update(w1Ts=z(d.Xep, d.hep), cpack=z(_lib.CONV_PACK_ELEMS), img=z(Bp, d.D, dt=f32), yc=z(Bp, d.NYlp),
+                     a2=z(Bp, 18 * 18 * 16), yv=z(Bp, d.NY, dt=f32), da2=z(Bp, 18 * 18 * 16), dyc=z(Bp, d.NYlp),
+                     dycT=z(d.NYl, Bp), dfeat=z(Bp, d.Xep, dt=f32))
         t["P"] = self._arena
         t["rng"][0] = int(torch.randint(0, 2 ** 62, (1,)).item())          # Philox seed from torch's global RNG
         ws = _lib.HlvaeWs()
         ws.Bp_max, ws.splitk_enc, ws.splitk_dec = Bp, S_e, S_d
         for name in _lib.WS_POINTERS:
-            setattr(ws, name, t[name].data_ptr())
+            setattr(ws, name, t[name].data_ptr() if name in t else None)
         # second set of the input-stage buffers (statistics + packed batch): the next batch can be normalised and packed
         # on a side stream while this one trains (ELBOTrainer.step(prefetch=...)); everything else is shared
-        alt = {n: torch.zeros_like(t[n]) for n in _INPUT_STAGE}
+        self._input_stage = _INPUT_STAGE + (("img",) if d.conv else ())
+        alt = {n: torch.zeros_like(t[n]) for n in self._input_stage}
         ws2 = _lib.HlvaeWs()
         C.memmove(C.byref(ws2), C.byref(ws), C.sizeof(ws))
-        for n in _INPUT_STAGE:
+        for n in self._input_stage:
             setattr(ws2, n, alt[n].data_ptr())
         self._ws_alt, self._ws_t_alt = ws2, alt
         self._packed_key = None
@@ -351,7 +404,7 @@ class HLVAE(nn.Module):
     def _swap_input_buffers(self):
         """exchange the two sets of input-stage buffers (host-side pointer swap)"""
         self._ws, self._ws_alt = self._ws_alt, self._ws
-        for n in _INPUT_STAGE:
+        for n in self._input_stage:
             self._ws_t[n], self._ws_t_alt[n] = self._ws_t_alt[n], self._ws_t[n]
 
     def _stream(self):

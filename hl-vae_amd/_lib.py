@@ -10,26 +10,30 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
 
 
 class HlvaeVar(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("kind", "ncls", "xoff", "sidx", "w_off", "b_off", "e_off", "pad")]
+    _fields_ = [(n, C.c_int32) for n in ("kind", "ncls", "xoff", "sidx", "w_off", "b_off", "e_off", "r_off", "rb_off", "pad")]
 
 
 class HlvaeDims(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ("D", "X", "y_dim", "h_e", "h_d", "L", "n_real", "n_pos",
-                                            "Xp", "hep", "hdp", "Lp", "NY", "NYp", "n_stat")]
+    _fields_ = ([(n, C.c_int32) for n in ("D", "X", "y_dim", "h_e", "h_d", "L", "n_real", "n_pos", "conv",
+                                            "Xp", "hep", "hdp", "Lp", "NY", "NYp", "n_stat", "Xe", "Xep", "NYl", "NYlp")]
                 + [(n, C.c_int64) for n in ("o_w1", "o_b1", "o_wmu", "o_bmu", "o_wlv", "o_blv", "o_wd", "o_bd",
-                                            "o_wy", "o_by", "arena_size", "atomic_region")])
+                                            "o_wy", "o_by", "o_c1w", "o_c1b", "o_c2w", "o_c2b", "o_t1w", "o_t1b", "o_t2w", "o_t2b",
+                                            "arena_size", "atomic_region")])
 
 
 WS_POINTERS = ("P", "G", "w1s", "wmls", "wmlTs", "wds", "wdTs", "wys", "wyTs", "sums", "norm", "xn", "xnT", "xt", "m8",
                "slab", "t", "tT", "mu", "lv", "z", "zb", "zbT", "u", "uT", "dy", "dyT", "log_p_x", "log_p_x_missing",
-               "rowpart", "nll", "scal", "klpart", "eps", "rng", "pfull", "xhat", "metpart", "du", "duT", "dz", "dml", "dmlT", "dt", "dtT")
+               "rowpart", "nll", "scal", "klpart", "eps", "rng", "pfull", "xhat", "metpart", "du", "duT", "dz", "dml", "dmlT", "dt", "dtT",
+               "w1Ts", "cpack", "img", "yc", "a2", "yv", "da2", "dyc", "dycT", "dfeat")
+CONV_PACK_ELEMS = 32 * 160 + 16 * 288 + 4 * 16 * 128 + 32 * 256 + 4 * 16 * 64 + 16 * 128      # csrc/conv.hip CP_TOTAL
+CONV_FEATURES = 32 * 9 * 9
 
 
 class HlvaeWs(C.Structure):

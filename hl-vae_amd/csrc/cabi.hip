@@ -20,6 +20,10 @@ int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
 int hl_launch_mid_fwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, int, uint64_t, int, int, hipStream_t);
 int hl_launch_mid_bwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, const float*, float, int, int, hipStream_t);
 int hl_adam(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t);
+int hl_launch_conv_enc_fwd(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, int, hipStream_t);
+int hl_launch_conv_dec_fwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
+int hl_launch_conv_dec_bwd(const hlvae_plan*, const hlvae_ws*, int, int, hipStream_t);
+int hl_launch_conv_enc_bwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
 
 static thread_local char g_err[512] = "";
 void hl_set_error(const char* fmt, ...) {
@@ -98,6 +102,10 @@ void hlvae_dims_fill(hlvae_dims* d) {
     d->NY = d->D * d->y_dim;
     d->NYp = ru(d->NY, 64);
     d->n_stat = d->n_real + d->n_pos;
+    d->Xe = d->conv ? 32 * 9 * 9 : d->X;              // HLVAE.py:155
+    d->Xep = ru(d->Xe, 64);
+    d->NYl = d->conv ? 32 * 9 * 9 : d->NY;            // HLVAE.py:246
+    d->NYlp = ru(d->NYl, 64);
 }
 
 int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var* vars) {
@@ -108,6 +116,14 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     HL_REQUIRE(d.y_dim == 5, HLVAE_EINVAL, "plan_create: y_dim=%d, only 5 is instantiated", d.y_dim);
     HL_REQUIRE(d.Lp <= 64, HLVAE_EINVAL, "plan_create: latent_dim=%d > 64 unsupported", d.L);
     HL_REQUIRE(d.arena_size % 4 == 0, HLVAE_EINVAL, "plan_create: arena_size must be a multiple of 4 floats");
+    HL_REQUIRE(!d.conv || d.D == 36 * 36, HLVAE_EINVAL, "plan_create: the convolutional model needs 36 x 36 = 1296 variables "
+               "(HLVAE.py:305), got %d", d.D);
+    if (d.conv) {
+        const int64_t offs[8] = {d.o_c1w, d.o_c1b, d.o_c2w, d.o_c2b, d.o_t1w, d.o_t1b, d.o_t2w, d.o_t2b};
+        for (int i = 0; i < 8; ++i)
+            HL_REQUIRE(offs[i] >= 0 && offs[i] < d.atomic_region, HLVAE_EINVAL, "plan_create: convolution parameter %d outside "
+                       "the atomic gradient region", i);
+    }
     std::vector<int32_t> col2var(d.Xp, -1), stat_var(d.n_stat > 0 ? d.n_stat : 1, 0);
     int x = 0, nstat_seen = 0;
     for (int i = 0; i < d.D; ++i) {
@@ -125,6 +141,9 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
             ++nstat_seen;
         }
         if (v.kind == HLVAE_ORDINAL) HL_REQUIRE(v.e_off >= 0, HLVAE_EINVAL, "variable %d: thresholds offset", i);
+        if (d.conv && disc)
+            HL_REQUIRE(v.r_off >= 0 && v.rb_off >= 0 && v.r_off + v.ncls <= d.atomic_region && v.rb_off < d.atomic_region,
+                       HLVAE_EINVAL, "variable %d: representation-layer offsets", i);
         for (int k = 0; k < v.ncls; ++k) col2var[x + k] = i;
         x += v.ncls;
     }
@@ -193,6 +212,10 @@ int hlvae_normalize_stats(const hlvae_plan* p, const hlvae_ws* ws, const double*
 int hlvae_normalize_pack(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask, int B,
                          hlvae_stream s) {
     CHECK_B();
+    if (d.conv) {   // representation layer + conv1 + conv2 (HLVAE.py:293-308) produce the encoder input
+        HL_REQUIRE(ws->cpack && ws->img, HLVAE_EINVAL, "convolutional model without its workspace buffers");
+        return hl_launch_conv_enc_fwd(p, ws, data, mask, B, Bp, st);
+    }
     return hl_launch_pack(p, ws, data, mask, B, Bp, st);
 }
 
@@ -202,7 +225,7 @@ int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps,
     int rc;
     HL_REQUIRE(ws->splitk_enc >= 1, HLVAE_EINVAL, "splitk_enc");
     // trunk product Xn W1^T as split-K slabs (HLVAE.py:316-317, evaluated once) ...
-    if ((rc = hl_launch_gemm_splitk(ws->xn, d.Xp, ws->w1s, d.Xp, ws->slab, d.hep, Bp, d.hep, d.Xp, ws->splitk_enc, "enc1_splitk", st))) return rc;
+    if ((rc = hl_launch_gemm_splitk(ws->xn, d.Xep, ws->w1s, d.Xep, ws->slab, d.hep, Bp, d.hep, d.Xep, ws->splitk_enc, "enc1_splitk", st))) return rc;
     // ... then bias + ReLU, mean / log-var heads, clamp, reparameterisation AND the decoder trunk in one fused kernel
     return hl_launch_mid_fwd_fused(p, ws, eps, sample, rng_host_offset, B, Bp, st);
 }
@@ -215,6 +238,11 @@ int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_lo
                    // after hlvae_encoder_fwd the trunk is already in ws->u
         if ((rc = hl_launch_gemm_act(0, ws->zb, d.Lp, ws->wds, d.Lp, Bp, d.hdp, d.Lp, ws->P + d.o_bd, d.h_d, nullptr, ws->u,
                                      d.hdp, ws->uT, Bp, B, nullptr, "dec1_relu", st))) return rc;
+    }
+    if (d.conv) {   // y_layer as a plain Linear, then the two transposed convolutions (HLVAE.py:337-341)
+        if ((rc = hl_launch_gemm_act(2, ws->u, d.hdp, ws->wys, d.hdp, Bp, d.NYlp, d.hdp, ws->P + d.o_by, d.NYl, nullptr, ws->yc,
+                                     d.NYlp, nullptr, 0, B, nullptr, "y_layer_conv", st))) return rc;
+        if ((rc = hl_launch_conv_dec_fwd(p, ws, B, st))) return rc;
     }
     return hl_launch_y_heads(p, ws, g_logpx, g_scale, want_grad, want_params, B, Bp, st);
 }
@@ -257,6 +285,8 @@ int hlvae_backward_wy(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stre
     CHECK_B();
     // d Wy = dY^T U   [NY][h_d]: the largest gradient (55 % of the arena for D4) and the first one that is final, so a
     // data-parallel host can start its all-reduce while hlvae_backward(skip_wy = 1) is still running
+    HL_REQUIRE(!d.conv, HLVAE_EINVAL, "backward_wy: not available for the convolutional model (y_layer's gradient is final "
+               "only after the transposed convolutions' backward)");
     return hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", st);
 }
 
@@ -269,13 +299,17 @@ int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, c
     // events, so the structure is preserved under hipGraph capture) beside the critical path
     //   dY -> dU -> d(mu, lv) -> dT -> dW1.
     hipStream_t s0 = p->side[0], s1 = p->side[1];
+    if (d.conv)     // d y_grouped -> d a2 -> d (y_layer output), weight gradients of the transposed convolutions
+        if ((rc = hl_launch_conv_dec_bwd(p, ws, B, Bp, st))) return rc;
+    const bf16_t* dyl = d.conv ? ws->dyc : ws->dy;          // gradient of y_layer's output, both layouts
+    const bf16_t* dylT = d.conv ? ws->dycT : ws->dyT;
     HL_CHECK(hipEventRecord(p->ev[0], st));
     HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
-    // d Wy = dY^T U                                  [NY][h_d]
+    // d Wy = dY^T U                                  [NYl][h_d]
     if (!skip_wy)
-        if ((rc = hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
+        if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
     // d U slabs = dY Wy (split-K), then the fused middle: dU -> dz -> d(mu, lv) -> dT, bias gradients
-    if ((rc = hl_launch_gemm_splitk(ws->dy, d.NYp, ws->wyTs, d.NYp, ws->slab, d.hdp, Bp, d.hdp, d.NYp, ws->splitk_dec, "dU_splitk", st))) return rc;
+    if ((rc = hl_launch_gemm_splitk(dyl, d.NYlp, ws->wyTs, d.NYlp, ws->slab, d.hdp, Bp, d.hdp, d.NYlp, ws->splitk_dec, "dU_splitk", st))) return rc;
     if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st))) return rc;
     HL_CHECK(hipEventRecord(p->ev[1], st));
     HL_CHECK(hipStreamWaitEvent(s1, p->ev[1], 0));
@@ -284,7 +318,11 @@ int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, c
     if ((rc = hl_launch_gemm_f32(ws->dmlT, Bp, ws->tT, Bp, ws->G + d.o_wmu, d.h_e, 2 * d.Lp, d.h_e, Bp, d.Lp, d.L,
                                  ws->G + d.o_wlv, "dWmu_dWlv", s1))) return rc;
     // d W1 = dT^T Xn                                 [h_e][X]   (no input gradient for layer 1)
-    if ((rc = hl_launch_gemm_f32(ws->dtT, Bp, ws->xnT, Bp, ws->G + d.o_w1, d.X, d.h_e, d.X, Bp, 0, 0, nullptr, "dW1", st))) return rc;
+    if ((rc = hl_launch_gemm_f32(ws->dtT, Bp, ws->xnT, Bp, ws->G + d.o_w1, d.Xe, d.h_e, d.Xe, Bp, 0, 0, nullptr, "dW1", st))) return rc;
+    if (d.conv) {   // the convolutional features receive a gradient: d feat = dT W1, then conv2 / conv1 / representation layer
+        if ((rc = hl_launch_gemm_f32(ws->dt, d.hep, ws->w1Ts, d.hep, ws->dfeat, d.Xep, Bp, d.Xe, d.hep, 0, 0, nullptr, "dfeat", st))) return rc;
+        if ((rc = hl_launch_conv_enc_bwd(p, ws, B, st))) return rc;
+    }
     HL_CHECK(hipEventRecord(p->ev[3], s0));
     HL_CHECK(hipEventRecord(p->ev[4], s1));
     HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));

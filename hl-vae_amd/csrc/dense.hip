@@ -95,6 +95,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __rest
 // ------------------------------------------------------------------------------------------------
 // GEMM + elementwise epilogue into dual bf16.  MODE 0: relu(acc + bias)   (decoder trunk, HLVAE.py:336)
 //                                             MODE 1: acc * (ref > 0)    (d trunk of the encoder), colsum
+//                                             MODE 2: acc + bias         (y_layer under conv, HLVAE.py:337)
 // ------------------------------------------------------------------------------------------------
 template <int BK, int MODE>
 __global__ __launch_bounds__(HL_THREADS) void k_gemm_act(const bf16_t* __restrict__ A, int lda,
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_act(const bf16_t* __restric
             if (MODE == 0) {
                 v += bias[gc];
                 v = v > 0.f ? v : 0.f;
+            } else if (MODE == 2) {
+                v += bias[gc];                                   // plain Linear (y_layer of the convolutional decoder)
             } else {
                 v = bf2f(ref[(size_t)gr * ldo + gc]) > 0.f ? v : 0.f;
             }
@@ -177,7 +180,12 @@ int hl_launch_gemm_act(int mode, const bf16_t* A, int lda, const bf16_t* Bm, int
     HL_REQUIRE(K % 32 == 0 && M % 64 == 0 && N % 64 == 0, HLVAE_ESHAPE, "gemm_act: M=%d N=%d K=%d", M, N, K);
     dim3 grid(N / 64, M / 64);
     HL_PROF(label, s);
-    if (K % 64 == 0) {
+    if (mode == 2) {
+        if (K % 64 == 0)
+            k_gemm_act<64, 2><<<grid, HL_THREADS, 0, s>>>(A, lda, Bm, ldb, M, N, K, bias, nvalid, ref, out, ldo, outT, ldT, B, gbias);
+        else
+            k_gemm_act<32, 2><<<grid, HL_THREADS, 0, s>>>(A, lda, Bm, ldb, M, N, K, bias, nvalid, ref, out, ldo, outT, ldT, B, gbias);
+    } else if (K % 64 == 0) {
         if (mode == 0)
             k_gemm_act<64, 0><<<grid, HL_THREADS, 0, s>>>(A, lda, Bm, ldb, M, N, K, bias, nvalid, ref, out, ldo, outT, ldT, B, gbias);
         else

@@ -33,7 +33,9 @@ __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int 
                                              const float* __restrict__ g_elem, float g_scale,
                                              float* __restrict__ logpx, float* __restrict__ logpx_miss,
                                              float* __restrict__ pfull, int X, float* __restrict__ xhat,
-                                             float (&acc)[NACC], float (&lpo)[BM / 16]) {
+                                             float (&acc)[NACC], float (&lpo)[BM / 16], bool conv_real) {
+    // conv_real: real variable under the convolutional decoder -- sigmoid on the mean (HLVAE.py:271-273, 428-430), data
+    // scaled by 1/255 (HLVAE.py:393-394), no batch statistics (norm holds mean 0 / var 1; loglik.py:40-41)
     float w[YD];
 #pragma unroll
     for (int k = 0; k < YD; ++k) w[k] = P[var.w_off + k];
@@ -41,6 +43,7 @@ __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int 
     const float p = P[var.e_off];
     const float mean_d = norm[var.sidx];
     float vd = norm[n_stat + var.sidx];
+    const float xscale = conv_real ? 1.f / 255.f : 1.f;
     float ev, dp_fac;
     if (!is_pos) {
         vd = fmaxf(vd, 3e-4f);                                   // loglik.py:38
@@ -70,9 +73,14 @@ __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int 
         float lp_obs = 0.f, dth = 0.f;
         if (gr < B) {
             const size_t o = (size_t)gr * D + d;
-            const float x = xt[o];                               // raw x (real) or log1p x (pos)
+            const float x = xt[o] * xscale;                      // raw x (real) or log1p x (pos)
             const bool ob = m8[o] != 0;
-            const float mean = sd * th + mean_d;                 // :55 / :96
+            float thv = th, dsig = 1.f;
+            if (conv_real) {
+                thv = sigmoid_f(th);
+                dsig = thv * (1.f - thv);
+            }
+            const float mean = sd * thv + mean_d;                // :55 / :96
             const float rr = x - mean;
             float lp = -0.5f * rr * rr * inv_ev + c0;            // :58 / :102
             if (is_pos) lp -= x;
@@ -81,7 +89,7 @@ __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int 
             if (ob) {
                 const float g = g_elem != nullptr ? g_elem[o] : g_scale;
                 lp_obs = lp;
-                dth = g * rr * inv_ev * sd;
+                dth = g * rr * inv_ev * sd * dsig;
                 acc[YD + 1] += g * (0.5f * rr * rr * inv_ev - 0.5f) * dp_fac;
             }
             if (pfull != nullptr) pfull[(size_t)gr * X + var.xoff] = mean;      // loglik.py:64-67 (mean only)
@@ -405,7 +413,9 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
     const float* __restrict__ xt, const uint8_t* __restrict__ m8, int D, const float* __restrict__ g_elem, float g_scale,
     bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dyT, int Bp, float* __restrict__ logpx,
     float* __restrict__ logpx_miss, float* __restrict__ rowpart, float* __restrict__ pfull, int X,
-    float* __restrict__ xhat, int B, int want_grad) {
+    float* __restrict__ xhat, int B, int want_grad, const float* __restrict__ ysrc, int ldys) {
+    // ysrc != nullptr: convolutional decoder -- the tile of y_grouped comes from the second ConvTranspose (csrc/conv.hip,
+    // bias included) instead of the y_layer GEMM; d Y leaves in row-major layout only and d by is not ours
     constexpr int BN = 16 * YD;
     using Gm = GemmNT<BM, BN, 64, 4, 1>;
     constexpr int CLD = Gm::CLD;
@@ -418,11 +428,20 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = lid / tiles_m, m0 = (lid % tiles_m) * BM, n0 = tn * BN;
     const int NY = D * YD;
-    typename Gm::Acc accm;
-    Gm::zero(accm);
-    Gm::run(U, ldu, Wy, ldu, m0, n0, Bp, NY, 0, K, smem, accm);
-    Gm::to_lds(accm, smem);
     float* Cs = reinterpret_cast<float*>(smem);
+    const bool conv = ysrc != nullptr;
+    if (!conv) {
+        typename Gm::Acc accm;
+        Gm::zero(accm);
+        Gm::run(U, ldu, Wy, ldu, m0, n0, Bp, NY, 0, K, smem, accm);
+        Gm::to_lds(accm, smem);
+    } else {
+        for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
+            const int r = idx / BN, c = idx % BN;
+            Cs[r * CLD + c] = (m0 + r < B && n0 + c < NY) ? ysrc[(size_t)(m0 + r) * ldys + n0 + c] : 0.f;
+        }
+        __syncthreads();
+    }
     float* red = reinterpret_cast<float*>(smem + Gm::SMEM_BYTES);
 
     const int tid = threadIdx.x, v = tid & 15, rg = tid >> 4;
@@ -439,15 +458,15 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
         var = vars[d];
         float byv[YD];
 #pragma unroll
-        for (int k = 0; k < YD; ++k) byv[k] = P[o_by + (long)d * YD + k];
+        for (int k = 0; k < YD; ++k) byv[k] = conv ? 0.f : P[o_by + (long)d * YD + k];
         switch (var.kind) {
             case HLVAE_REAL:
                 proc_realpos<YD, BM, CLD, NACC>(false, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
-                                                g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo);
+                                                g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo, conv);
                 break;
             case HLVAE_POS:
                 proc_realpos<YD, BM, CLD, NACC>(true, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
-                                                g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo);
+                                                g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo, false);
                 break;
             case HLVAE_COUNT:
                 proc_count<YD, BM, CLD, NACC>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
@@ -520,6 +539,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
             *reinterpret_cast<uint32_t*>(dy + (size_t)(m0 + r) * lddy + n0 + c) =
                 (uint32_t)f2bf(Cs[r * CLD + c]) | ((uint32_t)f2bf(Cs[r * CLD + c + 1]) << 16);
     }
+    if (conv) return;
     for (int idx = tid; idx < BM * BN / 2; idx += HL_THREADS) {
         const int c = idx / (BM / 2), r = (idx % (BM / 2)) * 2;
         if (n0 + c < NY)
@@ -692,7 +712,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
         k_y_heads<5, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,  \
                                                           ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, \
                                                           d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing,       \
-                                                          ws->rowpart, pf, d.X, xh, B, want_grad)
+                                                          ws->rowpart, pf, d.X, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY)
         if (p->kmax <= 3) { if (big) HL_LAUNCH_HEADS(128, 3); else HL_LAUNCH_HEADS(64, 3); }
         else if (p->kmax <= 5) { if (big) HL_LAUNCH_HEADS(128, 5); else HL_LAUNCH_HEADS(64, 5); }
         else { if (big) HL_LAUNCH_HEADS(128, 8); else HL_LAUNCH_HEADS(64, 8); }

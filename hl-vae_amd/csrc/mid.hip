@@ -208,7 +208,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     const float* __restrict__ mu, const float* __restrict__ g_mu, const float* __restrict__ g_lv, float kl_w, int L,
     bf16_t* __restrict__ dmlT_out, float* __restrict__ gbmu, float* __restrict__ gblv,
     const bf16_t* __restrict__ wmlT, int hep, int h_e, const bf16_t* __restrict__ t, bf16_t* __restrict__ dtT_out,
-    float* __restrict__ gb1, int B) {
+    float* __restrict__ gb1, int B, bf16_t* __restrict__ dt_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lda = hdp + 8;
     bf16_t* Ua = reinterpret_cast<bf16_t*>(smem);                            // dU tile bf16 [16][hdp+8]
@@ -323,6 +323,10 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
         pk.x = (uint32_t)f2bf(o4[0]) | ((uint32_t)f2bf(o4[1]) << 16);
         pk.y = (uint32_t)f2bf(o4[2]) | ((uint32_t)f2bf(o4[3]) << 16);
         *reinterpret_cast<uint2*>(dtT_out + (size_t)col * Bp + m0 + (lane >> 4) * 4) = pk;
+        if (dt_out != nullptr) {                                 // row-major copy: only the convolutional model continues
+#pragma unroll                                                   // the backward pass below the first Linear
+            for (int r = 0; r < 4; ++r) dt_out[(size_t)(m0 + (lane >> 4) * 4 + r) * hep + col] = f2bf(o4[r]);
+        }
         s += __shfl_xor(s, 16, 64);                              // the 4 row groups of a column
         s += __shfl_xor(s, 32, 64);
         if (lane < 16 && col < h_e) atomicAdd(gb1 + col, s);
@@ -385,7 +389,7 @@ int hl_launch_mid_bwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
         k_mid_bwd_fused<LPv><<<Bp / MID_ROWS, MID_THREADS, smem, s>>>(                                                    \
             ws->slab, ws->splitk_dec, Bp, d.hdp, d.h_d, ws->u, ws->duT, ws->G + d.o_bd, ws->wdTs, ws->eps, ws->lv,     \
             ws->mu, g_mu, g_lv, kl_w, d.L, ws->dmlT, ws->G + d.o_bmu, ws->G + d.o_blv, ws->wmlTs, d.hep, d.h_e, ws->t, \
-            ws->dtT, ws->G + d.o_b1, B);                                                                               \
+            ws->dtT, ws->G + d.o_b1, B, d.conv ? ws->dt : nullptr);                                                    \
     }
     if (d.Lp == 32) HL_MB(32) else if (d.Lp == 64) HL_MB(64) else HL_REQUIRE(false, HLVAE_EINVAL, "latent_dim > 64");
 #undef HL_MB

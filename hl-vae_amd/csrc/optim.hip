@@ -161,8 +161,10 @@ static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws) {
     };
     // Wy [NY][h_d] -> wys [NY][hdp] (+ [hdp][NYp]);  W1 [h_e][X] -> w1s [hep][Xp];
     // Wd [h_d][L] -> wds [hdp][Lp] (+ [Lp][hdp]);  [Wmu; Wlv] [L][h_e] each -> wmls [2Lp][hep] (+ [hep][2Lp])
-    put(0, d.o_wy, d.NY, d.h_d, ws->wys, d.hdp, 0, ws->wyTs, d.NYp, d.NY, d.hdp);
-    put(1, d.o_w1, d.h_e, d.X, ws->w1s, d.Xp, 0, nullptr, 0, d.hep, d.Xp);
+    // (conv: y_layer is [2592][h_d], the first encoder Linear is [h_e][2592] and also needs its transpose: the convolutional
+    //  features receive a gradient, the raw inputs of the MLP path do not)
+    put(0, d.o_wy, d.NYl, d.h_d, ws->wys, d.hdp, 0, ws->wyTs, d.NYlp, d.NYl, d.hdp);
+    put(1, d.o_w1, d.h_e, d.Xe, ws->w1s, d.Xep, 0, d.conv ? ws->w1Ts : nullptr, d.hep, d.hep, d.Xep);
     put(2, d.o_wd, d.h_d, d.L, ws->wds, d.Lp, 0, ws->wdTs, d.hdp, d.hdp, d.Lp);
     put(3, d.o_wmu, d.L, d.h_e, ws->wmls, d.hep, 0, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep);
     put(4, d.o_wlv, d.L, d.h_e, ws->wmls, d.hep, d.Lp, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep);
@@ -188,12 +190,17 @@ static int check_set(const ShadowSet& s) {
     return 0;
 }
 
+int hl_conv_pack_weights(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s);
+
 int hl_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s) {
     const ShadowSet set = make_set(p, ws);
     if (int rc = check_set(set)) return rc;
-    HL_PROF("shadow_cast", s);
-    k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0);
-    HL_LAUNCH_CHECK();
+    {
+        HL_PROF("shadow_cast", s);
+        k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0);
+        HL_LAUNCH_CHECK();
+    }
+    if (p->d.conv) return hl_conv_pack_weights(p, ws, s);
     return 0;
 }
 
@@ -219,5 +226,6 @@ int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64
         k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 1);
     }
     HL_LAUNCH_CHECK();
+    if (d.conv) return hl_conv_pack_weights(p, ws, s);       // the convolution weights live in the small (atomic) region
     return 0;
 }

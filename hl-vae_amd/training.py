@@ -124,6 +124,11 @@ class ELBOTrainer:
             g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch)
         if self.dp is None:
             _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 0, B, s), "backward")
+        elif m.conv:
+            # convolutional model: y_layer's gradient is final only after the transposed convolutions' backward and the arena
+            # is 2.7 M parameters (10.8 MB): one all-reduce after the backward pass
+            _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 0, B, s), "backward")
+            self.dp.allreduce_(m._grad_arena)
         else:
             # data parallel: the y_layer gradient (the largest slice of the arena) is final first; its all-reduce runs on
             # RCCL's stream while the rest of the backward pass is still computing

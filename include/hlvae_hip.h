@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 10
+#define HLVAE_ABI_VERSION 11
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -44,6 +44,8 @@ typedef struct {
     int32_t w_off;   /* arena offset of the head weight   [y_dim][a]  (HLVAE.py:14,37,57,74) */
     int32_t b_off;   /* arena offset of the head bias     [a]                        */
     int32_t e_off;   /* arena offset of _log_vy_{real,pos}[i] or ordinal thresholds[K-1], -1 if none */
+    int32_t r_off;   /* conv only: arena offset of representation_layer weight[d][K] (HLVAE.py:94), -1 otherwise */
+    int32_t rb_off;  /* conv only: arena offset of representation_layer bias[d], -1 otherwise                     */
     int32_t pad;
 } hlvae_var;
 
@@ -51,14 +53,21 @@ typedef struct {
 typedef struct {
     int32_t D, X, y_dim, h_e, h_d, L;          /* reference dims = [X, [h_e], L, [h_d], y_dim], D = n_variables */
     int32_t n_real, n_pos;
+    int32_t conv;                              /* 1 = convolutional front / back end (HLVAE.py:139-152, 253-259): D must be 36 * 36 */
     /* derived */
     int32_t Xp, hep, hdp, Lp, NY, NYp, n_stat;
+    int32_t Xe, Xep;                           /* width of the first encoder Linear's input: X, or 32*9*9 under conv            */
+    int32_t NYl, NYlp;                         /* width of y_layer's output: D * y_dim, or 32*9*9 under conv                     */
     /* arena offsets (floats) of the dense layers, reference names in comments */
     int64_t o_w1, o_b1;          /* VAE_encoder_common_layers.0.{weight [h_e,X], bias}   (HLVAE.py:131) */
     int64_t o_wmu, o_bmu;        /* mean_layer.0        [L,h_e]                           (HLVAE.py:168) */
     int64_t o_wlv, o_blv;        /* log_var_layer.0     [L,h_e]                           (HLVAE.py:174) */
     int64_t o_wd, o_bd;          /* hidden.0 / d_layers.0 [h_d,L]                         (HLVAE.py:236) */
-    int64_t o_wy, o_by;          /* y_layer.0           [D*y_dim,h_d]                     (HLVAE.py:248) */
+    int64_t o_wy, o_by;          /* y_layer.0           [NYl,h_d]                         (HLVAE.py:246-248) */
+    int64_t o_c1w, o_c1b;        /* conv1  [16,1,3,3]   (HLVAE.py:147)  -- conv only, inside the atomic region */
+    int64_t o_c2w, o_c2b;        /* conv2  [32,16,3,3]  (HLVAE.py:151)                                         */
+    int64_t o_t1w, o_t1b;        /* deconv_layer.0  ConvTranspose2d [32,16,4,4]  (HLVAE.py:255)                */
+    int64_t o_t2w, o_t2b;        /* deconv_layer.2  ConvTranspose2d [16,y_dim,4,4]  (HLVAE.py:257-258)         */
     int64_t arena_size;          /* floats */
     int64_t atomic_region;       /* grads in [0, atomic_region) are accumulated with atomics and
                                     must be zero when a backward pass starts (hlvae_backward zeroes them) */
@@ -112,6 +121,16 @@ typedef struct {
     float* dz;                       /* [Bp][Lp]                                            */
     uint16_t* dml; uint16_t* dmlT;   /* [Bp][2Lp], [2Lp][Bp]                                */
     uint16_t* dt; uint16_t* dtT;     /* [Bp][hep], [hep][Bp]                                */
+    /* convolutional front / back end (NULL otherwise) */
+    uint16_t* w1Ts;      /* bf16 shadow [Xep][hep] of W1^T (input gradient of the first encoder Linear) */
+    uint16_t* cpack;     /* packed bf16 convolution weights (csrc/conv.hip, CP_TOTAL elements)          */
+    float* img;          /* [Bp][1296] the one-number-per-variable image the encoder convolves          */
+    uint16_t* yc;        /* [Bp][NYlp] y_layer output (bf16), viewed as [32][9][9]                      */
+    uint16_t* a2;        /* [Bp][18*18][16] ReLU(deconv 1), channel-last                                */
+    float* yv;           /* [Bp][NY]  deconv 2 output = y_grouped[b][pixel][c], fp32                    */
+    uint16_t* da2;       /* [Bp][18*18][16]                                                             */
+    uint16_t* dyc; uint16_t* dycT;   /* d yc [Bp][NYlp], [NYl][Bp]                                      */
+    float* dfeat;        /* [Bp][Xep] gradient of the 2592 convolutional features                       */
 } hlvae_ws;
 
 typedef struct hlvae_plan hlvae_plan;

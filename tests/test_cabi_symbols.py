@@ -46,5 +46,11 @@ def test_cpu_tensors_raise():
     m = HLVAE([src.cov_dim_ext, [16], 4, [16], 5], src.types_info, src.n_variables, conv=False)
     with pytest.raises(RuntimeError):
         m(torch.tensor(src.data), torch.tensor(src.mask), None, src.types_info)
-    with pytest.raises(NotImplementedError):
-        HLVAE([src.cov_dim_ext, [16], 4, [16], 5], src.types_info, src.n_variables)      # conv=True default
+    with pytest.raises(ValueError):      # conv=True (the default, as in the reference) needs 36 x 36 = 1296 variables
+        HLVAE([src.cov_dim_ext, [16], 4, [16], 5], src.types_info, src.n_variables)
+    d4 = synthetic.make_d4(n_subjects=1, T=2, seed=0)
+    mc = HLVAE([d4.cov_dim_ext, [16], 4, [16], 5], d4.types_info, d4.n_variables)       # convolutional model, CPU tensors
+    assert {"conv1.weight", "conv2.bias", "deconv_layer.2.weight", "Decoder_Conv_layer.0.bias",
+            "representation_layer.0.weight"} <= set(mc.state_dict())
+    with pytest.raises(RuntimeError):
+        mc(torch.tensor(d4.data), torch.tensor(d4.mask), None, d4.types_info)

@@ -1,0 +1,172 @@
+"""Convolutional front / back end (csrc/conv.hip) on the GPU:
+  1. every intermediate tensor the kernels leave in HBM against the oracle's value for the same weights (stage-wise
+     localisation: input image, 2592 convolutional features, y_layer output, ReLU(deconv 1), y_grouped);
+  2. the reference fixture d4_conv_small (reference HLVAE with conv=True): mu, log_var, log_p_x, loss, every gradient.
+Tolerances are those of the MLP tests: bf16 operands with fp32 accumulation against an fp64 reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import hlvae_amd                      # noqa: E402
+from hlvae_amd import synthetic       # noqa: E402
+from tests_common import max_abs_err, rel_err   # noqa: E402
+
+
+def _setup(golden_dir):
+    import hlvae_oracle as orc
+    from hlvae_amd.HLVAE import HLVAE
+    g = np.load(os.path.join(golden_dir, "d4_conv_small.npz"))
+    src = synthetic.make_d4(n_subjects=2, T=4, seed=5)
+    dims = [src.cov_dim_ext, [32], 8, [32], 5]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=13, std=0.05, conv=True)
+    dev = torch.device("cuda:0")
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=True, max_batch=128, materialize_samples=False)
+    model.load_state_dict(state)
+    model = model.to(dev)
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    for k in list(st):
+        if k.startswith("hidden."):
+            st[k] = st["d_layers." + k[len("hidden."):]]
+        if k.startswith("Decoder_Conv_layer."):
+            st[k] = st["deconv_layer." + k[len("Decoder_Conv_layer."):]]
+    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st, conv=True)
+    return g, src, dims, model, om, st, dev
+
+
+def _bf16_forward_statement(g, src, om, st):
+    """The oracle's fp64 network with the activations / weights rounded to bf16 at the points where the kernels round them
+    (straight-through, i.e. the exact fp64 gradient of the ROUNDED forward pass).  Separates the effect of bf16 storage,
+    which moves the ReLU / max-pool gates of the convolutional encoder, from kernel logic."""
+    import torch.nn.functional as F
+    import hlvae_oracle as orc
+
+    def q(x):
+        return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+    data, mask, eps = torch.tensor(src.data[:8]), torch.tensor(g["mask"]), torch.tensor(g["eps"])
+    X_list, norm = orc.batch_normalization(data, mask, om.blocks, conv=True)
+    one, j = torch.zeros_like(mask), 0
+    for b in om.blocks:
+        if b["type"] in ("cat", "ordinal"):
+            rep = torch.einsum("bdc,dc->bd", X_list[:, b["exp"]].reshape(8, -1, b["K"]),
+                               st[f"representation_layer.{j}.weight"]) + st[f"representation_layer.{j}.bias"]
+            j += 1
+        else:
+            rep = X_list[:, b["exp"]]
+        one[:, b["var"]] = rep * mask[:, b["var"]]
+    img = one.view(8, 1, 36, 36)
+    a1 = q(F.max_pool2d(F.relu(F.conv2d(img, st["conv1.weight"], st["conv1.bias"], padding=1)), 2))
+    feat = q(F.max_pool2d(F.relu(F.conv2d(a1, q(st["conv2.weight"]), st["conv2.bias"], padding=1)), 2)).reshape(8, -1)
+    t = q(F.relu(F.linear(feat, q(st["VAE_encoder_common_layers.0.weight"]), st["VAE_encoder_common_layers.0.bias"])))
+    mu = F.linear(t, q(st["mean_layer.0.weight"]), st["mean_layer.0.bias"])
+    lv = torch.clamp(F.linear(t, q(st["log_var_layer.0.weight"]), st["log_var_layer.0.bias"]), -15, 15)
+    z = q(mu + eps * torch.exp(0.5 * lv))
+    u = q(F.relu(F.linear(z, q(st["hidden.0.weight"]), st["hidden.0.bias"])))
+    yc = q(F.linear(u, q(st["y_layer.0.weight"]), st["y_layer.0.bias"]))
+    a2 = q(F.relu(F.conv_transpose2d(yc.view(-1, 32, 9, 9), q(st["deconv_layer.0.weight"]), st["deconv_layer.0.bias"], stride=2, padding=1)))
+    y = F.conv_transpose2d(a2, q(st["deconv_layer.2.weight"]), st["deconv_layer.2.bias"], stride=2, padding=1)
+    theta = orc.heads(y.view(8, 5, -1).permute(0, 2, 1), om.blocks, st, om.Theta, conv=True)
+    pm = torch.zeros_like(theta)
+    for b in om.blocks:
+        pm[:, b["par"]] = mask[:, b["var"]].repeat_interleave(b["K"], dim=1)
+    theta = pm * theta + (1 - pm) * theta.detach()
+    lpx, lpm, _ = orc.loglik_blocks(theta, data, mask, om.blocks, st, norm, conv=True)
+    loss = float(g["nll_scale"][0]) * (-lpx.sum()) + orc.standard_normal_kl(mu, lv)
+    loss.backward()
+    return {k: v.grad for k, v in st.items() if v.grad is not None}
+
+
+def test_conv_intermediates_against_oracle(golden_dir):
+    import torch.nn.functional as F
+    import hlvae_oracle as orc
+    g, src, dims, model, om, st, dev = _setup(golden_dir)
+    data, mask = torch.tensor(src.data[:8]), torch.tensor(g["mask"])
+    eps = torch.tensor(g["eps"])
+    with torch.no_grad():
+        out = model(data.to(dev), mask.to(dev), None, src.types_info, eps=eps.to(dev))
+    torch.cuda.synchronize()
+    ws = model._ws_t
+    # oracle intermediates
+    with torch.no_grad():
+        X_list, norm = orc.batch_normalization(data, mask, om.blocks, conv=True)
+        feat, img = om.conv_features(X_list, mask)
+        mu, lv = om.encode_params(X_list, mask)
+        z = mu + eps * torch.exp(0.5 * lv)
+        u = F.relu(F.linear(z, st["hidden.0.weight"], st["hidden.0.bias"]))
+        yc = F.linear(u, st["y_layer.0.weight"], st["y_layer.0.bias"])
+        a2 = F.relu(F.conv_transpose2d(yc.view(-1, 32, 9, 9), st["deconv_layer.0.weight"], st["deconv_layer.0.bias"], stride=2, padding=1))
+        y = F.conv_transpose2d(a2, st["deconv_layer.2.weight"], st["deconv_layer.2.bias"], stride=2, padding=1)
+        yg = y.view(8, 5, -1).permute(0, 2, 1).reshape(8, -1)
+    assert max_abs_err(ws["img"][:8].cpu(), img.view(8, -1)) < 1e-5
+    assert rel_err(ws["xn"][:8, :2592].float().cpu(), feat) < 1e-2, "convolutional features"
+    assert rel_err(ws["xnT"][:2592, :8].float().cpu().t(), feat) < 1e-2
+    assert max_abs_err(ws["mu"][:8].cpu(), mu) < 2e-2
+    assert rel_err(ws["yc"][:8, :2592].float().cpu(), yc) < 2e-2, "y_layer output"
+    a2_dev = ws["a2"][:8].float().cpu().view(8, 18, 18, 16).permute(0, 3, 1, 2)
+    assert rel_err(a2_dev, a2) < 2e-2, "deconv 1"
+    assert rel_err(ws["yv"][:8].cpu(), yg) < 2e-2, "deconv 2 (y_grouped)"
+
+
+def test_conv_forward_backward_against_reference_fixture(golden_dir):
+    g, src, dims, model, om, st, dev = _setup(golden_dir)
+    data, mask = torch.tensor(src.data[:8], device=dev), torch.tensor(g["mask"], device=dev)
+    eps = torch.tensor(g["eps"], device=dev)
+    p_samples, mu, lv, lpx, lpm, p_params, q_samples, q_params = model(data, mask, None, src.types_info, eps=eps)
+    torch.cuda.synchronize()
+    assert max_abs_err(mu.cpu(), g["mu"]) < 2e-2 and max_abs_err(lv.cpu(), g["log_var"]) < 2e-2
+    e_lpx = np.abs(lpx.detach().double().cpu().numpy() - g["log_p_x"])
+    assert np.all(e_lpx <= 3e-2 + 2e-2 * np.abs(g["log_p_x"]))
+    e_lpm = np.abs(lpm.detach().double().cpu().numpy() - g["log_p_x_missing"])
+    assert np.all(e_lpm <= 3e-2 + 2e-2 * np.abs(g["log_p_x_missing"]))
+    elbo, elbo_ref = float(lpx.double().sum()), float(g["log_p_x"].sum())
+    assert abs(elbo - elbo_ref) <= 1e-3 * abs(elbo_ref), (elbo, elbo_ref)
+    nll = model.loss_function(lpx)
+    kl = -0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
+    loss = float(g["nll_scale"][0]) * nll.sum() + kl
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"][0])) <= 1e-3 * abs(float(g["loss"][0]))
+    sd = dict(model.named_parameters())
+    errs = {}
+    for k in g.files:
+        if k.startswith("grad__"):
+            pname = k[len("grad__"):]
+            assert sd[pname].grad is not None, pname
+            errs[pname] = rel_err(sd[pname].grad.double().cpu().numpy(), g[k])
+    errs["y_layer.0.weight[:40]"] = rel_err(sd["y_layer.0.weight"].grad[:40].double().cpu().numpy(), g["grad_slice__y_layer.0.weight"])
+    errs["enc.weight[:, :64]"] = rel_err(sd["VAE_encoder_common_layers.0.weight"].grad[:, :64].double().cpu().numpy(),
+                                         g["grad_slice__VAE_encoder_common_layers.0.weight"])
+    # (1) against the reference itself (fp64): bf16 storage of the activations moves a few ReLU / max-pool gates of the
+    #     convolutional encoder, which an 8-row batch does not average out -> 12 % for the parameters below the first
+    #     Linear, 6 % elsewhere;  (2) against the exact gradient of the bf16-rounded forward pass: 2 %
+    enc_side = ("conv1.", "conv2.", "representation_layer.")
+    bad = {k: v for k, v in errs.items() if not v < (0.12 if k.startswith(enc_side) else 6e-2)}
+    assert not bad, (bad, errs)
+    stmt = _bf16_forward_statement(g, src, om, st)
+    errs2 = {k: rel_err(sd[k].grad.double().cpu().numpy(), v.numpy()) for k, v in stmt.items()
+             if k in sd and sd[k].grad is not None and v.numel() > 0 and float(v.abs().max()) > 0}
+    bad2 = {k: v for k, v in errs2.items() if not v < 2e-2}
+    assert len(errs2) >= 20 and not bad2, (bad2, errs2)
+
+
+def test_conv_training_steps_run_and_reduce_the_loss(golden_dir):
+    """fused ELBOTrainer step with the convolutional model (Adam on the conv parameters through the small-region kernel,
+    re-packed convolution weights every step): the NLL of a fixed batch goes down."""
+    from hlvae_amd.training import ELBOTrainer
+    g, src, dims, model, om, st, dev = _setup(golden_dir)
+    data, mask = torch.tensor(src.data[:8], device=dev), torch.tensor(g["mask"], device=dev)
+    tr = ELBOTrainer(model, P_total=2, kl="normal", max_batch=128, lr=1e-3)
+    nll = []
+    for i in range(30):
+        tr.step(data, mask, 2)
+        nll.append(float(tr.scalars()["nll_sum"]))
+    assert np.isfinite(nll).all() and nll[-1] < nll[0], nll
