@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--prefetch", action="store_true",
                     help="run the NEXT batch's input stage on a side stream inside each step (measured slower on MI355X: a forked "
                          "branch in the HIP graph costs more than the 31 us it hides; DESIGN.md section 5)")
+    ap.add_argument("--conv", action="store_true",
+                    help="convolutional encoder/decoder (conv_hivae = True, what config/hlvae_config_file.txt:51 selects) "
+                         "instead of the MLP the north star names")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
@@ -65,7 +68,7 @@ def build_batches(src, batch, n_ring, dev):
     return out
 
 
-def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps):
+def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps, conv=False):
     """The oracle (CPU fp64 restatement, kind "port") executing the training.py:70-137 sequence:
     forward, NLL, per-step metrics, KL, backward, Adam -- on the host cores of this box."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -75,12 +78,15 @@ def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps):
     # the many small fp64 ops of the step)
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    st = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in state.items() if not k.startswith("hidden.")}
+    st = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in state.items()
+          if not k.startswith(("hidden.", "Decoder_Conv_layer."))}
     for k in list(st):
         if k.startswith("d_layers."):
             st["hidden." + k[len("d_layers."):]] = st[k]
-    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st)
-    names = [k for k in st if not k.startswith("hidden.") and k != "_disp_param"]
+        if k.startswith("deconv_layer."):
+            st["Decoder_Conv_layer." + k[len("deconv_layer."):]] = st[k]
+    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st, conv=conv)
+    names = [k for k in st if not k.startswith(("hidden.", "Decoder_Conv_layer.")) and k != "_disp_param"]
     params = [st[k] for k in names]
     m1 = [torch.zeros_like(p) for p in params]
     m2 = [torch.zeros_like(p) for p in params]
@@ -130,7 +136,7 @@ def main():
     src = synthetic.make_d4(n_subjects=50, T=20, seed=100 + rank)          # BASELINE configs[1]: 1k-sample set
     dims = [src.cov_dim_ext, [500], 32, [500], 5]
     torch.manual_seed(0)                                                   # identical initial weights on all ranks
-    model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=a.batch, materialize_samples=False).to(dev)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=a.conv, max_batch=a.batch, materialize_samples=False).to(dev)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     P_total = 50 * world
     kl = None if a.kl == "none" else a.kl
@@ -202,7 +208,7 @@ def main():
         print(f"[bench] roofline: {json.dumps(roof)}", file=sys.stderr, flush=True)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(src, dims, state0, ring[0]["rows"], P_total, ring[0]["P_batch"], kl, a.cpu_steps)
+        cpu = cpu_baseline(src, dims, state0, ring[0]["rows"], P_total, ring[0]["P_batch"], kl, a.cpu_steps, conv=a.conv)
 
     if rank == 0:
         line = {
@@ -210,7 +216,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic 1k-sample D4 Het-HealthMNIST set (324 real + 972 cat5, 25 pct missing), "
-                                   f"MLP [5184,[500],32,[500],5], batch {a.batch} rows/GPU, fp64 inputs resident in HBM",
+                                   + ("convolutional encoder/decoder (conv 1-16-32 + 2592-500-32 | 32-500-2592 + deconv 32-16-5), "
+                                      if a.conv else "MLP [5184,[500],32,[500],5], ")
+                                   + f"batch {a.batch} rows/GPU, fp64 inputs resident in HBM",
                        "kl": a.kl, "hip_graph": use_graph, "input_stage_prefetch": pipelined, "rows_per_step_per_gpu": rows_per_step,
                        "final_nll_sum": nll_last},
             "roofline": roof, "cpu_baseline": cpu,

@@ -294,6 +294,9 @@ class HLVAE(nn.Module):
             d.o_c1w, d.o_c1b, d.o_c2w, d.o_c2b = ao(self.conv1.weight), ao(self.conv1.bias), ao(self.conv2.weight), ao(self.conv2.bias)
             d.o_t1w, d.o_t1b = ao(self.deconv_layer[0].weight), ao(self.deconv_layer[0].bias)
             d.o_t2w, d.o_t2b = ao(self.deconv_layer[2].weight), ao(self.deconv_layer[2].bias)
+            first = self.representation_layer[0].weight if len(self.representation_layer) else self.conv1.weight
+            d.o_cv_lo = ao(first)                         # the arena order puts these tensors back to back (see __init__)
+            d.cv_n = ao(self.y_layer[0].bias) + self.y_layer[0].bias.numel() - d.o_cv_lo
         d.o_w1, d.o_b1 = ao(self.VAE_encoder_common_layers[0].weight), ao(self.VAE_encoder_common_layers[0].bias)
         d.o_wmu, d.o_bmu = ao(self.mean_layer[0].weight), ao(self.mean_layer[0].bias)
         d.o_wlv, d.o_blv = ao(self.log_var_layer[0].weight), ao(self.log_var_layer[0].bias)
@@ -380,7 +383,7 @@ class HLVAE(nn.Module):
         if d.conv:          # convolutional front / back end (csrc/conv.hip)
             t.update(w1Ts=z(d.Xep, d.hep), cpack=z(_lib.CONV_PACK_ELEMS), img=z(Bp, d.D, dt=f32), yc=z(Bp, d.NYlp),
                      a2=z(Bp, 18 * 18 * 16), yv=z(Bp, d.NY, dt=f32), da2=z(Bp, 18 * 18 * 16), dyc=z(Bp, d.NYlp),
-                     dycT=z(d.NYl, Bp), dfeat=z(Bp, d.Xep, dt=f32))
+                     dycT=z(d.NYl, Bp), dfeat=z(Bp, d.Xep, dt=f32), cvpart=z(_lib.CONV_PART_ROWS, d.cv_n, dt=f32))
         t["P"] = self._arena
         t["rng"][0] = int(torch.randint(0, 2 ** 62, (1,)).item())          # Philox seed from torch's global RNG
         ws = _lib.HlvaeWs()

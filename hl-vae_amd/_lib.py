@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -25,13 +25,14 @@ class HlvaeDims(C.Structure):
                                             "Xp", "hep", "hdp", "Lp", "NY", "NYp", "n_stat", "Xe", "Xep", "NYl", "NYlp")]
                 + [(n, C.c_int64) for n in ("o_w1", "o_b1", "o_wmu", "o_bmu", "o_wlv", "o_blv", "o_wd", "o_bd",
                                             "o_wy", "o_by", "o_c1w", "o_c1b", "o_c2w", "o_c2b", "o_t1w", "o_t1b", "o_t2w", "o_t2b",
-                                            "arena_size", "atomic_region")])
+                                            "o_cv_lo", "cv_n", "arena_size", "atomic_region")])
 
 
 WS_POINTERS = ("P", "G", "w1s", "wmls", "wmlTs", "wds", "wdTs", "wys", "wyTs", "sums", "norm", "xn", "xnT", "xt", "m8",
                "slab", "t", "tT", "mu", "lv", "z", "zb", "zbT", "u", "uT", "dy", "dyT", "log_p_x", "log_p_x_missing",
                "rowpart", "nll", "scal", "klpart", "eps", "rng", "pfull", "xhat", "metpart", "du", "duT", "dz", "dml", "dmlT", "dt", "dtT",
-               "w1Ts", "cpack", "img", "yc", "a2", "yv", "da2", "dyc", "dycT", "dfeat")
+               "w1Ts", "cpack", "img", "yc", "a2", "yv", "da2", "dyc", "dycT", "dfeat", "cvpart")
+CONV_PART_ROWS = 256
 CONV_PACK_ELEMS = 32 * 160 + 16 * 288 + 4 * 16 * 128 + 32 * 256 + 4 * 16 * 64 + 16 * 128      # csrc/conv.hip CP_TOTAL
 CONV_FEATURES = 32 * 9 * 9
 

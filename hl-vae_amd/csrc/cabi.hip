@@ -123,6 +123,11 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
         for (int i = 0; i < 8; ++i)
             HL_REQUIRE(offs[i] >= 0 && offs[i] < d.atomic_region, HLVAE_EINVAL, "plan_create: convolution parameter %d outside "
                        "the atomic gradient region", i);
+        HL_REQUIRE(d.o_cv_lo >= 0 && d.cv_n > 0 && d.o_cv_lo + d.cv_n <= d.atomic_region && d.o_by + d.NYl == d.o_cv_lo + d.cv_n,
+                   HLVAE_EINVAL, "plan_create: convolution gradient range [%ld, +%ld) must end with y_layer's bias inside the "
+                   "atomic region", (long)d.o_cv_lo, (long)d.cv_n);
+        for (int i = 0; i < 8; ++i)
+            HL_REQUIRE(offs[i] >= d.o_cv_lo, HLVAE_EINVAL, "plan_create: convolution parameter %d below the gradient range", i);
     }
     std::vector<int32_t> col2var(d.Xp, -1), stat_var(d.n_stat > 0 ? d.n_stat : 1, 0);
     int x = 0, nstat_seen = 0;

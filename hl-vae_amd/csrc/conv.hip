@@ -21,6 +21,7 @@
 #define CV_H1 18
 #define CV_H2 9
 #define CV_FEAT (CV_C2 * CV_H2 * CV_H2)
+#define CV_PART_ROWS 256              // workgroups of the backward kernels = rows of the partial-gradient buffer
 
 // packed bf16 weights inside ws->cpack (elements)
 #define CP_C2F 0                          // conv2 forward        [32 co][160]   k = tap * 16 + ci        (144 used)
@@ -325,7 +326,11 @@ __global__ __launch_bounds__(256) void k_convT2_fwd(const bf16_t* __restrict__ a
 // d a2 = ConvTranspose^T(dY) * ReLU'(a2);  d W_t2 += a2 (x) dY;  d b_t2 += sum dY
 __global__ __launch_bounds__(256) void k_convT2_bwd(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ a2,
                                                     const bf16_t* __restrict__ cp, bf16_t* __restrict__ da2,
-                                                    float* __restrict__ gw, float* __restrict__ gb, int B) {
+                                                    float* __restrict__ part, long part_stride, long part_lo, long o_w,
+                                                    long o_b, int B) {
+    // gw / gb: this workgroup's row of the partial-gradient buffer (plain stores, every entry written: no atomics, no memset)
+    float* __restrict__ gw = part + (size_t)blockIdx.x * part_stride - part_lo + o_w;
+    float* __restrict__ gb = part + (size_t)blockIdx.x * part_stride - part_lo + o_b;
     __shared__ __attribute__((aligned(16))) bf16_t dys[DY_LD * DY_LD * 8];
     __shared__ __attribute__((aligned(16))) bf16_t a2s[(CV_H1 * CV_H1 + 1) * 16];        // + one zero row
     __shared__ __attribute__((aligned(16))) bf16_t outs[CV_H1 * CV_H1 * 16];
@@ -400,10 +405,7 @@ __global__ __launch_bounds__(256) void k_convT2_bwd(const bf16_t* __restrict__ d
         const int n = (wave + 4 * j) * 16 + r16, tap = n >> 3, co = n & 7;
         if (co < 5)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ci = 4 * q + r;
-                if (wacc[j][r] != 0.f) atomicAdd(gw + (ci * 5 + co) * 16 + tap, wacc[j][r]);
-            }
+            for (int r = 0; r < 4; ++r) gw[((4 * q + r) * 5 + co) * 16 + tap] = wacc[j][r];
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -411,14 +413,18 @@ __global__ __launch_bounds__(256) void k_convT2_bwd(const bf16_t* __restrict__ d
         if (lane == 0) atomicAdd(&bred[k], v);
     }
     __syncthreads();
-    if (tid < 5 && bred[tid] != 0.f) atomicAdd(gb + tid, bred[tid]);
+    if (tid < 5) gb[tid] = bred[tid];
 }
 
 // d yc = ConvTranspose^T(d a2);  d W_t1 += yc (x) d a2;  d b_t1 += sum d a2
 __global__ __launch_bounds__(256) void k_convT1_bwd(const bf16_t* __restrict__ da2, const bf16_t* __restrict__ yc, int ldy,
                                                     const bf16_t* __restrict__ cp, bf16_t* __restrict__ dyc,
-                                                    bf16_t* __restrict__ dycT, int Bp, float* __restrict__ gw,
-                                                    float* __restrict__ gb, float* __restrict__ gby, int B) {
+                                                    bf16_t* __restrict__ dycT, int Bp, float* __restrict__ part,
+                                                    long part_stride, long part_lo, long o_w, long o_b, long o_by, int B) {
+    float* __restrict__ prow = part + (size_t)blockIdx.x * part_stride - part_lo;
+    float* __restrict__ gw = prow + o_w;
+    float* __restrict__ gb = prow + o_b;
+    float* __restrict__ gby = prow + o_by;
     __shared__ __attribute__((aligned(16))) bf16_t das[A1_LD * A1_LD * 16];
     __shared__ __attribute__((aligned(16))) bf16_t ycs[82 * 32];                  // NHWC, row 81 = zeros
     __shared__ __attribute__((aligned(16))) bf16_t outs[CV_FEAT];
@@ -503,21 +509,18 @@ __global__ __launch_bounds__(256) void k_convT1_bwd(const bf16_t* __restrict__ d
     }
 #pragma unroll
     for (int k = 0; k < (CV_FEAT + 255) / 256; ++k)
-        if (tid + 256 * k < CV_FEAT && yacc[k] != 0.f) atomicAdd(gby + tid + 256 * k, yacc[k]);
+        if (tid + 256 * k < CV_FEAT) gby[tid + 256 * k] = yacc[k];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int tap = wave + 4 * j;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ci = i * 16 + 4 * q + r;
-                if (wacc[i][j][r] != 0.f) atomicAdd(gw + (ci * 16 + r16) * 16 + tap, wacc[i][j][r]);
-            }
+            for (int r = 0; r < 4; ++r) gw[((i * 16 + 4 * q + r) * 16 + r16) * 16 + tap] = wacc[i][j][r];
         }
     atomicAdd(&bred[r16], bacc);
     __syncthreads();
-    if (tid < 16 && bred[tid] != 0.f) atomicAdd(gb + tid, bred[tid]);
+    if (tid < 16) gb[tid] = bred[tid];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -530,6 +533,8 @@ struct EncBwdSmem {
     float da1[CV_H1 * CV_H1 * CV_C1];
     float w1s[160];
     float red[16 * 10];
+    float red2[32];
+    float rep[CV_D * 9];                                    // representation layer: d w[d][k < 8], d bias[d] of this workgroup
     __attribute__((aligned(16))) bf16_t a1[A1_LD * A1_LD * CV_C1];
     __attribute__((aligned(16))) bf16_t dz2[A1_LD * A1_LD * CV_C2];
     uint8_t am1[CV_H1 * CV_H1 * CV_C1];
@@ -539,7 +544,10 @@ __global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ 
                                                       int ldf, const hlvae_var* __restrict__ vars,
                                                       const float* __restrict__ P, hlvae_dims d,
                                                       const bf16_t* __restrict__ cp, const float* __restrict__ xt,
-                                                      const uint8_t* __restrict__ m8, float* __restrict__ G, int B) {
+                                                      const uint8_t* __restrict__ m8, float* __restrict__ Gpart, long part_stride,
+                                                      long part_lo, int B) {
+    // G = this workgroup's row of the partial-gradient buffer, addressed with ARENA offsets (row - part_lo)
+    float* __restrict__ G = Gpart + (size_t)blockIdx.x * part_stride - part_lo;
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     EncBwdSmem& sm = *reinterpret_cast<EncBwdSmem*>(dsm);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, r16 = lane & 15;
@@ -547,6 +555,8 @@ __global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ 
     for (int i = tid; i < A1_LD * A1_LD * CV_C1 / 2; i += 256) reinterpret_cast<uint32_t*>(sm.a1)[i] = 0u;
     for (int i = tid; i < A1_LD * A1_LD * CV_C2 / 2; i += 256) reinterpret_cast<uint32_t*>(sm.dz2)[i] = 0u;
     if (tid < 160) sm.w1s[tid] = tid < 144 ? P[d.o_c1w + tid] : P[d.o_c1b + tid - 144];
+    for (int i = tid; i < CV_D * 9; i += 256) sm.rep[i] = 0.f;
+    if (tid < 32) sm.red2[tid] = 0.f;
     bf16x8_t bwd[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) bwd[s] = ld8(cp + CP_C2D + r16 * 288 + s * 32 + q * 8);
@@ -660,15 +670,13 @@ __global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ 
         for (int dd = tid; dd < CV_D; dd += 256) {
             const hlvae_var var = vars[dd];
             if ((var.kind == HLVAE_CAT || var.kind == HLVAE_ORDINAL) && m8[(size_t)b * d.D + dd]) {
-                const float g = sm.dimg[dd];
+                const float g = sm.dimg[dd];                       // variable dd is always this thread's: plain adds
                 const int cls = (int)xt[(size_t)b * d.D + dd];
-                if (g != 0.f) {
-                    atomicAdd(G + var.rb_off, g);
-                    if (var.kind == HLVAE_CAT) {
-                        if (cls >= 0) atomicAdd(G + var.r_off + cls, g);
-                    } else {
-                        for (int k = 0; k <= cls && k < var.ncls; ++k) atomicAdd(G + var.r_off + k, g);
-                    }
+                sm.rep[dd * 9 + 8] += g;
+                if (var.kind == HLVAE_CAT) {
+                    if (cls >= 0) sm.rep[dd * 9 + cls] += g;
+                } else {
+                    for (int k = 0; k <= cls && k < var.ncls; ++k) sm.rep[dd * 9 + k] += g;
                 }
             }
         }
@@ -682,28 +690,49 @@ __global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ 
             const int tap = wave + 4 * j;
             if (tap < 9)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = i * 16 + 4 * q + r;
-                    if (wacc[i][j][r] != 0.f) atomicAdd(G + d.o_c2w + (co * 16 + r16) * 9 + tap, wacc[i][j][r]);
-                }
+                for (int r = 0; r < 4; ++r) G[d.o_c2w + ((i * 16 + 4 * q + r) * 16 + r16) * 9 + tap] = wacc[i][j][r];
         }
+    if (tid < 160) sm.red[tid] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float v = b2acc[i];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (q == 0 && v != 0.f) atomicAdd(G + d.o_c2b + i * 16 + r16, v);
+        if (q == 0) atomicAdd(&sm.red2[i * 16 + r16], v);          // LDS: the four waves own different pooling windows
     }
-    if (tid < 160) sm.red[tid] = 0.f;
-    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 10; ++t) atomicAdd(&sm.red[(tid & 15) * 10 + t], w1acc[t]);
     __syncthreads();
     if (tid < 160) {
         const int co = tid / 10, t = tid % 10;
-        const float v = sm.red[tid];
-        if (v != 0.f) atomicAdd(t < 9 ? G + d.o_c1w + co * 9 + t : G + d.o_c1b + co, v);
+        G[t < 9 ? d.o_c1w + co * 9 + t : d.o_c1b + co] = sm.red[tid];
     }
+    if (tid < 32) G[d.o_c2b + tid] = sm.red2[tid];
+    for (int dd = tid; dd < CV_D; dd += 256) {
+        const hlvae_var var = vars[dd];
+        if (var.kind == HLVAE_CAT || var.kind == HLVAE_ORDINAL) {
+            G[var.rb_off] = sm.rep[dd * 9 + 8];
+            for (int k = 0; k < var.ncls; ++k) G[var.r_off + k] = sm.rep[dd * 9 + k];
+        }
+    }
+}
+
+// G[lo + i] += sum over the workgroups' partial rows (coalesced across i): replaces one atomic per weight and workgroup,
+// which on MI355X serialises in the fabric when 256 workgroups on 8 XCDs hit the same address
+__global__ __launch_bounds__(256) void k_conv_wgrad_reduce(const float* __restrict__ part, int nrows, long n, float* __restrict__ G) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < nrows; r += 4) {
+        s0 += part[(size_t)r * n + i];
+        s1 += part[(size_t)(r + 1) * n + i];
+        s2 += part[(size_t)(r + 2) * n + i];
+        s3 += part[(size_t)(r + 3) * n + i];
+    }
+    for (; r < nrows; ++r) s0 += part[(size_t)r * n + i];
+    G[i] += (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -742,16 +771,17 @@ int hl_launch_conv_dec_fwd(const hlvae_plan* p, const hlvae_ws* ws, int B, hipSt
 
 int hl_launch_conv_dec_bwd(const hlvae_plan* p, const hlvae_ws* ws, int B, int Bp, hipStream_t s) {
     const hlvae_dims& d = p->d;
-    const int grid = B < 256 ? B : 256;
+    const int grid = B < CV_PART_ROWS ? B : CV_PART_ROWS;
     {
         HL_PROF("convT2_bwd", s);
-        k_convT2_bwd<<<grid, 256, 0, s>>>(ws->dy, d.NYp, ws->a2, ws->cpack, ws->da2, ws->G + d.o_t2w, ws->G + d.o_t2b, B);
+        k_convT2_bwd<<<grid, 256, 0, s>>>(ws->dy, d.NYp, ws->a2, ws->cpack, ws->da2, ws->cvpart, d.cv_n, d.o_cv_lo, d.o_t2w,
+                                          d.o_t2b, B);
         HL_LAUNCH_CHECK();
     }
     {
         HL_PROF("convT1_bwd", s);
-        k_convT1_bwd<<<grid, 256, 0, s>>>(ws->da2, ws->yc, d.NYlp, ws->cpack, ws->dyc, ws->dycT, Bp, ws->G + d.o_t1w,
-                                          ws->G + d.o_t1b, ws->G + d.o_by, B);
+        k_convT1_bwd<<<grid, 256, 0, s>>>(ws->da2, ws->yc, d.NYlp, ws->cpack, ws->dyc, ws->dycT, Bp, ws->cvpart, d.cv_n,
+                                          d.o_cv_lo, d.o_t1w, d.o_t1b, d.o_by, B);
         HL_LAUNCH_CHECK();
     }
     return 0;
@@ -759,16 +789,23 @@ int hl_launch_conv_dec_bwd(const hlvae_plan* p, const hlvae_ws* ws, int B, int B
 
 int hl_launch_conv_enc_bwd(const hlvae_plan* p, const hlvae_ws* ws, int B, hipStream_t s) {
     const hlvae_dims& d = p->d;
-    const int grid = B < 256 ? B : 256;
+    const int grid = B < CV_PART_ROWS ? B : CV_PART_ROWS;
     static bool attr_set = false;
     if (!attr_set) {
         HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_enc_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)sizeof(EncBwdSmem)));
         attr_set = true;
     }
-    HL_PROF("conv_enc_bwd", s);
-    k_conv_enc_bwd<<<grid, 256, sizeof(EncBwdSmem), s>>>(ws->img, ws->dfeat, d.Xep, p->vars_dev, ws->P, d, ws->cpack, ws->xt,
-                                                         ws->m8, ws->G, B);
-    HL_LAUNCH_CHECK();
+    {
+        HL_PROF("conv_enc_bwd", s);
+        k_conv_enc_bwd<<<grid, 256, sizeof(EncBwdSmem), s>>>(ws->img, ws->dfeat, d.Xep, p->vars_dev, ws->P, d, ws->cpack, ws->xt,
+                                                             ws->m8, ws->cvpart, d.cv_n, d.o_cv_lo, B);
+        HL_LAUNCH_CHECK();
+    }
+    {   // all three backward kernels have filled their columns of the partial rows: fold them into the gradient arena
+        HL_PROF("conv_wgrad_reduce", s);
+        k_conv_wgrad_reduce<<<(int)((d.cv_n + 255) / 256), 256, 0, s>>>(ws->cvpart, grid, d.cv_n, ws->G + d.o_cv_lo);
+        HL_LAUNCH_CHECK();
+    }
     return 0;
 }

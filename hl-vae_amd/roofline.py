@@ -44,12 +44,13 @@ def algorithmic_work(model, B):
     d = model._dims
     Bp = _ru(B, 128)
     X, Xp, D, he, hep, hd, hdp, L, Lp, NY = d.X, d.Xp, d.D, d.h_e, d.hep, d.h_d, d.hdp, d.L, d.Lp, d.NY
+    Xe, Xep, NYl, NYlp = d.Xe, d.Xep, d.NYl, d.NYlp          # first encoder Linear input / y_layer output (conv: 2592)
     S_e, S_d = model._ws.splitk_enc, model._ws.splitk_dec
     Pn = model._arena_size
     w = {}
     w["colstats"] = (B * d.n_stat * 16, 0)
     w["normalize_pack"] = (B * (X + D) * 8 + 2 * B * Xp * 2 + B * D * 5, 0)
-    w["enc1_splitk"] = ((B * Xp + hep * Xp) * 2 + S_e * B * hep * 4, 2 * B * X * he)
+    w["enc1_splitk"] = ((B * Xep + hep * Xep) * 2 + S_e * B * hep * 4, 2 * B * Xe * he)
     w["mid_fwd_fused"] = (S_e * B * hep * 4 + 2 * B * hep * 2 + 2 * Lp * hep * 2 + B * L * 16 + hdp * Lp * 2 + 2 * B * hdp * 2,
                           2 * B * he * 2 * L + 2 * B * L * hd)
     w["dec1_relu"] = ((B * Lp + hdp * Lp) * 2 + 2 * B * hdp * 2, 2 * B * L * hd)
@@ -57,15 +58,27 @@ def algorithmic_work(model, B):
     w["metrics_partial"] = (B * D * 9, 0)
     w["metrics_finish"] = (16 * 6 * D * 4, 0)
     w["elbo_finalize"] = (((D + 15) // 16) * B * 4, 0)
-    w["dWy"] = ((NY * Bp + hdp * Bp) * 2 + NY * hd * 4, 2 * B * NY * hd)
-    w["dU_splitk"] = ((B * d.NYp + hdp * d.NYp) * 2 + S_d * B * hdp * 4, 2 * B * NY * hd)
+    w["dWy"] = ((NYl * Bp + hdp * Bp) * 2 + NYl * hd * 4, 2 * B * NYl * hd)
+    w["dU_splitk"] = ((B * NYlp + hdp * NYlp) * 2 + S_d * B * hdp * 4, 2 * B * NYl * hd)
     w["mid_bwd_fused"] = (S_d * B * hdp * 4 + 2 * B * hdp * 2 + B * L * 16 + 2 * B * 2 * Lp * 2 + 2 * B * hep * 2,
                           2 * B * hd * L + 2 * B * 2 * L * he)
     w["dWd"] = ((hdp * Bp + Lp * Bp) * 2 + hd * L * 4, 2 * B * hd * L)
     w["dWmu_dWlv"] = ((2 * Lp * Bp + hep * Bp) * 2 + 2 * L * he * 4, 2 * B * 2 * L * he)
-    w["dW1"] = ((hep * Bp + Xp * Bp) * 2 + he * X * 4, 2 * B * X * he)
-    n_w = he * X + 2 * L * he + hd * L + NY * hd
-    shadow_bytes = (he * X + 2 * (2 * L * he + hd * L + NY * hd)) * 2
+    w["dW1"] = ((hep * Bp + Xep * Bp) * 2 + he * Xe * 4, 2 * B * Xe * he)
+    n_w = he * Xe + 2 * L * he + hd * L + NYl * hd
+    shadow_bytes = ((2 if d.conv else 1) * he * Xe + 2 * (2 * L * he + hd * L + NYl * hd)) * 2
+    if d.conv:      # csrc/conv.hip, per launch over the whole batch: activations in / out once; MACs x 2
+        px = 36 * 36
+        w["conv_enc_fwd"] = (B * (X + D) * 8 + B * px * 4 + 2 * B * Xe * 2 + B * D * 5, 2 * B * (px * 16 * 9 + 324 * 32 * 144))
+        w["y_layer_conv"] = ((B * hdp + NYl * hdp) * 2 + B * NYl * 2, 2 * B * NYl * hd)
+        w["convT1_fwd"] = (B * NYl * 2 + B * 5184 * 2, 2 * B * 324 * 16 * 128)
+        w["convT2_fwd"] = (B * 5184 * 2 + B * NY * 4, 2 * B * px * 5 * 64)
+        w["y_heads_loglik"] = (B * NY * 4 + B * D * 5 + B * NY * 2 + 2 * B * D * 4, 150 * B * D)
+        w["convT2_bwd"] = (B * NY * 2 + 2 * B * 5184 * 2, 2 * 2 * B * px * 5 * 64)
+        w["convT1_bwd"] = (B * 5184 * 2 + B * NYl * 2 + 2 * B * NYl * 2, 2 * 2 * B * 324 * 16 * 128)
+        w["dfeat"] = ((B * hep + Xe * hep) * 2 + B * Xe * 4, 2 * B * Xe * he)
+        w["conv_enc_bwd"] = (B * px * 4 + B * Xe * 4 + B * D * 5, 2 * B * (3 * 324 * 32 * 144 + 2 * px * 16 * 9))
+        w["conv_pack_weights"] = (32256 * 2 + 15000 * 4, 0)
     w["adam_small"] = (model._atomic_region * 32, 0)
     w["adam_weights_shadows"] = (n_w * 28 + shadow_bytes, 0)
     w["shadow_cast"] = (n_w * 4 + shadow_bytes, 0)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 11
+#define HLVAE_ABI_VERSION 12
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -68,6 +68,8 @@ typedef struct {
     int64_t o_c2w, o_c2b;        /* conv2  [32,16,3,3]  (HLVAE.py:151)                                         */
     int64_t o_t1w, o_t1b;        /* deconv_layer.0  ConvTranspose2d [32,16,4,4]  (HLVAE.py:255)                */
     int64_t o_t2w, o_t2b;        /* deconv_layer.2  ConvTranspose2d [16,y_dim,4,4]  (HLVAE.py:257-258)         */
+    int64_t o_cv_lo, cv_n;       /* conv only: arena range [o_cv_lo, o_cv_lo + cv_n) holding the representation layers, the four
+                                    convolution layers and y_layer's bias -- gradients produced by csrc/conv.hip */
     int64_t arena_size;          /* floats */
     int64_t atomic_region;       /* grads in [0, atomic_region) are accumulated with atomics and
                                     must be zero when a backward pass starts (hlvae_backward zeroes them) */
@@ -131,6 +133,8 @@ typedef struct {
     uint16_t* da2;       /* [Bp][18*18][16]                                                             */
     uint16_t* dyc; uint16_t* dycT;   /* d yc [Bp][NYlp], [NYl][Bp]                                      */
     float* dfeat;        /* [Bp][Xep] gradient of the 2592 convolutional features                       */
+    float* cvpart;       /* [256][cv_n] per-workgroup partial gradients of the arena range above; padding entries must be
+                            zero at allocation (the kernels write every real entry each step, never the padding) */
 } hlvae_ws;
 
 typedef struct hlvae_plan hlvae_plan;

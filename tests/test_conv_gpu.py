@@ -170,3 +170,29 @@ def test_conv_training_steps_run_and_reduce_the_loss(golden_dir):
         tr.step(data, mask, 2)
         nll.append(float(tr.scalars()["nll_sum"]))
     assert np.isfinite(nll).all() and nll[-1] < nll[0], nll
+
+
+def test_conv_d4_batch512_against_oracle():
+    """the BASELINE-shaped case with the convolutional model (hidden 500, latent 32, 512 rows, 25 % missing): ELBO and
+    per-entry log-likelihood against the fp64 oracle on the same weights and noise."""
+    import hlvae_oracle as orc
+    from hlvae_amd.HLVAE import HLVAE
+    dev = torch.device("cuda:0")
+    src = synthetic.make_d4(n_subjects=26, T=20, seed=100)
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    torch.manual_seed(3)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=True, max_batch=512, materialize_samples=False).to(dev)
+    state = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
+    B = 512
+    eps = torch.randn(B, 32, generator=torch.Generator().manual_seed(1))
+    data, mask = torch.tensor(src.data[:B]), torch.tensor(src.mask[:B])
+    with torch.no_grad():
+        out = model(data.to(dev), mask.to(dev), None, src.types_info, eps=eps.to(dev))
+    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, state, conv=True)
+    with torch.no_grad():
+        ref = om.forward(data, mask, eps.double())
+    elbo, elbo_ref = float(out[3].double().sum()), float(ref["log_p_x"].sum())
+    assert abs(elbo - elbo_ref) <= 1e-4 * abs(elbo_ref), (elbo, elbo_ref)          # north-star tolerance
+    assert max_abs_err(out[1].cpu(), ref["mu"]) < 3e-2
+    e = np.abs(out[3].double().cpu().numpy() - ref["log_p_x"].numpy())
+    assert np.all(e <= 5e-2 + 3e-2 * np.abs(ref["log_p_x"].numpy()))
