@@ -383,7 +383,7 @@ class HLVAE(nn.Module):
         if d.conv:          # convolutional front / back end (csrc/conv.hip)
             t.update(w1Ts=z(d.Xep, d.hep), cpack=z(_lib.CONV_PACK_ELEMS), img=z(Bp, d.D, dt=f32), yc=z(Bp, d.NYlp),
                      a2=z(Bp, 18 * 18 * 16), yv=z(Bp, d.NY, dt=f32), da2=z(Bp, 18 * 18 * 16), dyc=z(Bp, d.NYlp),
-                     dycT=z(d.NYl, Bp), dfeat=z(Bp, d.Xep, dt=f32), cvpart=z(_lib.CONV_PART_ROWS, d.cv_n, dt=f32))
+                     dycT=z(d.NYl, Bp), dfeat=z(Bp, d.Xep, dt=f32), dimg=z(Bp, d.D, dt=f32), cvpart=z(_lib.CONV_PART_ROWS, d.cv_n, dt=f32))
         t["P"] = self._arena
         t["rng"][0] = int(torch.randint(0, 2 ** 62, (1,)).item())          # Philox seed from torch's global RNG
         ws = _lib.HlvaeWs()

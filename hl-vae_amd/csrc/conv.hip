@@ -21,7 +21,7 @@
 #define CV_H1 18
 #define CV_H2 9
 #define CV_FEAT (CV_C2 * CV_H2 * CV_H2)
-#define CV_PART_ROWS 256              // workgroups of the backward kernels = rows of the partial-gradient buffer
+#define CV_PART_ROWS 512              // workgroups of the backward kernels = rows of the partial-gradient buffer
 
 // packed bf16 weights inside ws->cpack (elements)
 #define CP_C2F 0                          // conv2 forward        [32 co][160]   k = tap * 16 + ci        (144 used)
@@ -84,24 +84,29 @@ __global__ __launch_bounds__(256) void k_conv_pack(const float* __restrict__ P, 
 // conv1 3x3 (1 -> 16) + bias + ReLU + maxpool 2 from the fp32 image tile (halo = 0) into the NHWC bf16 tile a1;
 // am1 (optional): which of the 4 window positions won (first maximum, scan order), 4 = none (all <= 0)
 __device__ __forceinline__ void conv1_pool(const float* img, const float* w1s, bf16_t* a1, uint8_t* am1, int tid) {
-    for (int o = tid; o < CV_H1 * CV_H1 * CV_C1; o += 256) {
-        const int co = o & 15, pp = o >> 4, py = pp / CV_H1, px = pp % CV_H1;
-        float w[9];
+    const int co = tid & 15;                                   // 256 % 16 == 0: a thread keeps its output channel
+    float w[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = w1s[co * 9 + t];
-        const float bias = w1s[144 + co];
+    for (int t = 0; t < 9; ++t) w[t] = w1s[co * 9 + t];
+    const float bias = w1s[144 + co];
+    for (int pp = tid >> 4; pp < CV_H1 * CV_H1; pp += 16) {
+        const int py = pp / CV_H1, px = pp % CV_H1;
+        float pch[4][4];                                       // the 4 x 4 input patch of one pooling window (16-lane broadcast)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pch[i][j] = img[(2 * py + i) * IMG_LD + 2 * px + j];
         float best = 0.f;
         int sel = 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int y = 2 * py + (r >> 1), x = 2 * px + (r & 1);
             float acc = bias;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc += img[(y + t / 3) * IMG_LD + x + t % 3] * w[t];
+            for (int t = 0; t < 9; ++t) acc += pch[(r >> 1) + t / 3][(r & 1) + t % 3] * w[t];
             if (acc > best) { best = acc; sel = r; }
         }
         a1[((py + 1) * A1_LD + px + 1) * CV_C1 + co] = f2bf(best);
-        if (am1 != nullptr) am1[o] = (uint8_t)sel;
+        if (am1 != nullptr) am1[pp * CV_C1 + co] = (uint8_t)sel;
     }
 }
 
@@ -527,35 +532,36 @@ __global__ __launch_bounds__(256) void k_convT1_bwd(const bf16_t* __restrict__ d
 // backward of the convolutional encoder front end.  The forward activations are recomputed from the stored image
 // (one number per variable), which is cheaper than keeping [B, 16, 36, 36] + [B, 32, 18, 18] around.
 // ------------------------------------------------------------------------------------------------------------
-struct EncBwdSmem {
+struct EncBwdSmem {                                          // one per image group; two groups share a workgroup's LDS
     float img[IMG_LD * IMG_LD];
     float dimg[CV_D];
-    float da1[CV_H1 * CV_H1 * CV_C1];
+    float dfeat[CV_FEAT];
     float w1s[160];
     float red[16 * 10];
     float red2[32];
-    float rep[CV_D * 9];                                    // representation layer: d w[d][k < 8], d bias[d] of this workgroup
     __attribute__((aligned(16))) bf16_t a1[A1_LD * A1_LD * CV_C1];
     __attribute__((aligned(16))) bf16_t dz2[A1_LD * A1_LD * CV_C2];
-    uint8_t am1[CV_H1 * CV_H1 * CV_C1];
+    __attribute__((aligned(16))) bf16_t da1[CV_H1 * CV_H1 * CV_C1];
+    __attribute__((aligned(16))) uint8_t am1[CV_H1 * CV_H1 * CV_C1];
 };
 
-__global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ img_in, const float* __restrict__ dfeat,
+// blockDim = 256 * ngroups (1 or 2): a group of four waves owns one image at a time (its own LDS tiles); with two groups
+// the workgroup still produces ONE partial-gradient row (group 0 stores, group 1 adds).
+__global__ __launch_bounds__(512) void k_conv_enc_bwd(const float* __restrict__ img_in, const float* __restrict__ dfeat,
                                                       int ldf, const hlvae_var* __restrict__ vars,
                                                       const float* __restrict__ P, hlvae_dims d,
-                                                      const bf16_t* __restrict__ cp, const float* __restrict__ xt,
-                                                      const uint8_t* __restrict__ m8, float* __restrict__ Gpart, long part_stride,
-                                                      long part_lo, int B) {
+                                                      const bf16_t* __restrict__ cp, float* __restrict__ dimg_out,
+                                                      float* __restrict__ Gpart, long part_stride, long part_lo, int B) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int gi = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    EncBwdSmem& sm = reinterpret_cast<EncBwdSmem*>(dsm)[gi];
     // G = this workgroup's row of the partial-gradient buffer, addressed with ARENA offsets (row - part_lo)
     float* __restrict__ G = Gpart + (size_t)blockIdx.x * part_stride - part_lo;
-    extern __shared__ __attribute__((aligned(16))) char dsm[];
-    EncBwdSmem& sm = *reinterpret_cast<EncBwdSmem*>(dsm);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, r16 = lane & 15;
+    const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, r16 = lane & 15;
     for (int i = tid; i < IMG_LD * IMG_LD; i += 256) sm.img[i] = 0.f;
     for (int i = tid; i < A1_LD * A1_LD * CV_C1 / 2; i += 256) reinterpret_cast<uint32_t*>(sm.a1)[i] = 0u;
     for (int i = tid; i < A1_LD * A1_LD * CV_C2 / 2; i += 256) reinterpret_cast<uint32_t*>(sm.dz2)[i] = 0u;
-    if (tid < 160) sm.w1s[tid] = tid < 144 ? P[d.o_c1w + tid] : P[d.o_c1b + tid - 144];
-    for (int i = tid; i < CV_D * 9; i += 256) sm.rep[i] = 0.f;
+    if (tid < 160) { sm.w1s[tid] = tid < 144 ? P[d.o_c1w + tid] : P[d.o_c1b + tid - 144]; sm.red[tid] = 0.f; }
     if (tid < 32) sm.red2[tid] = 0.f;
     bf16x8_t bwd[9];
 #pragma unroll
@@ -570,11 +576,20 @@ __global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 10; ++t) w1acc[t] = 0.f;
     __syncthreads();
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int ngroups = blockDim.x >> 8;                                         // 1 or 2 image groups per workgroup
+    const int n_iter = (B + ngroups * (int)gridDim.x - 1) / (ngroups * (int)gridDim.x);   // same trip count for all groups
+    for (int it = 0; it < n_iter; ++it) {
+        const int b = (it * gridDim.x + blockIdx.x) * ngroups + gi;
+        const bool live = b < B;
+        const int bb = live ? b : 0;
         for (int dd = tid; dd < CV_D; dd += 256) {
-            sm.img[(dd / CV_W + 1) * IMG_LD + dd % CV_W + 1] = img_in[(size_t)b * CV_D + dd];
-            sm.dimg[dd] = 0.f;
+            sm.img[(dd / CV_W + 1) * IMG_LD + dd % CV_W + 1] = img_in[(size_t)bb * CV_D + dd];
         }
+        if (it > 0) {                                   // a1 / dz2 were reused as scratch: restore their zero halos
+            for (int i = tid; i < A1_LD * A1_LD * CV_C1 / 2; i += 256) reinterpret_cast<uint32_t*>(sm.a1)[i] = 0u;
+            for (int i = tid; i < A1_LD * A1_LD * CV_C2 / 2; i += 256) reinterpret_cast<uint32_t*>(sm.dz2)[i] = 0u;
+        }
+        for (int i = tid; i < CV_FEAT; i += 256) sm.dfeat[i] = live ? dfeat[(size_t)bb * ldf + i] : 0.f;
         __syncthreads();
         conv1_pool(sm.img, sm.w1s, sm.a1, sm.am1, tid);
         __syncthreads();
@@ -587,7 +602,7 @@ __global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ 
                 const float v = fmaxf(c[r], 0.f);
                 if (v > best) { best = v; sel = r; }
             }
-            const float g = best > 0.f ? dfeat[(size_t)b * ldf + co * 81 + wi] : 0.f;
+            const float g = best > 0.f ? sm.dfeat[co * 81 + wi] : 0.f;
             b2acc[co >> 4] += g;
             const int y0 = 2 * (wi / CV_H2), x0 = 2 * (wi % CV_H2);
 #pragma unroll
@@ -607,7 +622,7 @@ __global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ 
                 const int m = mt * 16 + 4 * q + r;
                 if (m < CV_H1 * CV_H1) {
                     const bool on = bf2f(sm.a1[((m / CV_H1 + 1) * A1_LD + m % CV_H1 + 1) * CV_C1 + r16]) > 0.f;
-                    sm.da1[m * CV_C1 + r16] = on ? acc[r] : 0.f;
+                    sm.da1[m * CV_C1 + r16] = f2bf(on ? acc[r] : 0.f);
                 }
             }
         }
@@ -651,7 +666,7 @@ __global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ 
 #pragma unroll
             for (int t = 0; t < 9; ++t) w[t] = sm.w1s[co * 9 + t];
             for (int pp = tid >> 4; pp < CV_H1 * CV_H1; pp += 16) {
-                const float g = sm.da1[pp * CV_C1 + co];
+                const float g = bf2f(sm.da1[pp * CV_C1 + co]);
                 const int sel = sm.am1[pp * CV_C1 + co];
                 if (g != 0.f && sel < 4) {
                     const int y = 2 * (pp / CV_H1) + (sel >> 1), x = 2 * (pp % CV_H1) + (sel & 1);
@@ -660,79 +675,156 @@ __global__ __launch_bounds__(256) void k_conv_enc_bwd(const float* __restrict__ 
                     for (int t = 0; t < 9; ++t) {
                         const int yy = y + t / 3, xx = x + t % 3;                  // halo coordinates
                         w1acc[t] += g * sm.img[yy * IMG_LD + xx];
-                        if (yy >= 1 && yy <= CV_W && xx >= 1 && xx <= CV_W) atomicAdd(&sm.dimg[(yy - 1) * CV_W + xx - 1], g * w[t]);
                     }
                 }
             }
         }
-        __syncthreads();
-        // representation layer (HLVAE.py:91-102): d w[d][k] += g x_k, d bias[d] += g for observed cat / ordinal variables
-        for (int dd = tid; dd < CV_D; dd += 256) {
-            const hlvae_var var = vars[dd];
-            if ((var.kind == HLVAE_CAT || var.kind == HLVAE_ORDINAL) && m8[(size_t)b * d.D + dd]) {
-                const float g = sm.dimg[dd];                       // variable dd is always this thread's: plain adds
-                const int cls = (int)xt[(size_t)b * d.D + dd];
-                sm.rep[dd * 9 + 8] += g;
-                if (var.kind == HLVAE_CAT) {
-                    if (cls >= 0) sm.rep[dd * 9 + cls] += g;
-                } else {
-                    for (int k = 0; k <= cls && k < var.ncls; ++k) sm.rep[dd * 9 + k] += g;
+        // image gradient on the MFMA units: S[pos][tap] = sum_co dz1[pos][co] w1[co][tap] (M = 1296 conv1 output positions,
+        // N = 9 taps, K = 16 channels), where dz1 is expanded on the fly from the pooled gradient and the winner index (no
+        // dense [36][36][16] tile).  S goes to LDS (the a1 / dz2 tiles are free now) in two passes of 19 image rows, and
+        // every pixel then GATHERS its nine S values: LDS float atomics run at ~1 lane per 2.5 clocks on this part and the
+        // scatter formulations spent 55-90 k clocks here.
+        {
+            float* S = reinterpret_cast<float*>(sm.a1);                             // [19 * 36][9] floats <= a1 + dz2 (38.4 KB)
+            bf16x8_t bw1;                                                            // B[n = tap][k = co], k >= 16 is zero
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                bw1[e] = (__bf16)((q < 2 && r16 < 9) ? sm.w1s[(q * 8 + e) * 9 + r16] : 0.f);
+            for (int pass = 0; pass < 2; ++pass) {
+                const int row0 = pass * 17, pos0 = row0 * CV_W;                     // S rows [row0, row0 + 19)
+                for (int mt = wave + (pos0 >> 4); mt * 16 < pos0 + 19 * CV_W; mt += 4) {
+                    const int pos = mt * 16 + r16, Y = pos / CV_W, X = pos % CV_W;
+                    const int pp = (Y >> 1) * CV_H1 + (X >> 1);
+                    const uint32_t r = (uint32_t)((Y & 1) * 2 + (X & 1));
+                    bf16x8_t a;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
+                    if (q < 2) {
+                        const uint2 am = *reinterpret_cast<const uint2*>(sm.am1 + pp * CV_C1 + q * 8);
+                        const uint4 g = *reinterpret_cast<const uint4*>(sm.da1 + pp * CV_C1 + q * 8);
+                        const uint32_t amw[2] = {am.x, am.y};
+                        const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const uint32_t sel = (amw[e >> 2] >> (8 * (e & 3))) & 0xffu;
+                            const uint16_t gv = (uint16_t)((e & 1) ? (gw[e >> 1] >> 16) : (gw[e >> 1] & 0xffffu));
+                            a[e] = __builtin_bit_cast(__bf16, (uint16_t)(sel == r ? gv : 0));
+                        }
+                    }
+                    const f32x4_t acc = mfma16(a, bw1, F4Z);
+                    if (r16 < 9) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int po = mt * 16 + 4 * q + rr - pos0;
+                            if (po >= 0 && po < 19 * CV_W) S[po * 9 + r16] = acc[rr];
+                        }
+                    }
                 }
+                __syncthreads();
+                for (int pix = tid + pass * 18 * CV_W; pix < (pass + 1) * 18 * CV_W; pix += 256) {   // pixel rows [18 pass, +18)
+                    const int y = pix / CV_W, x = pix % CV_W;
+                    float v = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int Y = y - t / 3 + 1, X = x - t % 3 + 1;
+                        if (Y >= 0 && Y < CV_W && X >= 0 && X < CV_W) v += S[((Y - row0) * CV_W + X) * 9 + t];
+                    }
+                    sm.dimg[pix] = v;
+                }
+                __syncthreads();
             }
         }
         __syncthreads();
+        // gradient of the image (one number per variable): the representation layer's reduction over the batch is a
+        // separate kernel (k_conv_rep_grad)
+        if (live)
+            for (int dd = tid; dd < CV_D; dd += 256) dimg_out[(size_t)b * CV_D + dd] = sm.dimg[dd];
+        __syncthreads();
     }
-    // flush: conv2 weight / bias, conv1 weight / bias
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int tap = wave + 4 * j;
-            if (tap < 9)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) G[d.o_c2w + ((i * 16 + 4 * q + r) * 16 + r16) * 9 + tap] = wacc[i][j][r];
-        }
-    if (tid < 160) sm.red[tid] = 0.f;
-    __syncthreads();
+    // per-group reductions in LDS, then group 0 stores its partial row and group 1 adds to it
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float v = b2acc[i];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (q == 0) atomicAdd(&sm.red2[i * 16 + r16], v);          // LDS: the four waves own different pooling windows
+        if (q == 0) atomicAdd(&sm.red2[i * 16 + r16], v);          // the four waves own different pooling windows
     }
 #pragma unroll
     for (int t = 0; t < 10; ++t) atomicAdd(&sm.red[(tid & 15) * 10 + t], w1acc[t]);
     __syncthreads();
-    if (tid < 160) {
-        const int co = tid / 10, t = tid % 10;
-        G[t < 9 ? d.o_c1w + co * 9 + t : d.o_c1b + co] = sm.red[tid];
-    }
-    if (tid < 32) G[d.o_c2b + tid] = sm.red2[tid];
-    for (int dd = tid; dd < CV_D; dd += 256) {
-        const hlvae_var var = vars[dd];
-        if (var.kind == HLVAE_CAT || var.kind == HLVAE_ORDINAL) {
-            G[var.rb_off] = sm.rep[dd * 9 + 8];
-            for (int k = 0; k < var.ncls; ++k) G[var.r_off + k] = sm.rep[dd * 9 + k];
+    for (int phase = 0; phase < ngroups; ++phase) {
+        if (gi == phase) {
+            const bool add = phase == 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int tap = wave + 4 * j;
+                    if (tap < 9)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* dst = G + d.o_c2w + ((i * 16 + 4 * q + r) * 16 + r16) * 9 + tap;
+                            *dst = add ? *dst + wacc[i][j][r] : wacc[i][j][r];
+                        }
+                }
+            if (tid < 160) {
+                float* dst = G + (tid % 10 < 9 ? d.o_c1w + (tid / 10) * 9 + tid % 10 : d.o_c1b + tid / 10);
+                *dst = add ? *dst + sm.red[tid] : sm.red[tid];
+            }
+            if (tid < 32) {
+                float* dst = G + d.o_c2b + tid;
+                *dst = add ? *dst + sm.red2[tid] : sm.red2[tid];
+            }
         }
+        __threadfence_block();            // workgroup scope is enough (same CU, same L1); a device-scope fence writes back L2
+        __syncthreads();
     }
+}
+
+// representation layer (HLVAE.py:91-102): d w[d][k] = sum_b g[b][d] x_k[b][d], d bias[d] = sum_b g[b][d] over the observed
+// rows, x = one-hot (cat) or thermometer (ordinal) of the packed class index.  grid (ceil(D / 256), row chunks)
+__global__ __launch_bounds__(256) void k_conv_rep_grad(const float* __restrict__ dimg, const float* __restrict__ xt,
+                                                       const uint8_t* __restrict__ m8, const hlvae_var* __restrict__ vars, int D,
+                                                       int B, float* __restrict__ G) {
+    const int dd = blockIdx.x * 256 + threadIdx.x;
+    if (dd >= D) return;
+    const hlvae_var var = vars[dd];
+    if (var.kind != HLVAE_CAT && var.kind != HLVAE_ORDINAL) return;
+    const int rows = (B + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * rows, b1 = min(B, b0 + rows);
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+#pragma unroll 4
+    for (int b = b0; b < b1; ++b) {
+        const size_t o = (size_t)b * D + dd;
+        const float g = m8[o] ? dimg[o] : 0.f;                   // three independent loads per row, no branch around them
+        const int cls = (int)xt[o];
+        acc[8] += g;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += (var.kind == HLVAE_CAT ? k == cls : k <= cls) ? g : 0.f;
+    }
+    if (acc[8] != 0.f) atomicAdd(G + var.rb_off, acc[8]);
+    for (int k = 0; k < var.ncls; ++k)
+        if (acc[k] != 0.f) atomicAdd(G + var.r_off + k, acc[k]);
 }
 
 // G[lo + i] += sum over the workgroups' partial rows (coalesced across i): replaces one atomic per weight and workgroup,
 // which on MI355X serialises in the fabric when 256 workgroups on 8 XCDs hit the same address
 __global__ __launch_bounds__(256) void k_conv_wgrad_reduce(const float* __restrict__ part, int nrows, long n, float* __restrict__ G) {
+    // grid (ceil(n / 256), 8): workgroup (x, y) sums rows y, y + 8, ... of its 256 columns, then 8-way atomics
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 3 < nrows; r += 4) {
+    int r = blockIdx.y;
+    for (; r + 24 < nrows; r += 32) {
         s0 += part[(size_t)r * n + i];
-        s1 += part[(size_t)(r + 1) * n + i];
-        s2 += part[(size_t)(r + 2) * n + i];
-        s3 += part[(size_t)(r + 3) * n + i];
+        s1 += part[(size_t)(r + 8) * n + i];
+        s2 += part[(size_t)(r + 16) * n + i];
+        s3 += part[(size_t)(r + 24) * n + i];
     }
-    for (; r < nrows; ++r) s0 += part[(size_t)r * n + i];
-    G[i] += (s0 + s1) + (s2 + s3);
+    for (; r < nrows; r += 8) s0 += part[(size_t)r * n + i];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (v != 0.f) atomicAdd(G + i, v);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -793,18 +885,26 @@ int hl_launch_conv_enc_bwd(const hlvae_plan* p, const hlvae_ws* ws, int B, hipSt
     static bool attr_set = false;
     if (!attr_set) {
         HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_enc_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(EncBwdSmem)));
+                                     (int)(2 * sizeof(EncBwdSmem))));
         attr_set = true;
     }
     {
         HL_PROF("conv_enc_bwd", s);
-        k_conv_enc_bwd<<<grid, 256, sizeof(EncBwdSmem), s>>>(ws->img, ws->dfeat, d.Xep, p->vars_dev, ws->P, d, ws->cpack, ws->xt,
-                                                             ws->m8, ws->cvpart, d.cv_n, d.o_cv_lo, B);
+        // same number of workgroups (= partial rows) as the decoder kernels; a workgroup without images stores zeros
+        // one image group (256 threads) per workgroup, two workgroups per CU (77 KB of LDS each); the kernel also runs
+        // with 512 threads = two groups sharing one partial row (measured equal within 7 %)
+        k_conv_enc_bwd<<<grid, 256, sizeof(EncBwdSmem), s>>>(ws->img, ws->dfeat, d.Xep, p->vars_dev, ws->P, d, ws->cpack,
+                                                             ws->dimg, ws->cvpart, d.cv_n, d.o_cv_lo, B);
+        HL_LAUNCH_CHECK();
+    }
+    {
+        HL_PROF("conv_rep_grad", s);
+        k_conv_rep_grad<<<dim3((CV_D + 255) / 256, 64), 256, 0, s>>>(ws->dimg, ws->xt, ws->m8, p->vars_dev, d.D, B, ws->G);
         HL_LAUNCH_CHECK();
     }
     {   // all three backward kernels have filled their columns of the partial rows: fold them into the gradient arena
         HL_PROF("conv_wgrad_reduce", s);
-        k_conv_wgrad_reduce<<<(int)((d.cv_n + 255) / 256), 256, 0, s>>>(ws->cvpart, grid, d.cv_n, ws->G + d.o_cv_lo);
+        k_conv_wgrad_reduce<<<dim3((unsigned)((d.cv_n + 255) / 256), 8), 256, 0, s>>>(ws->cvpart, grid, d.cv_n, ws->G + d.o_cv_lo);
         HL_LAUNCH_CHECK();
     }
     return 0;

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 12
+#define HLVAE_ABI_VERSION 13
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -133,7 +133,8 @@ typedef struct {
     uint16_t* da2;       /* [Bp][18*18][16]                                                             */
     uint16_t* dyc; uint16_t* dycT;   /* d yc [Bp][NYlp], [NYl][Bp]                                      */
     float* dfeat;        /* [Bp][Xep] gradient of the 2592 convolutional features                       */
-    float* cvpart;       /* [256][cv_n] per-workgroup partial gradients of the arena range above; padding entries must be
+    float* dimg;         /* [Bp][1296] gradient of img                                                  */
+    float* cvpart;       /* [512][cv_n] per-workgroup partial gradients of the arena range above; padding entries must be
                             zero at allocation (the kernels write every real entry each step, never the padding) */
 } hlvae_ws;
 
