@@ -100,7 +100,7 @@ def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps, conv=False
         eps = torch.randn(len(rows), dims[2], generator=g, dtype=torch.float64)
         out = om.forward(data, mask, eps)
         nll = om.loss_function(out["log_p_x"]).sum()
-        mo.step_metrics([p.detach() for p in out["p_params"]], data, mask, src.types_info, st["_log_vy_pos"].detach())
+        mo.step_metrics([p.detach() for p in out["p_params"]], data, mask, src.types_info, st["_log_vy_pos"].detach(), conv=conv)
         loss = nll * P_total / P_batch
         if kl == "normal":
             loss = loss + orc.standard_normal_kl(out["mu"], out["log_var"])

@@ -598,7 +598,9 @@ __global__ __launch_bounds__(1024) void k_elbo_finalize(const float* __restrict_
 #define HL_MET_CHUNKS 16
 __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict__ xt, const uint8_t* __restrict__ m8,
                                                          const float* __restrict__ xhat, const hlvae_var* __restrict__ vars,
-                                                         int B, int D, float* __restrict__ part) {
+                                                         int B, int D, float* __restrict__ part, int conv) {
+    // conv (types_info['conv'], read_functions.py:366-369): continuous data are divided by 255 (x_hat too for pos / count)
+    // and the range normalisation is dropped
     __shared__ float red[6][4][64];
     const int d = blockIdx.x * 64 + threadIdx.x, g = threadIdx.y;
     const int rpc = (B + HL_MET_CHUNKS - 1) / HL_MET_CHUNKS;
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
         for (int b = b_lo + g; b < b_hi; b += 4) {
             const size_t o = (size_t)b * D + d;
             float x = xt[o];
-            const float xh = xhat[o];
+            float xh = xhat[o];
             float e;
             if (kind == HLVAE_CAT) {
                 e = (fmaxf(x, 0.f) != xh) ? 1.f : 0.f;           // argmax of an all-zero one-hot row is class 0
@@ -618,6 +620,10 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
                 e = fabsf(x - xh) / (float)K;
             } else {
                 if (kind == HLVAE_POS) x = expm1f(x);            // the target buffer holds log1p(x) for pos
+                if (conv) {
+                    x *= 1.f / 255.f;
+                    if (kind != HLVAE_REAL) xh *= 1.f / 255.f;
+                }
                 mx = fmaxf(mx, x);
                 mn = fminf(mn, x);
                 e = (xh - x) * (xh - x);
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
 }
 
 __global__ void k_metrics_finish(const float* __restrict__ part, const hlvae_var* __restrict__ vars, int B, int D,
-                                 float* __restrict__ err) {
+                                 float* __restrict__ err, int conv) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
     float mx = -3.4e38f, mn = 3.4e38f, s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -653,7 +659,7 @@ __global__ void k_metrics_finish(const float* __restrict__ part, const hlvae_var
     const int kind = vars[d].kind;
     const bool disc = kind == HLVAE_CAT || kind == HLVAE_ORDINAL;
     float inv2 = 1.f;
-    if (!disc) {
+    if (!disc && !conv) {
         float nt = mx - mn;
         if (nt == 0.f) nt = 1.f;                                 // read_functions.py:372
         inv2 = 1.f / (nt * nt);
@@ -672,11 +678,11 @@ int hl_launch_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float
     {
         HL_PROF("metrics_partial", s);
         k_metrics_partial<<<dim3((d.D + 63) / 64, HL_MET_CHUNKS), dim3(64, 4), 0, s>>>(ws->xt, ws->m8, ws->xhat, p->vars_dev, B,
-                                                                                      d.D, ws->metpart);
+                                                                                      d.D, ws->metpart, d.conv);
     }
     HL_LAUNCH_CHECK();
     HL_PROF("metrics_finish", s);
-    k_metrics_finish<<<(d.D + 255) / 256, 256, 0, s>>>(ws->metpart, p->vars_dev, B, d.D, err);
+    k_metrics_finish<<<(d.D + 255) / 256, 256, 0, s>>>(ws->metpart, p->vars_dev, B, d.D, err, d.conv);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -61,8 +61,8 @@ def statistics(params_full, blocks, D, log_vy_pos):
     return mean, mode
 
 
-def error_computation(x_train, x_hat, blocks, mask):
-    """read_functions.py:342-386 with true_miss_mask = ones, conv False, dim 0.
+def error_computation(x_train, x_hat, blocks, mask, conv=False):
+    """read_functions.py:342-386 with true_miss_mask = ones, dim 0 (conv: :366-369).
     Returns per-variable (error_observed, error_missing, error_all) BEFORE the per-type sqrt
     bookkeeping, and the same after it (:388-393)."""
     err = torch.zeros_like(x_train)
@@ -72,6 +72,11 @@ def error_computation(x_train, x_hat, blocks, mask):
             e = (xt != xh).to(DT)
         elif b["type"] == "ordinal":
             e = torch.abs(xt - xh) / b["K"]
+        elif conv:
+            xt = xt / 255                                                 # :367
+            if b["type"] in ("pos", "count"):
+                xh = xh / 255                                             # :368-369
+            e = (xh - xt) ** 2
         else:
             # get_norm_terms (HL_VAE/utils.py:216-225) fills a torch.empty(sz) -> FLOAT32 vector, and
             # read_functions.py:373 squares it in float32 before the float64 division.
@@ -95,12 +100,12 @@ def error_computation(x_train, x_hat, blocks, mask):
     return fin(e_obs), fin(e_mis), fin(e_all)
 
 
-def step_metrics(p_params, data, mask, types_info, log_vy_pos):
+def step_metrics(p_params, data, mask, types_info, log_vy_pos, conv=False):
     """training.py:84-101 up to error_computation; returns (x_hat_mean, e_obs, e_mis, e_all)."""
     blocks = block_indices(types_info)
     B, D = mask.shape
     full = params_by_key(p_params, blocks, B, len(types_info["param_indexes"]))
     xt = discrete_transform(data, blocks, D)
     xh, _ = statistics(full, blocks, D, log_vy_pos)
-    e_obs, e_mis, e_all = error_computation(xt, xh, blocks, mask)
+    e_obs, e_mis, e_all = error_computation(xt, xh, blocks, mask, conv=conv)
     return xh, e_obs, e_mis, e_all

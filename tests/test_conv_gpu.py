@@ -196,3 +196,22 @@ def test_conv_d4_batch512_against_oracle():
     assert max_abs_err(out[1].cpu(), ref["mu"]) < 3e-2
     e = np.abs(out[3].double().cpu().numpy() - ref["log_p_x"].numpy())
     assert np.all(e <= 5e-2 + 3e-2 * np.abs(ref["log_p_x"].numpy()))
+
+
+def test_conv_step_metrics_against_reference_fixture(golden_dir):
+    """row M with the convolutional model: imputed values and per-variable errors (read_functions.py:268-412) against what
+    the reference computed for the fixture batch (its real-valued means live on the [0, 1] scale of the sigmoid while the data
+    are raw pixel values: the reference compares them as they are, so do we)."""
+    g, src, dims, model, om, st, dev = _setup(golden_dir)
+    data, mask = torch.tensor(src.data[:8], device=dev), torch.tensor(g["mask"], device=dev)
+    with torch.no_grad():
+        model(data, mask, None, src.types_info, eps=torch.tensor(g["eps"], device=dev))
+    e_obs, e_mis, e_all, xhat = model.step_metrics(8)
+    disc = np.isin(model.plan.kind, [3, 4])
+    xh, xr = xhat.cpu().numpy(), g["x_hat_mean"]
+    assert np.mean(xh[:, disc] == xr[:, disc]) > 0.97
+    assert np.allclose(xh[:, ~disc], xr[:, ~disc], rtol=3e-2, atol=3e-2)
+    eo, em = e_obs.cpu().numpy(), e_mis.cpu().numpy()
+    assert np.allclose(eo[~disc], g["err_observed"][~disc], rtol=5e-2, atol=5e-3)
+    assert np.allclose(em[~disc], g["err_missing"][~disc], rtol=5e-2, atol=5e-3)
+    assert np.mean(np.abs(eo[disc] - g["err_observed"][disc]) <= 1.0 / 4) > 0.97

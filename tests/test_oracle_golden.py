@@ -120,6 +120,11 @@ def test_d4_conv_small(golden_dir):
                    g["grad_slice__VAE_encoder_common_layers.0.weight"]) < 1e-9
     ts = model.test_samples(torch.tensor(d), torch.tensor(g["mask"]))
     assert rel_err(ts["mu"].numpy(), g["test_mu"]) < TOL and rel_err(ts["log_p_x"].numpy(), g["test_log_p_x"]) < TOL
+    # row M under conv (read_functions.py:366-369)
+    xh, e_obs, e_mis, e_all = mo.step_metrics([p.detach() for p in out["p_params"]], torch.tensor(d), torch.tensor(g["mask"]),
+                                              src.types_info, st["_log_vy_pos"].detach(), conv=True)
+    assert rel_err(xh.numpy(), g["x_hat_mean"]) < TOL
+    assert rel_err(e_obs.numpy(), g["err_observed"]) < 1e-7 and rel_err(e_mis.numpy(), g["err_missing"]) < 1e-7
 
 
 def test_gp_kl(golden_dir):
