@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--prefetch", action="store_true",
                     help="run the NEXT batch's input stage on a side stream inside each step (measured slower on MI355X: a forked "
                          "branch in the HIP graph costs more than the 31 us it hides; DESIGN.md section 5)")
+    ap.add_argument("--feed", default="fp64", choices=["fp64", "compact"],
+                    help="fp64: the reference's expanded fp64 batch tensors resident in HBM (drop-in call surface); compact: the "
+                         "whole dataset resident in HBM at 5 B/entry, a batch = a vector of row indices (SURVEY 8(f).3)")
     ap.add_argument("--conv", action="store_true",
                     help="convolutional encoder/decoder (conv_hivae = True, what config/hlvae_config_file.txt:51 selects) "
                          "instead of the MLP the north star names")
@@ -151,7 +154,17 @@ def main():
     # (row A depends on the data only).  Every step still runs exactly one input stage inside the timed region.
     nxt = lambda i: (ring[(i + 1) % len(ring)]["data"], ring[(i + 1) % len(ring)]["mask"])
     pipelined = a.prefetch
-    if use_graph:
+    compact = a.feed == "compact"
+    if compact:
+        from hlvae_amd.datafeed import CompactDataset
+        assert kl != "gp", "--feed compact with --kl gp: not wired in bench.py"
+        dsd = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+        for b in ring:
+            b["rows_dev"] = torch.tensor(b["rows"].astype(np.int32), device=dev)
+        if use_graph:
+            for i, b in enumerate(ring):
+                trainer.capture_rows(i, dsd, b["rows_dev"], b["P_batch"] * world)
+    elif use_graph:
         for i, b in enumerate(ring):
             trainer.capture(i, b["data"], b["mask"], b["P_batch"] * world, train_x=b["labels"],
                             prefetch=nxt(i) if pipelined else None)
@@ -167,6 +180,8 @@ def main():
             b = ring[i % len(ring)]
             if use_graph:
                 trainer.replay(i % len(ring))
+            elif compact:
+                trainer.step_rows(dsd, b["rows_dev"], b["P_batch"] * world)
             else:
                 trainer.step(b["data"], b["mask"], b["P_batch"] * world, train_x=b["labels"],
                              prefetch=nxt(i) if pipelined else None)
@@ -195,7 +210,7 @@ def main():
     if rank == 0:
         print(f"[bench] {world} GPU(s): {value:.0f} samples/s, {1e3 * dt / a.steps:.4f} ms/step", file=sys.stderr, flush=True)
     from hlvae_amd import roofline
-    roof = roofline.measure_dominant_kernel(trainer, ring[0], a.steps) if rank == 0 else None
+    roof = roofline.measure_dominant_kernel(trainer, ring[0], a.steps, ds=dsd if compact else None) if rank == 0 else None
     if roof is not None:      # HBM traffic from PMC counters is collected offline (separate rocprofv3 --pmc passes)
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
@@ -218,7 +233,9 @@ def main():
             "config": {"workload": "configs[1]: synthetic 1k-sample D4 Het-HealthMNIST set (324 real + 972 cat5, 25 pct missing), "
                                    + ("convolutional encoder/decoder (conv 1-16-32 + 2592-500-32 | 32-500-2592 + deconv 32-16-5), "
                                       if a.conv else "MLP [5184,[500],32,[500],5], ")
-                                   + f"batch {a.batch} rows/GPU, fp64 inputs resident in HBM",
+                                   + f"batch {a.batch} rows/GPU, "
+                                   + ("compact dataset (5 B/entry) resident in HBM, batches = row-index vectors" if compact
+                                      else "fp64 inputs resident in HBM"),
                        "kl": a.kl, "hip_graph": use_graph, "input_stage_prefetch": pipelined, "rows_per_step_per_gpu": rows_per_step,
                        "final_nll_sum": nll_last},
             "roofline": roof, "cpu_baseline": cpu,

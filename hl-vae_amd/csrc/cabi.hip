@@ -20,7 +20,10 @@ int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
 int hl_launch_mid_fwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, int, uint64_t, int, int, hipStream_t);
 int hl_launch_mid_bwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, const float*, float, int, int, hipStream_t);
 int hl_adam(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t);
-int hl_launch_conv_enc_fwd(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, int, hipStream_t);
+int hl_launch_conv_enc_fwd(const hlvae_plan*, const hlvae_ws*, const double*, const double*, const float*, const uint8_t*,
+                           const int32_t*, int, int, hipStream_t);
+int hl_launch_stats_compact(const hlvae_plan*, const hlvae_ws*, const float*, const uint8_t*, const int32_t*, int, hipStream_t);
+int hl_launch_pack_compact(const hlvae_plan*, const hlvae_ws*, const float*, const uint8_t*, const int32_t*, int, int, hipStream_t);
 int hl_launch_conv_dec_fwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
 int hl_launch_conv_dec_bwd(const hlvae_plan*, const hlvae_ws*, int, int, hipStream_t);
 int hl_launch_conv_enc_bwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
@@ -219,9 +222,27 @@ int hlvae_normalize_pack(const hlvae_plan* p, const hlvae_ws* ws, const double* 
     CHECK_B();
     if (d.conv) {   // representation layer + conv1 + conv2 (HLVAE.py:293-308) produce the encoder input
         HL_REQUIRE(ws->cpack && ws->img, HLVAE_EINVAL, "convolutional model without its workspace buffers");
-        return hl_launch_conv_enc_fwd(p, ws, data, mask, B, Bp, st);
+        return hl_launch_conv_enc_fwd(p, ws, data, mask, nullptr, nullptr, nullptr, B, Bp, st);
     }
     return hl_launch_pack(p, ws, data, mask, B, Bp, st);
+}
+
+int hlvae_feed_stats(const hlvae_plan* p, const hlvae_ws* ws, const float* values, const uint8_t* mask8, const int32_t* rows,
+                     int B, hlvae_stream s) {
+    CHECK_B();
+    HL_REQUIRE(values && mask8 && rows, HLVAE_EINVAL, "feed_stats: null pointer");
+    return hl_launch_stats_compact(p, ws, values, mask8, rows, B, st);
+}
+
+int hlvae_feed_pack(const hlvae_plan* p, const hlvae_ws* ws, const float* values, const uint8_t* mask8, const int32_t* rows,
+                    int B, hlvae_stream s) {
+    CHECK_B();
+    HL_REQUIRE(values && mask8 && rows, HLVAE_EINVAL, "feed_pack: null pointer");
+    if (d.conv) {
+        HL_REQUIRE(ws->cpack && ws->img, HLVAE_EINVAL, "convolutional model without its workspace buffers");
+        return hl_launch_conv_enc_fwd(p, ws, nullptr, nullptr, values, mask8, rows, B, Bp, st);
+    }
+    return hl_launch_pack_compact(p, ws, values, mask8, rows, B, Bp, st);
 }
 
 int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int sample, uint64_t rng_host_offset,

@@ -188,8 +188,24 @@ __device__ __forceinline__ void conv2_mfma(const bf16_t* a1, const bf16_t* __res
     }
 }
 
+// value of one variable from the compact feed (csrc/feed.hip): cv = raw value | class index | level - 1
+__device__ __forceinline__ float conv_input_value_compact(const hlvae_var& var, float cv, const float* __restrict__ P,
+                                                          const double* __restrict__ sums, int n_stat) {
+    if (var.kind == HLVAE_CAT || var.kind == HLVAE_ORDINAL) {
+        float rep = P[var.rb_off];
+        const int cls = (int)cv;
+        for (int k = 0; k < var.ncls; ++k)
+            if (var.kind == HLVAE_CAT ? k == cls : k <= cls) rep += P[var.r_off + k];
+        return rep;
+    }
+    double x = (double)cv;
+    float tv;
+    return conv_input_value(var, &x, P, sums, n_stat, tv);
+}
+
 __global__ __launch_bounds__(256) void k_conv_enc_fwd(
-    const double* __restrict__ data, const double* __restrict__ mask, const hlvae_var* __restrict__ vars,
+    const double* __restrict__ data, const double* __restrict__ mask, const float* __restrict__ cvals,
+    const uint8_t* __restrict__ cmask, const int32_t* __restrict__ crows, const hlvae_var* __restrict__ vars,
     const float* __restrict__ P, hlvae_dims d, const double* __restrict__ sums, float* __restrict__ norm,
     const bf16_t* __restrict__ cp, bf16_t* __restrict__ xn, bf16_t* __restrict__ xnT, float* __restrict__ xt,
     uint8_t* __restrict__ m8, float* __restrict__ img_out, int B, int Bp) {
@@ -204,9 +220,18 @@ __global__ __launch_bounds__(256) void k_conv_enc_fwd(
     __syncthreads();
     for (int dd = tid; dd < CV_D; dd += 256) {
         const hlvae_var var = vars[dd];
-        const bool ob = mask[(size_t)b * d.D + dd] != 0.0;
-        float tv;
-        const float rep = conv_input_value(var, data + (size_t)b * d.X + var.xoff, P, sums, d.n_stat, tv);
+        bool ob;
+        float tv, rep;
+        if (cvals != nullptr) {                                               // compact device-resident feed
+            const size_t o = (size_t)crows[b] * d.D + dd;
+            ob = cmask[o] != 0;
+            tv = cvals[o];
+            rep = conv_input_value_compact(var, tv, P, sums, d.n_stat);
+            if (var.kind == HLVAE_POS) tv = log1pf(tv);
+        } else {
+            ob = mask[(size_t)b * d.D + dd] != 0.0;
+            rep = conv_input_value(var, data + (size_t)b * d.X + var.xoff, P, sums, d.n_stat, tv);
+        }
         const float val = ob ? rep : 0.f;                                     // HLVAE.py:304 (representation * mask)
         img[(dd / CV_W + 1) * IMG_LD + dd % CV_W + 1] = val;
         img_out[(size_t)b * CV_D + dd] = val;
@@ -837,10 +862,10 @@ int hl_conv_pack_weights(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s)
     return 0;
 }
 
-int hl_launch_conv_enc_fwd(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask, int B, int Bp,
-                           hipStream_t s) {
+int hl_launch_conv_enc_fwd(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask, const float* cvals,
+                           const uint8_t* cmask, const int32_t* crows, int B, int Bp, hipStream_t s) {
     HL_PROF("conv_enc_fwd", s);
-    k_conv_enc_fwd<<<B, 256, 0, s>>>(data, mask, p->vars_dev, ws->P, p->d, ws->sums, ws->norm, ws->cpack, ws->xn, ws->xnT,
+    k_conv_enc_fwd<<<B, 256, 0, s>>>(data, mask, cvals, cmask, crows, p->vars_dev, ws->P, p->d, ws->sums, ws->norm, ws->cpack, ws->xn, ws->xnT,
                                      ws->xt, ws->m8, ws->img, B, Bp);
     HL_LAUNCH_CHECK();
     return 0;

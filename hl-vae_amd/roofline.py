@@ -85,7 +85,7 @@ def algorithmic_work(model, B):
     return w
 
 
-def measure_dominant_kernel(trainer, batch, steps, eager_steps=None):
+def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None):
     """Run `steps` eager steps with the library's per-kernel HIP events on, find the kernel with the
     largest total time and price it against its roofline.  Returns the bench.py 'roofline' object
     (plus the per-kernel table for DESIGN.md / profiles)."""
@@ -95,16 +95,26 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None):
     n = max(5, min(n, 100))
     B = batch["data"].shape[0]
     import torch
+    def one():
+        if ds is not None:
+            trainer.step_rows(ds, batch["rows_dev"], batch["P_batch"])
+        else:
+            trainer.step(batch["data"], batch["mask"], batch["P_batch"], train_x=batch.get("labels"))
+
     for _ in range(3):
-        trainer.step(batch["data"], batch["mask"], batch["P_batch"], train_x=batch.get("labels"))
+        one()
     torch.cuda.synchronize()
     lib.hlvae_prof_enable(1)
     for _ in range(n):
-        trainer.step(batch["data"], batch["mask"], batch["P_batch"], train_x=batch.get("labels"))
+        one()
     lib.hlvae_prof_enable(0)
     buf = C.create_string_buffer(1 << 16)
     _lib.check(lib.hlvae_prof_report(buf, len(buf)), "hlvae_prof_report")
     work = algorithmic_work(m, B)
+    if ds is not None:      # compact feed: 5 B per entry in instead of the expanded fp64 matrices
+        d_ = m._dims
+        work["normalize_pack"] = (B * d_.D * 5 + 2 * B * d_.Xp * 2 + B * d_.D * 5, 0)
+        work["colstats"] = (B * d_.n_stat * 5, 0)
     if getattr(trainer, "gp", None) is not None and batch.get("labels") is not None and hasattr(trainer.gp, "_group"):
         S, T = trainer.gp._group(batch["labels"].contiguous()).shape
         work.update(gp_algorithmic_work(trainer.gp, B, S, T))

@@ -99,6 +99,28 @@ class ELBOTrainer:
             prepacked = m._packed_key is not None and m._packed_key == self._batch_key(data, mask)
         if not prepacked:
             m._run_normalize(data, mask, B, hook)
+        self._step_core(B, scale, eps, train_x, P_batch, prefetch, hook)
+
+    def step_rows(self, ds, rows: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None, groups=None):
+        """One step on the rows ``rows`` (int32 device tensor) of a device-resident ``datafeed.DeviceDataset``: the input
+        stage gathers from the compact form inside its kernels (csrc/feed.hip); nothing else crosses PCIe.  Capturable:
+        refill ``rows`` in place and replay."""
+        m = self.model
+        lib = _lib.load()
+        B = rows.shape[0]
+        m._ensure_device_state(B)
+        m._packed_key = None
+        ws, s = C.byref(m._ws), m._stream()
+        _lib.check(lib.hlvae_feed_stats(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_stats")
+        if self.dp is not None:
+            self.dp.allreduce_stats(m._ws_t["sums"])
+        _lib.check(lib.hlvae_feed_pack(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_pack")
+        train_x = ds.labels.index_select(0, rows.long()) if self.kl == "gp" else None
+        self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None)
+
+    def _step_core(self, B, scale, eps, train_x, P_batch, prefetch, hook):
+        m = self.model
+        lib = _lib.load()
         ws, s = C.byref(m._ws), m._stream()
         # forward (+ head backward in the same pass: upstream gradient of log_p_x is -scale).
         # eps None -> reparameterisation noise from the in-kernel Philox stream (device-side offset: graph safe)
@@ -173,6 +195,22 @@ class ELBOTrainer:
             torch.cuda.synchronize()
         with torch.cuda.graph(g):
             self.step(data, mask, P_batch, train_x=train_x, prefetch=prefetch, prepacked=(prefetch is not None) or None)
+        self._graphs[key] = g
+        return g
+
+    def capture_rows(self, key, ds, rows: torch.Tensor, P_batch: int):
+        """Capture ``step_rows`` reading the STATIC index tensor ``rows``: refill it in place (``rows.copy_(...)``) and
+        replay -- one graph serves every batch of that size and subject count."""
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.step_rows(ds, rows, P_batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            self.step_rows(ds, rows, P_batch)
         self._graphs[key] = g
         return g
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 13
+#define HLVAE_ABI_VERSION 14
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -149,6 +149,15 @@ void hlvae_struct_sizes(int32_t* dims_bytes, int32_t* var_bytes, int32_t* ws_byt
 /* replaces: building types_info index vectors per step (HL_VAE/utils.py:94-96, HLVAE.py:387-410) */
 int  hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var* vars /* host, [D] */);
 void hlvae_plan_destroy(hlvae_plan* p);
+
+/* The same input stage from the COMPACT device-resident dataset (csrc/feed.hip; replaces the per-row pandas gather of
+ * dataset_def.py:67-92 and the 93 kB/row fp64 transfer): values fp32 [N][D] = raw value (real / pos / count), class index
+ * (cat, -1 = none) or level - 1 (ordinal); mask8 u8 [N][D], 1 = observed; rows int32 [B] = dataset rows of this batch.
+ * Outputs are those of hlvae_normalize_stats / hlvae_normalize_pack on the expanded fp64 form of the same rows. */
+int  hlvae_feed_stats(const hlvae_plan* p, const hlvae_ws* ws, const float* values, const uint8_t* mask8, const int32_t* rows,
+                      int B, hlvae_stream s);
+int  hlvae_feed_pack(const hlvae_plan* p, const hlvae_ws* ws, const float* values, const uint8_t* mask8, const int32_t* rows,
+                     int B, hlvae_stream s);
 
 /* bf16 shadows of the dense weights from the fp32 arena (no reference counterpart: the reference
  * computes in fp64; BASELINE.json config 2 asks for bf16 encoder/decoder) */

@@ -594,3 +594,45 @@ def test_gp_prior_hip_against_autograd_statement(varying_T):
     ref.optimizer_step()
     assert rel_err(hip.m, ref.m) < 1e-8 and rel_err(hip.H, ref.H) < 1e-8
     assert rel_err(hip.zt_list, ref.zt_list) < 1e-9
+
+
+@pytest.mark.parametrize("conv", [False, True])
+def test_compact_feed_matches_expanded_inputs(conv):
+    """the input stage gathering from the device-resident compact dataset (csrc/feed.hip) leaves exactly the
+    buffers the fp64 path leaves for the same rows -- packed encoder input (both layouts), likelihood targets, mask,
+    statistics -- and a training step from it follows the same trajectory."""
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    from hlvae_amd.datafeed import CompactDataset
+    dev = _dev()
+    if conv:
+        src = synthetic.make_d4(n_subjects=6, T=5, seed=2)
+        dims = [src.cov_dim_ext, [32], 8, [32], 5]
+    else:
+        src = synthetic.make_tabular(n_rows=60, T=6, seed=3, spec=MIX_SPEC)
+        dims = [src.cov_dim_ext, [16], 4, [16], 5]
+    ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    rows = np.array([7, 3, 22, 23, 24, 11, 0, 29, 18, 19, 20, 5, 6, 1, 28, 2, 9], dtype=np.int32)
+    eps = torch.randn(len(rows), dims[2], generator=torch.Generator().manual_seed(4)).to(dev)
+
+    def run(compact):
+        torch.manual_seed(0)
+        model = HLVAE(dims, src.types_info, src.n_variables, conv=conv, max_batch=128, materialize_samples=False).to(dev)
+        tr = ELBOTrainer(model, P_total=10, kl="normal", max_batch=128)
+        for _ in range(2):
+            if compact:
+                tr.step_rows(ds, torch.tensor(rows, device=dev), 5, eps=eps)
+            else:
+                tr.step(torch.tensor(src.data[rows], device=dev), torch.tensor(src.mask[rows], device=dev), 5, eps=eps)
+        torch.cuda.synchronize()
+        t = model._ws_t
+        B = len(rows)
+        return dict(xn=t["xn"][:B].float().cpu(), xnT=t["xnT"][:, :B].float().cpu(), xt=t["xt"][:B].cpu(), m8=t["m8"][:B].cpu(),
+                    norm=t["norm"].cpu(), nll=float(tr.scalars()["nll_sum"]), P=model._arena.cpu())
+
+    a, b = run(False), run(True)
+    assert torch.equal(a["m8"], b["m8"]) and torch.equal(a["xt"], b["xt"])
+    assert rel_err(b["norm"], a["norm"]) < 1e-6
+    assert rel_err(b["xn"], a["xn"]) < 1e-6 and rel_err(b["xnT"], a["xnT"]) < 1e-6
+    assert abs(a["nll"] - b["nll"]) <= 1e-6 * abs(a["nll"])
+    assert rel_err(b["P"], a["P"]) < 1e-6
