@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -79,6 +79,8 @@ _SIGS = {
     "hlvae_zero_grad": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp]),
     "hlvae_adam_step": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _vp]),
+    "hlvae_backward_adam": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_float, C.c_int, _vp, _vp, _vp, C.c_float, C.c_float,
+                                      C.c_float, C.c_float, C.c_float, _vp]),
     "hlvae_gp_kernel_matrix": (C.c_int, [C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp,
                                          C.c_int, C.c_int, C.c_double, _vp, _vp]),
     "hlvae_gp_chol_inv": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

@@ -19,7 +19,8 @@ int hl_launch_pack(const hlvae_plan*, const hlvae_ws*, const double*, const doub
 int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
 int hl_launch_mid_fwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, int, uint64_t, int, int, hipStream_t);
 int hl_launch_mid_bwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, const float*, float, int, int, hipStream_t);
-int hl_adam(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t);
+int hl_adam(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t, int);
+int hl_adam_early_wy(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t);
 int hl_launch_conv_enc_fwd(const hlvae_plan*, const hlvae_ws*, const double*, const double*, const float*, const uint8_t*,
                            const int32_t*, int, int, hipStream_t);
 int hl_launch_stats_compact(const hlvae_plan*, const hlvae_ws*, const float*, const uint8_t*, const int32_t*, int, hipStream_t);
@@ -316,8 +317,14 @@ int hlvae_backward_wy(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stre
     return hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", st);
 }
 
-int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
-                   int skip_wy, int B, hlvae_stream s) {
+struct HlAdamArgs {
+    float *m1, *m2;
+    int64_t* step_count;
+    float lr, b1, b2, eps, gscale;
+};
+
+static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
+                            int skip_wy, int B, hlvae_stream s, const HlAdamArgs* early) {
     CHECK_B();
     int rc;
     HL_REQUIRE(ws->splitk_dec >= 1, HLVAE_EINVAL, "splitk_dec");
@@ -336,6 +343,15 @@ int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, c
         if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
     // d U slabs = dY Wy (split-K), then the fused middle: dU -> dz -> d(mu, lv) -> dT, bias gradients
     if ((rc = hl_launch_gemm_splitk(dyl, d.NYlp, ws->wyTs, d.NYlp, ws->slab, d.hdp, Bp, d.hdp, d.NYlp, ws->splitk_dec, "dU_splitk", st))) return rc;
+    if (early != nullptr && !skip_wy) {
+        // y_layer's weight has its gradient (side stream) and its last reader of this step (dU_splitk, just queued) behind
+        // it: its Adam update + shadow refresh -- the largest slice of the HBM-bound optimiser -- runs on the side stream
+        // UNDER the latency-bound rest of the backward pass instead of after it
+        HL_CHECK(hipEventRecord(p->ev[2], st));
+        HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
+        if ((rc = hl_adam_early_wy(p, ws, early->m1, early->m2, early->step_count, early->lr, early->b1, early->b2, early->eps,
+                                   early->gscale, s0))) return rc;
+    }
     if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st))) return rc;
     HL_CHECK(hipEventRecord(p->ev[1], st));
     HL_CHECK(hipStreamWaitEvent(s1, p->ev[1], 0));
@@ -356,10 +372,24 @@ int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, c
     return hlvae_join(p, s);
 }
 
+int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
+                   int skip_wy, int B, hlvae_stream s) {
+    return hl_backward_impl(p, ws, g_mu, g_lv, kl_std_weight, skip_wy, B, s, nullptr);
+}
+
+int hlvae_backward_adam(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
+                        int B, float* m1, float* m2, int64_t* step_count, float lr, float beta1, float beta2, float eps,
+                        float grad_scale, hlvae_stream s) {
+    HL_REQUIRE(m1 && m2 && step_count, HLVAE_EINVAL, "backward_adam: null optimiser state");
+    const HlAdamArgs a{m1, m2, step_count, lr, beta1, beta2, eps, grad_scale};
+    if (int rc = hl_backward_impl(p, ws, g_mu, g_lv, kl_std_weight, 0, B, s, &a)) return rc;
+    return hl_adam(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, (hipStream_t)s, 1);
+}
+
 int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr,
                     float beta1, float beta2, float eps, float grad_scale, hlvae_stream s) {
     HL_REQUIRE(p && ws && m1 && m2 && step_count, HLVAE_EINVAL, "adam_step: null argument");
-    return hl_adam(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, (hipStream_t)s);
+    return hl_adam(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, (hipStream_t)s, 0);
 }
 
 int hlvae_gemm_nt_f32(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc, int M, int N, int K,

@@ -77,6 +77,9 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
                                                            float* __restrict__ M1, float* __restrict__ M2,
                                                            int64_t* __restrict__ step_count, float lr, float b1,
                                                            float b2, float eps, float gscale, int update) {
+    // update: 0 = shadows only; 1 = Adam with the step number k_adam_flat published in step_count[1], the last workgroup
+    // commits it to step_count[0]; 2 = Adam with step_count[0] + 1, nothing committed (a matrix updated EARLY, while the rest
+    // of the backward pass is still running: hlvae_backward_adam)
     constexpr int T = 64, CLD = T + 1;
     __shared__ float tile[T * CLD];
     int mi = 0;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
     const int tl = blockIdx.x - mt.tile0;
     const int r0 = (tl / mt.tiles_c) * T, c0 = (tl % mt.tiles_c) * T;
     AdamScalars a;
-    if (update) a = adam_scalars((float)step_count[1], lr, b1, b2, eps, gscale);
+    if (update) a = adam_scalars((float)(update == 2 ? step_count[0] + 1 : step_count[1]), lr, b1, b2, eps, gscale);
     const int c4 = (threadIdx.x & 15) * 4, rq = threadIdx.x >> 4;      // 16 float4 per tile row, 16 rows per pass
     // all 16 global loads of this lane are issued before the first store (a store to P / M1 / M2 orders every later load
     // from the same array behind it): unconditional loads from clamped addresses, predicated stores
@@ -147,10 +150,10 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
             }
         }
     }
-    if (update && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) step_count[0] = step_count[1];
+    if (update == 1 && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) step_count[0] = step_count[1];
 }
 
-static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws) {
+static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws, unsigned which = 0x1f) {
     const hlvae_dims& d = p->d;
     ShadowSet s;
     auto put = [&](int i, long off, int R, int C, bf16_t* dst, int ldd, int row_off, bf16_t* dstT, int ldT, int Rc, int Cc) {
@@ -168,9 +171,12 @@ static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws) {
     put(2, d.o_wd, d.h_d, d.L, ws->wds, d.Lp, 0, ws->wdTs, d.hdp, d.hdp, d.Lp);
     put(3, d.o_wmu, d.L, d.h_e, ws->wmls, d.hep, 0, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep);
     put(4, d.o_wlv, d.L, d.h_e, ws->wmls, d.hep, d.Lp, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep);
-    s.n = 5;
+    int n = 0;                                   // keep the selected matrices (bit i of `which`), compacted
+    for (int i = 0; i < 5; ++i)
+        if (which & (1u << i)) s.m[n++] = s.m[i];
+    s.n = n;
     int t = 0;
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < n; ++i) {
         s.m[i].tile0 = t;
         t += s.m[i].tiles_c * ((s.m[i].Rcover + 63) / 64);
     }
@@ -204,8 +210,19 @@ int hl_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s) {
     return 0;
 }
 
+// Adam + shadows of y_layer's weight alone (55 % of the MLP arena), with the step number taken as step_count[0] + 1
+int hl_adam_early_wy(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
+                     float b2, float eps, float gscale, hipStream_t s) {
+    const ShadowSet set = make_set(p, ws, 0x01);
+    if (int rc = check_set(set)) return rc;
+    HL_PROF("adam_wy_early", s);
+    k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 2);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
 int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
-            float b2, float eps, float gscale, hipStream_t s) {
+            float b2, float eps, float gscale, hipStream_t s, int skip_wy) {
     const hlvae_dims& d = p->d;
     HL_REQUIRE(d.atomic_region % 4 == 0, HLVAE_ESHAPE, "atomic region %ld not a multiple of 4", (long)d.atomic_region);
     const long n4 = d.atomic_region / 4;
@@ -219,7 +236,7 @@ int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64
         k_adam_flat<<<blocks, HL_THREADS, 0, s>>>(ws->P, ws->G, m1, m2, n4, step_count, lr, b1, b2, eps, gscale, 1);
     }
     HL_LAUNCH_CHECK();
-    const ShadowSet set = make_set(p, ws);
+    const ShadowSet set = make_set(p, ws, skip_wy ? 0x1e : 0x1f);
     if (int rc = check_set(set)) return rc;
     {
         HL_PROF("adam_weights_shadows", s);

@@ -144,8 +144,14 @@ class ELBOTrainer:
         kl_w = 1.0 if self.kl == "normal" else 0.0
         if self.kl == "gp":
             g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch)
-        if self.dp is None:
-            _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 0, B, s), "backward")
+        fused_opt = self.dp is None
+        if fused_opt:
+            # backward and optimiser in one call: y_layer's Adam update runs under the rest of the backward pass
+            o = self.opt
+            _lib.check(lib.hlvae_backward_adam(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), B, _lib.ptr(o.m1),
+                                               _lib.ptr(o.m2), _lib.ptr(o.step_count), C.c_float(o.lr), C.c_float(o.betas[0]),
+                                               C.c_float(o.betas[1]), C.c_float(o.eps), C.c_float(1.0), s), "backward_adam")
+            m.mark_shadows_fresh()
         elif m.conv:
             # convolutional model: y_layer's gradient is final only after the transposed convolutions' backward and the arena
             # is 2.7 M parameters (10.8 MB): one all-reduce after the backward pass
@@ -164,7 +170,8 @@ class ELBOTrainer:
             self.dp.allreduce_(G[hi:])
             pending.wait()
         m._fwd_token += 1
-        self.opt.step()
+        if not fused_opt:
+            self.opt.step()
         m._grad_region_clean = True
         if self.kl == "gp":
             self.gp.optimizer_step()

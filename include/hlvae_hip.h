@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 14
+#define HLVAE_ABI_VERSION 15
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -216,6 +216,13 @@ int hlvae_zero_grad(const hlvae_plan* p, const hlvae_ws* ws, hlvae_stream s);
  * The small-parameter gradient region [0, atomic_region) is zeroed after it is consumed. */
 int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count,
                     float lr, float beta1, float beta2, float eps, float grad_scale, hlvae_stream s);
+
+/* hlvae_backward + hlvae_adam_step as ONE call (single-process training): identical result, but the Adam update of
+ * y_layer's weight (the largest slice of the HBM-bound optimiser) is queued on the side stream as soon as its gradient and
+ * its last reader of the step are done, so it runs under the latency-bound remainder of the backward pass. */
+int hlvae_backward_adam(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
+                        int B, float* m1, float* m2, int64_t* step_count, float lr, float beta1, float beta2, float eps,
+                        float grad_scale, hlvae_stream s);
 
 /* ---- GP-prior KL (row K): reference elbo_functions.py:196-285 with the kernels of GP_model.py:27-116, fp64 ----------
  * An additive kernel = sum over terms of  scale_t[l] * prod_f factor_f(x[dim], x'[dim]);  factors: categorical equality,
