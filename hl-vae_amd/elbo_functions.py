@@ -414,6 +414,59 @@ class GPPriorHIP:
             self.dp.allreduce_(self._gtheta)
         return g_mu, g_lv
 
+    # ---- evaluation surface: posterior mean of the latent at new covariates ------------------------------------------
+    @torch.no_grad()
+    def batch_predict_varying_T(self, prediction_x, test_x, mu):
+        """Reference utils.py:99-191 (``batch_predict_varying_T``): prediction_x [Np, Q] (fp64) with encoder means
+        mu [Np, L]; test_x [Nt, Q]; returns Z_pred [Nt, L] fp64.  Kernel matrices, the per-subject blocks (B_st inverse,
+        iB K0xz, iB mu: the training kernel k_gp_subject_fwd with the roles a := mu, c := 1) and the M x M inverses run in
+        the HIP kernels of csrc/gp.hip; the remaining products are library GEMMs.  Evaluation path: host syncs allowed."""
+        lib, st = _lib.load(), self._stream()
+        L, M, Q = self.L, self.M, self.Q
+        dev = prediction_x.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        px, tx = prediction_x.to(torch.float64).contiguous(), test_x.to(torch.float64).contiguous()
+        Np = px.shape[0]
+        k0, k1, z = self.k0, self.k1, self.zt_list
+        hyp = self._transform()
+        K0xz = self.kernel_matrix(k0, px, z)                                             # utils.py:127
+        K0zz = self.kernel_matrix(k0, z, z, jitter=self.eps)                             # :128,131
+        K0Xz = self.kernel_matrix(k0, tx, z)                                             # :129
+        idx = self._group(px)
+        S, T = idx.shape
+        mu64T = mu.to(torch.float64).t().contiguous()                                    # [L, Np]
+        zeros32 = torch.zeros(Np, L, dtype=torch.float32, device=dev)
+        iB = torch.empty(S, L, T, T, **f64); K0s = torch.empty(S, L, T, T, **f64)
+        V = torch.empty(L, Np, M, **f64); v = torch.empty(L, Np, **f64); part = torch.empty(S, L, 4, **f64)
+        g1, g2 = torch.empty_like(zeros32), torch.empty_like(zeros32)
+        _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(px),
+                                            _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(K0xz), Np, M, _lib.ptr(mu64T),
+                                            _lib.ptr(zeros32), _C.c_double(1.0), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
+                                            _lib.ptr(part), _lib.ptr(g1), _lib.ptr(g2), st), "gp_subject_fwd(predict)")
+        K0zx = K0xz.transpose(1, 2)
+        inv, _ = self.chol_inv(torch.cat([K0zz + K0zx @ V, K0zz]))                       # H = K0zz + sum_s Ks^T iB Ks (:156-157)
+        iH, iK = inv[:L], inv[L:]
+        iB_mu = v.unsqueeze(2)                                                           # :158
+        t1 = (K0xz @ (iH @ (K0zx @ iB_mu))).squeeze(2)                                   # :162   [L, Np]
+        valid = idx >= 0
+        gi = idx.clamp(min=0).long()
+        t1g = t1[:, gi] * valid[None].to(torch.float64)                                  # [L, S, T]
+        t2g = torch.einsum("sltu,lsu->lst", iB, t1g)                                     # :164-166
+        t2 = torch.zeros(L, Np, **f64)
+        t2[:, gi[valid]] = t2g[:, valid]
+        mu_tilde = iB_mu - t2.unsqueeze(2)                                               # :167
+        a = K0Xz @ (iK @ (K0zx @ mu_tilde))                                              # :169
+        b = torch.zeros(L, tx.shape[0], 1, **f64)
+        ids_p, ids_t = px[:, self.id_covariate], tx[:, self.id_covariate]
+        for s_ in torch.unique(ids_t).tolist():                                          # :175-186
+            rp = torch.nonzero(ids_p == s_).flatten()
+            if rp.numel() == 0:
+                continue                                                                 # K1 of an unseen subject against the rest is zero
+            rt = torch.nonzero(ids_t == s_).flatten()
+            K1 = self.kernel_matrix(k1, tx[rt].contiguous(), px[rp].contiguous())
+            b[:, rt] = K1 @ mu_tilde[:, rp]
+        return (a + b).squeeze(2).t().contiguous()                                       # :188
+
     def optimizer_step(self):
         # Adam on [hyper-parameters | inducing points] (HLVAE_main.py:277-278), one fused kernel, device-side step counter
         _lib.check(_lib.load().hlvae_gp_adam(_lib.ptr(self._theta), _lib.ptr(self._gtheta), _lib.ptr(self._adam_m),

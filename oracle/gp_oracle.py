@@ -186,3 +186,46 @@ def natural_gradient_update(m, H, grad_m, grad_H, lr):
     H_new = torch.cholesky_solve(eye, torch.linalg.cholesky(iH_new)).detach()
     m_new = (H_new @ (iH @ m - lr * (grad_m - 2 * (grad_H @ m)))).detach()
     return m_new, H_new
+
+
+def batch_predict_varying_T(spec: KernelSpec, kprm, noise, latent_dim, prediction_x, test_x, mu, z, id_covariate, eps):
+    """GP posterior mean of the latent at new covariates (reference utils.py:99-191; the imputation / prediction entry of the
+    evaluation surface).  prediction_x [Np,Q] with encoder means mu [Np,L]; test_x [Nt,Q]; z [L,M,Q].  Returns Z_pred [Nt,L].
+    (torch.solve(B, A) of the reference is torch.linalg.solve(A, B).)"""
+    L, M = latent_dim, z.shape[1]
+    eyeM = torch.eye(M, dtype=DT)
+    K0xz = eval_kernel(spec.k0, kprm, "k0", prediction_x[None], z)                        # :127
+    K0zz = eval_kernel(spec.k0, kprm, "k0", z, z) + eps * eyeM                            # :128,131
+    K0Xz = eval_kernel(spec.k0, kprm, "k0", test_x[None], z)                              # :129
+    K0zx = K0xz.transpose(-1, -2)
+    H = K0zz.clone()
+    ids = prediction_x[:, id_covariate]
+    subjects = torch.unique(ids).tolist()                                                 # :136
+    iB_mu = torch.zeros(L, prediction_x.shape[0], 1, dtype=DT)
+    iBs = []
+    for s in subjects:                                                                    # :138-160
+        ind = ids == s
+        x_st = prediction_x[ind]
+        T = x_st.shape[0]
+        B_st = eval_kernel(spec.k1, kprm, "k1", x_st[None], x_st[None]) + torch.eye(T, dtype=DT) * noise.view(L, 1, 1)
+        iB = torch.cholesky_solve(torch.eye(T, dtype=DT).expand(L, T, T), torch.linalg.cholesky(B_st))
+        Ks = K0xz[:, ind]
+        H = H + Ks.transpose(-1, -2) @ (iB @ Ks)                                          # :156-157
+        iB_mu[:, ind] = iB @ mu[ind].T.unsqueeze(2)                                       # :158
+        iBs.append(iB)
+    t1 = K0xz @ torch.linalg.solve(H, K0zx @ iB_mu)                                       # :162
+    t2 = torch.zeros_like(iB_mu)
+    for i, s in enumerate(subjects):                                                      # :164-166
+        ind = ids == s
+        t2[:, ind] = iBs[i] @ t1[:, ind]
+    mu_tilde = iB_mu - t2                                                                 # :167
+    a = K0Xz @ torch.linalg.solve(K0zz, K0zx @ mu_tilde)                                  # :169
+    tids = test_x[:, id_covariate]
+    test_subjects = torch.unique(tids)
+    msk = torch.isin(ids, test_subjects)                                                  # :171-172
+    b = torch.zeros(L, test_x.shape[0], 1, dtype=DT)
+    for s in test_subjects.tolist():                                                      # :175-186
+        ind = tids == s
+        K1Xx = eval_kernel(spec.k1, kprm, "k1", test_x[ind][None], prediction_x[msk][None])
+        b[:, ind] = K1Xx @ mu_tilde[:, msk]
+    return (a + b).squeeze(2).T                                                           # :188

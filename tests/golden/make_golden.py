@@ -55,6 +55,9 @@ ref_hlvae = load_ref("ref_HLVAE", "HLVAE.py")
 ref_rf = load_ref("ref_read_functions", "HL_VAE/read_functions.py")
 ref_elbo = load_ref("ref_elbo_functions", "elbo_functions.py")
 ref_gp = load_ref("ref_GP_model", "GP_model.py")
+# torch >= 2 removed torch.solve(B, A) -> (X, LU); the reference calls it (utils.py:162,169)
+torch.solve = lambda B, A: (torch.linalg.solve(A, B), None)      # torch 2.10 keeps a stub that only raises
+ref_utils = load_ref("ref_utils", "utils.py")
 
 T64 = torch.float64
 
@@ -249,6 +252,9 @@ class _Noise:
         self.noise_covar = self._NC()
         self.noise_covar.noise = noise
 
+    def eval(self):
+        return self
+
 
 def case_gp():
     torch.manual_seed(0)
@@ -317,6 +323,63 @@ def case_gp():
     print("gp_kl", out["kld"])
 
 
+def case_gp_predict():
+    """GP posterior prediction of the latent (reference utils.py:99-191, batch_predict_varying_T) run with the GP_model.py
+    kernels: known subjects at new times plus rows of an unseen subject."""
+    torch.manual_seed(1)
+    L, M, Q, idc = 4, 10, 6, 2
+    Ts = [3, 6, 4, 5, 6]
+    rows = []
+    for s, T in enumerate(Ts):
+        sick = s % 2
+        for t in range(T):
+            rows.append([float(t), float(t - 2) if sick else 0.0, float(s + 10), float(s % 2), float(sick), float((s // 2) % 2)])
+    x = torch.tensor(rows, dtype=T64)
+    x = x[torch.randperm(x.shape[0])]
+    trows = []
+    for s in (1, 3, 4):                                    # known subjects, later time points
+        sick = s % 2
+        for t in (7, 8, 9):
+            trows.append([float(t), float(t - 2) if sick else 0.0, float(s + 10), float(s % 2), float(sick), float((s // 2) % 2)])
+    for t in range(3):                                     # an unseen subject
+        trows.append([float(t), 0.0, 99.0, 1.0, 0.0, 1.0])
+    tx = torch.tensor(trows, dtype=T64)
+    cfg = dict(cat_kernel=[2], bin_kernel=[], sqexp_kernel=[0],
+               cat_int_kernel=[{"cont_covariate": 0, "cat_covariate": 2}, {"cont_covariate": 0, "cat_covariate": 3},
+                               {"cont_covariate": 1, "cat_covariate": 4}], bin_int_kernel=[])
+    k0, k1 = ref_gp.generate_kernel_batched(L, cfg["cat_kernel"], cfg["bin_kernel"], cfg["sqexp_kernel"],
+                                            cfg["cat_int_kernel"], cfg["bin_int_kernel"], [], idc)
+    k0, k1 = k0.double(), k1.double()
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for p in list(k0.parameters()) + list(k1.parameters()):
+            p.add_(0.3 * torch.randn(p.shape, generator=g, dtype=T64))
+    mu = torch.randn(x.shape[0], L, generator=g, dtype=T64)
+    z = x[torch.randperm(x.shape[0], generator=g)[:M]].clone()[None].repeat(L, 1, 1)
+    z = z + 0.05 * torch.randn(z.shape, generator=g, dtype=T64)
+    noise = torch.ones(L, 1, dtype=T64)
+    with torch.no_grad():
+        Zp = ref_utils.batch_predict_varying_T(L, _LazyAdapter(k0), _LazyAdapter(k1), _Noise(noise), x, tx, mu, z, idc, 1e-6)
+    out = dict(x=np64(x), test_x=np64(tx), mu=np64(mu), z=np64(z), noise=np64(noise.flatten()), Z_pred=np64(Zp),
+               scalars=np.array([1e-6, idc]))
+    for name, add in (("k0", k0), ("k1", k1)):
+        for ti, sk in enumerate(add.kernels):
+            out[f"kp__{name}.{ti}.scale"] = np64(sk._log_scale)
+            fac = []
+
+            def walk(k):
+                if isinstance(k, ref_gp.ProductKernel):
+                    walk(k.k1); walk(k.k2)
+                else:
+                    fac.append(k)
+            walk(sk.kernel)
+            for fi, f in enumerate(fac):
+                if isinstance(f, ref_gp.RbfKernel):
+                    out[f"kp__{name}.{ti}.{fi}.ls"] = np64(f._log_lengthscale)
+    np.savez_compressed(os.path.join(HERE, "gp_predict.npz"), **out)
+    print("gp_predict", out["Z_pred"][:2])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     case_types_info()
@@ -325,3 +388,4 @@ if __name__ == "__main__":
     case_d4()
     case_d4_conv()
     case_gp()
+    case_gp_predict()

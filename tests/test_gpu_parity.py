@@ -636,3 +636,22 @@ def test_compact_feed_matches_expanded_inputs(conv):
     assert rel_err(b["xn"], a["xn"]) < 1e-6 and rel_err(b["xnT"], a["xnT"]) < 1e-6
     assert abs(a["nll"] - b["nll"]) <= 1e-6 * abs(a["nll"])
     assert rel_err(b["P"], a["P"]) < 1e-6
+
+
+def test_gp_posterior_prediction_against_reference_fixture(golden_dir):
+    """GPPriorHIP.batch_predict_varying_T (HIP kernel matrices, per-subject blocks, M x M inverses) against the
+    reference's utils.batch_predict_varying_T output stored in tests/golden/gp_predict.npz.  fp64: 1e-8."""
+    from hlvae_amd.elbo_functions import GPPriorHIP
+    g = np.load(os.path.join(golden_dir, "gp_predict.npz"))
+    dev = _dev()
+    x, tx, mu = (torch.tensor(g[k], device=dev) for k in ("x", "test_x", "mu"))
+    L, M = mu.shape[1], g["z"].shape[1]
+    gp = GPPriorHIP(L, x, M, int(g["scalars"][1]), N_total=1, eps=float(g["scalars"][0]))
+    with torch.no_grad():
+        gp.zt_list.copy_(torch.tensor(g["z"], device=dev))
+        for row, (which, t, f) in enumerate(gp.slot_names):
+            key = f"kp__{which}.{t}.scale" if f is None else f"kp__{which}.{t}.{f}.ls"
+            gp.prm[row].copy_(torch.tensor(g[key], device=dev))
+    Zp = gp.batch_predict_varying_T(x, tx, mu)
+    assert tuple(Zp.shape) == g["Z_pred"].shape
+    assert rel_err(Zp, g["Z_pred"]) < 1e-8

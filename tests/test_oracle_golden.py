@@ -154,3 +154,17 @@ def test_gp_kl(golden_dir):
     m_new, H_new = gpo.natural_gradient_update(m, H, gm.detach(), gH.detach(), float(lr))
     assert rel_err(m_new.numpy(), g["m_new"]) < 1e-9
     assert rel_err(H_new.numpy(), g["H_new"]) < 1e-9
+
+
+def test_gp_predict(golden_dir):
+    """GP posterior prediction (reference utils.py:99-191, run with torch.solve mapped onto torch.linalg.solve)"""
+    g = np.load(os.path.join(golden_dir, "gp_predict.npz"))
+    eps, idc = float(g["scalars"][0]), int(g["scalars"][1])
+    L = g["mu"].shape[1]
+    spec = gpo.spec_from_config([2], [], [0], [{"cont_covariate": 0, "cat_covariate": 2},
+                                               {"cont_covariate": 0, "cat_covariate": 3},
+                                               {"cont_covariate": 1, "cat_covariate": 4}], [], idc)
+    prm = {k[4:]: torch.tensor(g[k]) for k in g.files if k.startswith("kp__")}
+    Zp = gpo.batch_predict_varying_T(spec, prm, torch.tensor(g["noise"]), L, torch.tensor(g["x"]), torch.tensor(g["test_x"]),
+                                     torch.tensor(g["mu"]), torch.tensor(g["z"]), idc, eps)
+    assert rel_err(Zp.numpy(), g["Z_pred"]) < 1e-9
