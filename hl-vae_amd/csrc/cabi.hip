@@ -117,7 +117,8 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     hlvae_dims d = *dims;
     hlvae_dims_fill(&d);
     HL_REQUIRE(d.D > 0 && d.X >= d.D && d.h_e > 0 && d.h_d > 0 && d.L > 0, HLVAE_EINVAL, "plan_create: bad dims");
-    HL_REQUIRE(d.y_dim == 5, HLVAE_EINVAL, "plan_create: y_dim=%d, only 5 is instantiated", d.y_dim);
+    HL_REQUIRE(d.y_dim == 5 || d.y_dim == 3 || d.y_dim == 8, HLVAE_EINVAL, "plan_create: y_dim=%d (instantiated: 3, 5, 8)", d.y_dim);
+    HL_REQUIRE(!d.conv || d.y_dim == 5, HLVAE_EINVAL, "plan_create: the convolutional decoder has y_dim = 5 output channels");
     HL_REQUIRE(d.Lp <= 64, HLVAE_EINVAL, "plan_create: latent_dim=%d > 64 unsupported", d.L);
     HL_REQUIRE(d.arena_size % 4 == 0, HLVAE_EINVAL, "plan_create: arena_size must be a multiple of 4 floats");
     HL_REQUIRE(!d.conv || d.D == 36 * 36, HLVAE_EINVAL, "plan_create: the convolutional model needs 36 x 36 = 1296 variables "

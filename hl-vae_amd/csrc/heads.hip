@@ -705,7 +705,8 @@ __global__ void k_scale_dy(bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict
 int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_elem, float g_scale, int want_grad,
                       int want_params, int B, int Bp, hipStream_t s) {
     const hlvae_dims& d = p->d;
-    HL_REQUIRE(d.y_dim == 5, HLVAE_EINVAL, "y_dim=%d: only y_dim=5 (the reference configuration) is instantiated", d.y_dim);
+    HL_REQUIRE(d.y_dim == 5 || d.y_dim == 3 || d.y_dim == 8, HLVAE_EINVAL,
+               "y_dim=%d: instantiated for 5 (the reference configuration), 3 and 8", d.y_dim);
     const int NT = (d.D + 15) / 16;
     float* pf = want_params == 1 ? ws->pfull : nullptr;      // 1: p_params + x_hat, 2: x_hat only (training metrics)
     float* xh = want_params ? ws->xhat : nullptr;
@@ -715,14 +716,26 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
         const bool big = (long)(Bp / 128) * NT >= 512;
         const int grid = NT * (big ? Bp / 128 : Bp / 64);
 #define HL_LAUNCH_HEADS(BMv, KMv)                                                                                      \
-        k_y_heads<5, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,  \
+        HL_LAUNCH_HEADS_Y(5, BMv, KMv)
+#define HL_LAUNCH_HEADS_Y(YDv, BMv, KMv)                                                                               \
+        k_y_heads<YDv, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,  \
                                                           ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, \
                                                           d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing,       \
                                                           ws->rowpart, pf, d.X, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY)
+        if (d.y_dim != 5) {      // other y_dim (config/hlvae_config_file.txt: y_dim): 64-row tiles, all class counts up to 8
+            const int g64 = NT * (Bp / 64);
+            if (d.y_dim == 3) k_y_heads<3, 64, 8><<<g64, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G,
+                d.o_by, ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, d.NYp, ws->dyT, Bp, ws->log_p_x,
+                ws->log_p_x_missing, ws->rowpart, pf, d.X, xh, B, want_grad, nullptr, d.NY);
+            else k_y_heads<8, 64, 8><<<g64, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G,
+                d.o_by, ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, d.NYp, ws->dyT, Bp, ws->log_p_x,
+                ws->log_p_x_missing, ws->rowpart, pf, d.X, xh, B, want_grad, nullptr, d.NY);
+        } else
         if (p->kmax <= 3) { if (big) HL_LAUNCH_HEADS(128, 3); else HL_LAUNCH_HEADS(64, 3); }
         else if (p->kmax <= 5) { if (big) HL_LAUNCH_HEADS(128, 5); else HL_LAUNCH_HEADS(64, 5); }
         else { if (big) HL_LAUNCH_HEADS(128, 8); else HL_LAUNCH_HEADS(64, 8); }
 #undef HL_LAUNCH_HEADS
+#undef HL_LAUNCH_HEADS_Y
     }
     HL_LAUNCH_CHECK();
     HL_PROF("elbo_finalize", s);

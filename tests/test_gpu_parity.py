@@ -655,3 +655,31 @@ def test_gp_posterior_prediction_against_reference_fixture(golden_dir):
     Zp = gp.batch_predict_varying_T(x, tx, mu)
     assert tuple(Zp.shape) == g["Z_pred"].shape
     assert rel_err(Zp, g["Z_pred"]) < 1e-8
+
+
+@pytest.mark.parametrize("y_dim", [3, 8])
+def test_other_y_dim_against_oracle(y_dim):
+    """y_dim is a configuration value of the reference (config/hlvae_config_file.txt: y_dim, default 5): the head kernel is
+    also instantiated for 3 and 8.  Forward + backward on the five-type mix (class counts up to 5) against the oracle."""
+    import hlvae_oracle as orc
+    dev = _dev()
+    src = synthetic.make_tabular(n_rows=48, T=6, seed=7, spec=MIX_SPEC)
+    dims = [src.cov_dim_ext, [16], 4, [16], y_dim]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=21, std=0.2)
+    model = _model_from_state(src, dims, state)
+    rows = np.arange(48)
+    eps = torch.randn(48, dims[2], generator=torch.Generator().manual_seed(3))
+    data, mask = torch.tensor(src.data[rows], device=dev), torch.tensor(src.mask[rows], device=dev)
+    out = model(data, mask, None, src.types_info, eps=eps.to(dev))
+    loss = 1.3 * model.loss_function(out[3]).sum() - 0.5 * torch.sum(1.0 + out[2] - out[1] ** 2 - torch.exp(out[2]))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref, ref_loss, st = _oracle_step(src, rows, dims, state, eps, 1.3)
+    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    e = np.abs(out[3].detach().double().cpu().numpy() - ref["log_p_x"].detach().numpy())
+    assert np.all(e <= 5e-2 + 3e-2 * np.abs(ref["log_p_x"].detach().numpy()))
+    sd = dict(model.named_parameters())
+    for k in ("y_layer.0.weight", "y_layer.0.bias", "d_layers.0.bias", "obs_layer.0.weight", "obs_layer.3.weight_mean",
+              "obs_layer.2.weight_region", "obs_layer.2.weight_thresholds"):
+        if k in sd and st[k].grad is not None:
+            assert rel_err(sd[k].grad, st[k].grad) < 5e-2, k
