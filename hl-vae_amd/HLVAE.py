@@ -186,8 +186,10 @@ class HLVAE(nn.Module):
         order += [self.y_layer[0].bias, self.d_layers[0].bias, self.mean_layer[0].bias, self.log_var_layer[0].bias,
                   self.VAE_encoder_common_layers[0].bias]
         n_small = len(order)
-        order += [self.y_layer[0].weight, self.d_layers[0].weight, self.mean_layer[0].weight,
-                  self.log_var_layer[0].weight, self.VAE_encoder_common_layers[0].weight]
+        # y_layer's weight LAST: its gradient is final first and is all-reduced on its own while the rest of the backward
+        # pass runs; everything before it is then ONE contiguous slice for the second all-reduce
+        order += [self.d_layers[0].weight, self.mean_layer[0].weight, self.log_var_layer[0].weight,
+                  self.VAE_encoder_common_layers[0].weight, self.y_layer[0].weight]
         self._order = order
         offs, o = [], 0
         for i, p in enumerate(order):

@@ -163,11 +163,10 @@ class ELBOTrainer:
             d = m._dims
             _lib.check(lib.hlvae_backward_wy(m._plan_handle, ws, B, s), "backward_wy")
             G = m._grad_arena
-            lo, hi = int(d.o_wy), int(d.o_wy) + int(d.NY) * int(d.h_d)
-            pending = self.dp.allreduce_async(G[lo:hi])
+            lo = int(d.o_wy)                                 # y_layer's weight is the last tensor of the arena
+            pending = self.dp.allreduce_async(G[lo:])
             _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 1, B, s), "backward")
             self.dp.allreduce_(G[:lo])
-            self.dp.allreduce_(G[hi:])
             pending.wait()
         m._fwd_token += 1
         if not fused_opt:

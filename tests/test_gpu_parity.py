@@ -506,6 +506,13 @@ def test_data_parallel_code_path_single_rank_rccl(golden_dir):
         assert results[0][0] == results[1][0]
         # fp32 atomics in the small-gradient region may reorder between runs: allow rounding-level differences
         assert rel_err(results[1][1], results[0][1]) < 1e-5
+        # the data-parallel step (statistics all-reduce, overlapped gradient all-reduces) is capturable in a HIP graph
+        tr.capture("dp", data, mask, 4)
+        before = model._arena.clone()
+        tr.replay("dp")
+        tr.replay("dp")
+        torch.cuda.synchronize()
+        assert np.isfinite(float(tr.scalars()["nll_sum"])) and not torch.equal(before, model._arena)
     finally:
         dist.destroy_process_group()
 
