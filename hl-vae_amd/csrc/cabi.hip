@@ -12,6 +12,7 @@ int hl_launch_gemm_splitk(const bf16_t*, int, const bf16_t*, int, float*, int, i
 int hl_launch_gemm_act(int, const bf16_t*, int, const bf16_t*, int, int, int, int, const float*, int, const bf16_t*,
                        bf16_t*, int, bf16_t*, int, int, float*, const char*, hipStream_t);
 int hl_launch_y_heads(const hlvae_plan*, const hlvae_ws*, const float*, float, int, int, int, int, hipStream_t);
+int hl_launch_elbo_finalize(const hlvae_plan*, const hlvae_ws*, int, int, hipStream_t);
 int hl_launch_scale_dy(const hlvae_plan*, const hlvae_ws*, const float*, int, int, hipStream_t);
 int hl_launch_step_metrics(const hlvae_plan*, const hlvae_ws*, int, float*, hipStream_t);
 int hl_launch_stats(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, hipStream_t);
@@ -272,7 +273,10 @@ int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_lo
                                      d.NYlp, nullptr, 0, B, nullptr, "y_layer_conv", st))) return rc;
         if ((rc = hl_launch_conv_dec_fwd(p, ws, B, st))) return rc;
     }
-    return hl_launch_y_heads(p, ws, g_logpx, g_scale, want_grad, want_params, B, Bp, st);
+    if ((rc = hl_launch_y_heads(p, ws, g_logpx, g_scale, want_grad, want_params, B, Bp, st))) return rc;
+    // (moving this one-workgroup kernel to the side stream was measured: the extra fork/join in the HIP graph costs more
+    // than the 8 us it takes off the critical path -- 0.229 vs 0.205 ms/step)
+    return hl_launch_elbo_finalize(p, ws, B, Bp, st);
 }
 
 int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, int B, hlvae_stream s) {
@@ -332,7 +336,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     // The weight-gradient GEMMs are leaves of the dependency graph: they run on two side streams (fork/join with
     // events, so the structure is preserved under hipGraph capture) beside the critical path
     //   dY -> dU -> d(mu, lv) -> dT -> dW1.
-    hipStream_t s0 = p->side[0], s1 = p->side[1];
+    hipStream_t s0 = p->side[0], s1 = p->side[1];       // (everything on one stream was measured: 0.225 vs 0.207 ms/step)
     if (d.conv)     // d y_grouped -> d a2 -> d (y_layer output), weight gradients of the transposed convolutions
         if ((rc = hl_launch_conv_dec_bwd(p, ws, B, Bp, st))) return rc;
     const bf16_t* dyl = d.conv ? ws->dyc : ws->dy;          // gradient of y_layer's output, both layouts

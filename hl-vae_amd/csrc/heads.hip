@@ -738,6 +738,12 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
 #undef HL_LAUNCH_HEADS_Y
     }
     HL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ELBO bookkeeping (scalars, noise-stream advance); nothing of the backward pass depends on it
+int hl_launch_elbo_finalize(const hlvae_plan* p, const hlvae_ws* ws, int B, int Bp, hipStream_t s) {
+    const int NT = (p->d.D + 15) / 16;
     HL_PROF("elbo_finalize", s);
     k_elbo_finalize<<<1, 1024, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal, ws->klpart, Bp / 16, ws->rng);       // one partial per 16-row tile of k_mid_fwd_fused
     HL_LAUNCH_CHECK();
