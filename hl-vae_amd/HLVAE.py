@@ -440,6 +440,9 @@ class HLVAE(nn.Module):
     def _run_normalize(self, data, mask, B, stats_hook=None):
         lib, ws, s = _lib.load(), C.byref(self._ws), self._stream()
         self._packed_key = None
+        if stats_hook is None:      # single process: statistics and pack in one launch
+            _lib.check(lib.hlvae_normalize_fused(self._plan_handle, ws, _lib.ptr(data), _lib.ptr(mask), B, s), "normalize_fused")
+            return
         _lib.check(lib.hlvae_normalize_stats(self._plan_handle, ws, _lib.ptr(data), _lib.ptr(mask), B, s), "normalize_stats")
         if stats_hook is not None:
             stats_hook(self._ws_t["sums"])          # data-parallel: all-reduce the masked column sums

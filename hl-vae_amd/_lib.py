@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -67,6 +67,8 @@ _SIGS = {
     "hlvae_refresh_shadows": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp]),
     "hlvae_normalize_stats": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_int, _vp]),
     "hlvae_normalize_pack": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_int, _vp]),
+    "hlvae_normalize_fused": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_int, _vp]),
+    "hlvae_feed_fused": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_int, _vp]),
     "hlvae_feed_stats": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_int, _vp]),
     "hlvae_feed_pack": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_int, _vp]),
     "hlvae_encoder_fwd": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, C.c_uint64, C.c_int, _vp]),

@@ -230,6 +230,17 @@ int hlvae_normalize_pack(const hlvae_plan* p, const hlvae_ws* ws, const double* 
     return hl_launch_pack(p, ws, data, mask, B, Bp, st);
 }
 
+int hlvae_normalize_fused(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask, int B,
+                          hlvae_stream s) {
+    CHECK_B();
+    // real columns carry no batch statistics under conv (utils.py:99-102): only pos columns need the sums.
+    // (A pack kernel that sums its own columns over all rows was measured for the MLP path: the 48 workgroups that own real
+    //  columns become a long tail -- 0.208 vs 0.205 ms/step -- so the two-pass form stays.)
+    int rc;
+    if ((!d.conv || d.n_pos > 0) && (rc = hl_launch_stats(p, ws, data, mask, B, st))) return rc;
+    return hlvae_normalize_pack(p, ws, data, mask, B, s);
+}
+
 int hlvae_feed_stats(const hlvae_plan* p, const hlvae_ws* ws, const float* values, const uint8_t* mask8, const int32_t* rows,
                      int B, hlvae_stream s) {
     CHECK_B();
@@ -246,6 +257,15 @@ int hlvae_feed_pack(const hlvae_plan* p, const hlvae_ws* ws, const float* values
         return hl_launch_conv_enc_fwd(p, ws, nullptr, nullptr, values, mask8, rows, B, Bp, st);
     }
     return hl_launch_pack_compact(p, ws, values, mask8, rows, B, Bp, st);
+}
+
+int hlvae_feed_fused(const hlvae_plan* p, const hlvae_ws* ws, const float* values, const uint8_t* mask8, const int32_t* rows,
+                     int B, hlvae_stream s) {
+    CHECK_B();
+    HL_REQUIRE(values && mask8 && rows, HLVAE_EINVAL, "feed_fused: null pointer");
+    int rc;
+    if ((!d.conv || d.n_pos > 0) && (rc = hl_launch_stats_compact(p, ws, values, mask8, rows, B, st))) return rc;
+    return hlvae_feed_pack(p, ws, values, mask8, rows, B, s);
 }
 
 int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int sample, uint64_t rng_host_offset,

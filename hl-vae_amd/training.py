@@ -111,10 +111,12 @@ class ELBOTrainer:
         m._ensure_device_state(B)
         m._packed_key = None
         ws, s = C.byref(m._ws), m._stream()
-        _lib.check(lib.hlvae_feed_stats(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_stats")
-        if self.dp is not None:
+        if self.dp is None:
+            _lib.check(lib.hlvae_feed_fused(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_fused")
+        else:
+            _lib.check(lib.hlvae_feed_stats(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_stats")
             self.dp.allreduce_stats(m._ws_t["sums"])
-        _lib.check(lib.hlvae_feed_pack(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_pack")
+            _lib.check(lib.hlvae_feed_pack(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_pack")
         train_x = ds.labels.index_select(0, rows.long()) if self.kl == "gp" else None
         self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None)
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 15
+#define HLVAE_ABI_VERSION 16
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -158,6 +158,12 @@ int  hlvae_feed_stats(const hlvae_plan* p, const hlvae_ws* ws, const float* valu
                       int B, hlvae_stream s);
 int  hlvae_feed_pack(const hlvae_plan* p, const hlvae_ws* ws, const float* values, const uint8_t* mask8, const int32_t* rows,
                      int B, hlvae_stream s);
+
+/* statistics + pack in one call for single-process training (no statistics all-reduce between the passes); skips the
+ * statistics pass when no column needs it (convolutional model without pos variables). */
+int  hlvae_normalize_fused(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask, int B, hlvae_stream s);
+int  hlvae_feed_fused(const hlvae_plan* p, const hlvae_ws* ws, const float* values, const uint8_t* mask8, const int32_t* rows,
+                      int B, hlvae_stream s);
 
 /* bf16 shadows of the dense weights from the fp32 arena (no reference counterpart: the reference
  * computes in fp64; BASELINE.json config 2 asks for bf16 encoder/decoder) */
