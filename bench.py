@@ -45,9 +45,10 @@ def parse():
     ap.add_argument("--prefetch", action="store_true",
                     help="run the NEXT batch's input stage on a side stream inside each step (measured slower on MI355X: a forked "
                          "branch in the HIP graph costs more than the 31 us it hides; DESIGN.md section 5)")
-    ap.add_argument("--feed", default="fp64", choices=["fp64", "compact"],
-                    help="fp64: the reference's expanded fp64 batch tensors resident in HBM (drop-in call surface); compact: the "
-                         "whole dataset resident in HBM at 5 B/entry, a batch = a vector of row indices (SURVEY 8(f).3)")
+    ap.add_argument("--feed", default="compact", choices=["fp64", "compact"],
+                    help="compact (default): the whole dataset resident in HBM at 5 B/entry, a batch = a vector of row indices, "
+                         "the input stage gathers on the device (SURVEY 8(f).3; bit-identical packed inputs, tested); fp64: "
+                         "the reference's expanded fp64 batch tensors resident in HBM (the drop-in HLVAE.forward call surface)")
     ap.add_argument("--conv", action="store_true",
                     help="convolutional encoder/decoder (conv_hivae = True, what config/hlvae_config_file.txt:51 selects) "
                          "instead of the MLP the north star names")
@@ -154,10 +155,9 @@ def main():
     # (row A depends on the data only).  Every step still runs exactly one input stage inside the timed region.
     nxt = lambda i: (ring[(i + 1) % len(ring)]["data"], ring[(i + 1) % len(ring)]["mask"])
     pipelined = a.prefetch
-    compact = a.feed == "compact"
+    compact = a.feed == "compact" and kl != "gp"       # the GP variant takes the batch's covariates as a tensor (fp64 feed)
     if compact:
         from hlvae_amd.datafeed import CompactDataset
-        assert kl != "gp", "--feed compact with --kl gp: not wired in bench.py"
         dsd = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
         for b in ring:
             b["rows_dev"] = torch.tensor(b["rows"].astype(np.int32), device=dev)
@@ -213,9 +213,9 @@ def main():
     roof = roofline.measure_dominant_kernel(trainer, ring[0], a.steps, ds=dsd if compact else None) if rank == 0 else None
     if roof is not None:      # HBM traffic from PMC counters is collected offline (separate rocprofv3 --pmc passes)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if pm["kernel"].startswith("k_adam_tiled") and roof["kernel"] == "adam_weights_shadows":
-                roof["traffic"] = pm["traffic_bytes_per_launch"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
+            if roof["kernel"] in pm and not a.conv and kl != "gp":
+                roof["traffic"] = pm[roof["kernel"]]["traffic_bytes_per_launch"]
         except Exception:
             pass
 
