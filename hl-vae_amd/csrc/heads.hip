@@ -430,6 +430,33 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
     const int NY = D * YD;
     float* Cs = reinterpret_cast<float*>(smem);
     const bool conv = ysrc != nullptr;
+    // Parameter prefetch: the heads' weights hang off a dependent chain (vars[d] -> arena offsets -> P[...]) that used to sit,
+    // exposed, between the GEMM and the log-likelihoods.  16 lanes (one per variable of the tile) walk that chain NOW, keep
+    // the values in registers under the GEMM main loop and park them in LDS afterwards; the epilogue then reads LDS only.
+    constexpr int PW = YD * (KMAX - 1), PB = KMAX - 1, PS = PW + 2 * PB + 2;           // [w | b | e | mean, var]
+    static_assert(16 * PS * 4 <= RED_BYTES, "parameter scratch shares the LDS of the gradient reduction");
+    float* pscr = reinterpret_cast<float*>(smem + Gm::SMEM_BYTES);                     // = red, used strictly before it
+    const int tid = threadIdx.x, v = tid & 15, rg = tid >> 4;
+    const int d = tn * 16 + v;
+    hlvae_var var;
+    var.kind = -1;
+    if (d < D) var = vars[d];
+    float pre[PS];
+    if (tid < 16 && d < D) {
+        const int K1 = var.ncls - 1;
+        const bool cont = var.kind == HLVAE_REAL || var.kind == HLVAE_POS;
+        const int nw = var.kind == HLVAE_CAT ? YD * K1 : YD, nb = var.kind == HLVAE_CAT ? K1 : 1;
+        const int ne = cont ? 1 : (var.kind == HLVAE_ORDINAL ? K1 : 0);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) pre[i] = i < nw ? P[var.w_off + i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            pre[PW + i] = i < nb ? P[var.b_off + i] : 0.f;
+            pre[PW + PB + i] = i < ne ? P[var.e_off + i] : 0.f;
+        }
+        pre[PW + 2 * PB] = cont ? norm[var.sidx] : 0.f;
+        pre[PW + 2 * PB + 1] = cont ? norm[n_stat + var.sidx] : 1.f;
+    }
     if (!conv) {
         typename Gm::Acc accm;
         Gm::zero(accm);
@@ -444,21 +471,29 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
     }
     float* red = reinterpret_cast<float*>(smem + Gm::SMEM_BYTES);
 
-    const int tid = threadIdx.x, v = tid & 15, rg = tid >> 4;
-    const int d = tn * 16 + v;
+    if (tid < 16 && d < D) {
+#pragma unroll
+        for (int i = 0; i < PS; ++i) pscr[v * PS + i] = pre[i];
+    }
+    __syncthreads();
     float acc[NACC];
 #pragma unroll
     for (int n = 0; n < NACC; ++n) acc[n] = 0.f;
     float lpo[BM / 16];
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) lpo[i] = 0.f;
-    hlvae_var var;
-    var.kind = -1;
     if (d < D) {
-        var = vars[d];
-        float byv[YD];
+        float byv[YD];                        // y_layer's bias: independent loads, in flight together with the targets
 #pragma unroll
         for (int k = 0; k < YD; ++k) byv[k] = conv ? 0.f : P[o_by + (long)d * YD + k];
+        // from here on the "arena" and the statistics are this variable's slice of the LDS scratch
+        const float* P = pscr;
+        const float* norm = pscr;
+        const int n_stat = 1;
+        var.w_off = v * PS;
+        var.b_off = v * PS + PW;
+        var.e_off = v * PS + PW + PB;
+        var.sidx = v * PS + PW + 2 * PB;
         switch (var.kind) {
             case HLVAE_REAL:
                 proc_realpos<YD, BM, CLD, NACC>(false, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
@@ -510,6 +545,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
         if (v == 0 && gr < Bp) rowpart[(size_t)tn * Bp + gr] = gr < B ? s : 0.f;
     }
     if (!want_grad) return;
+    __syncthreads();                       // every wave is done with the parameter scratch that `red` overlays
     // head-parameter gradients: 4 lane groups of a wave share v -> shuffle, then 4 waves through LDS
     const int wave = tid >> 6;
 #pragma unroll
