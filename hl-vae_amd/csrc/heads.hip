@@ -567,26 +567,40 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
                           red[(2 * 16 + vv) * NACC + n] + red[(3 * 16 + vv) * NACC + n];
         atomicAdd(G + dst, sum);
     }
-    // dY tile -> HBM (bf16, both layouts) and d by = column sums
-    // (two bf16 per 32-bit store; columns in [NY, NYp) of the tile are zero, so pairs may spill into the padding)
-    for (int idx = tid; idx < BM * BN / 2; idx += HL_THREADS) {
-        const int r = idx / (BN / 2), c = (idx % (BN / 2)) * 2;
-        if (n0 + c < lddy)
-            *reinterpret_cast<uint32_t*>(dy + (size_t)(m0 + r) * lddy + n0 + c) =
-                (uint32_t)f2bf(Cs[r * CLD + c]) | ((uint32_t)f2bf(Cs[r * CLD + c + 1]) << 16);
+    // dY tile -> HBM (bf16, both layouts) and d by = column sums.  One 16-byte store (8 bf16) per task; the kernel is bound
+    // by instruction issue (PMC: 29 % active + 20 % issue stalls at 3 waves / SIMD), and the element-pair version of these
+    // loops was ~40 % of its VALU instructions.
+    auto pack8 = [](const float* p, int stride) {
+        uint4 o;
+        o.x = (uint32_t)f2bf(p[0]) | ((uint32_t)f2bf(p[stride]) << 16);
+        o.y = (uint32_t)f2bf(p[2 * stride]) | ((uint32_t)f2bf(p[3 * stride]) << 16);
+        o.z = (uint32_t)f2bf(p[4 * stride]) | ((uint32_t)f2bf(p[5 * stride]) << 16);
+        o.w = (uint32_t)f2bf(p[6 * stride]) | ((uint32_t)f2bf(p[7 * stride]) << 16);
+        return o;
+    };
+    constexpr int CCH = BN / 8;                                   // 8-column chunks per tile row
+    for (int idx = tid; idx < BM * CCH; idx += HL_THREADS) {
+        const int r = idx / CCH, c = (idx % CCH) * 8;
+        if (n0 + c + 8 <= lddy) {
+            *reinterpret_cast<uint4*>(dy + (size_t)(m0 + r) * lddy + n0 + c) = pack8(Cs + r * CLD + c, 1);
+        } else {
+            for (int e = 0; e < 8; ++e)
+                if (n0 + c + e < lddy) dy[(size_t)(m0 + r) * lddy + n0 + c + e] = f2bf(Cs[r * CLD + c + e]);
+        }
     }
     if (conv) return;
-    for (int idx = tid; idx < BM * BN / 2; idx += HL_THREADS) {
-        const int c = idx / (BM / 2), r = (idx % (BM / 2)) * 2;
-        if (n0 + c < NY)
-            *reinterpret_cast<uint32_t*>(dyT + (size_t)(n0 + c) * Bp + m0 + r) =
-                (uint32_t)f2bf(Cs[r * CLD + c]) | ((uint32_t)f2bf(Cs[(r + 1) * CLD + c]) << 16);
-    }
-    for (int c = tid; c < BN; c += HL_THREADS) {
-        if (n0 + c >= NY) continue;
+    constexpr int RCH = BM / 8;                                   // 8-row chunks per tile column: 8 consecutive lanes = 1 column
+    for (int idx = tid; idx < BN * RCH; idx += HL_THREADS) {
+        const int c = idx / RCH, r = (idx % RCH) * 8;
+        const float* src = Cs + r * CLD + c;
         float s = 0.f;
-        for (int r = 0; r < BM; ++r) s += Cs[r * CLD + c];
-        atomicAdd(G + o_by + n0 + c, s);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += src[e * CLD];
+        if (n0 + c < NY) *reinterpret_cast<uint4*>(dyT + (size_t)(n0 + c) * Bp + m0 + r) = pack8(src, CLD);
+        // d by[c] = column sum: the RCH lanes of a column are consecutive
+#pragma unroll
+        for (int o = 1; o < RCH; o <<= 1) s += __shfl_xor(s, o, 64);
+        if ((idx % RCH) == 0 && n0 + c < NY) atomicAdd(G + o_by + n0 + c, s);
     }
 }
 
