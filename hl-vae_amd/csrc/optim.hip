@@ -14,8 +14,8 @@ struct AdamScalars {
     float step_size, rs_bc2, b1, b2, eps, gscale;
 };
 
-// step_count[0] = completed steps (read by k_adam_flat, which publishes step_count[1] = step_count[0] + 1);
-// k_adam_tiled reads step_count[1] and copies it back to step_count[0] when it is done.  One writer each,
+// step_count[0] = completed steps; every Adam kernel of a step uses step_count[0] + 1; the launch that finishes the step
+// commits it through a ticket in step_count[1] (last workgroup to finish).  One writer,
 // ordered by the stream, so no separate "increment" launch is needed.
 __device__ __forceinline__ AdamScalars adam_scalars(float t, float lr, float b1, float b2, float eps, float gscale) {
     AdamScalars a;
@@ -76,12 +76,38 @@ struct ShadowSet {
 __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float* __restrict__ P, const float* __restrict__ G,
                                                            float* __restrict__ M1, float* __restrict__ M2,
                                                            int64_t* __restrict__ step_count, float lr, float b1,
-                                                           float b2, float eps, float gscale, int update) {
-    // update: 0 = shadows only; 1 = Adam with the step number k_adam_flat published in step_count[1], the last workgroup
-    // commits it to step_count[0]; 2 = Adam with step_count[0] + 1, nothing committed (a matrix updated EARLY, while the rest
-    // of the backward pass is still running: hlvae_backward_adam)
+                                                           float b2, float eps, float gscale, int update, long n4_flat) {
+    // update: 0 = shadows only; 1 or 2 = Adam with step number step_count[0] + 1.  1: this is the launch that finishes the
+    // optimiser step: workgroups past the tiles update the small flat region [0, 4 n4_flat) and zero its gradients, and
+    // the LAST workgroup to finish (ticket in step_count[1]) commits the step number.  2: nothing committed (a matrix
+    // updated EARLY, while the rest of the backward pass is still running: hlvae_backward_adam).
     constexpr int T = 64, CLD = T + 1;
     __shared__ float tile[T * CLD];
+    if ((int)blockIdx.x >= set.total_tiles) {                       // flat region (update == 1 only)
+        const AdamScalars a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
+        float4* P4 = reinterpret_cast<float4*>(P);
+        float4* G4 = reinterpret_cast<float4*>(const_cast<float*>(G));
+        float4* M14 = reinterpret_cast<float4*>(M1);
+        float4* M24 = reinterpret_cast<float4*>(M2);
+        const long nfb = (long)gridDim.x - set.total_tiles;
+        for (long i = ((long)blockIdx.x - set.total_tiles) * HL_THREADS + threadIdx.x; i < n4_flat; i += nfb * HL_THREADS) {
+            float4 p = P4[i], g = G4[i], m = M14[i], v = M24[i];
+            p.x = adam_one(p.x, g.x, m.x, v.x, a);
+            p.y = adam_one(p.y, g.y, m.y, v.y, a);
+            p.z = adam_one(p.z, g.z, m.z, v.z, a);
+            p.w = adam_one(p.w, g.w, m.w, v.w, a);
+            P4[i] = p;
+            M14[i] = m;
+            M24[i] = v;
+            G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);           // the atomically accumulated gradients start the next step at 0
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
+            if (done == gridDim.x - 1) { step_count[1] = 0; step_count[0] += 1; }
+        }
+        return;
+    }
     int mi = 0;
 #pragma unroll
     for (int k = 1; k < 5; ++k)
@@ -90,7 +116,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
     const int tl = blockIdx.x - mt.tile0;
     const int r0 = (tl / mt.tiles_c) * T, c0 = (tl % mt.tiles_c) * T;
     AdamScalars a;
-    if (update) a = adam_scalars((float)(update == 2 ? step_count[0] + 1 : step_count[1]), lr, b1, b2, eps, gscale);
+    if (update) a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
     const int c4 = (threadIdx.x & 15) * 4, rq = threadIdx.x >> 4;      // 16 float4 per tile row, 16 rows per pass
     // all 16 global loads of this lane are issued before the first store (a store to P / M1 / M2 orders every later load
     // from the same array behind it): unconditional loads from clamped addresses, predicated stores
@@ -150,7 +176,13 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
             }
         }
     }
-    if (update == 1 && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) step_count[0] = step_count[1];
+    if (update == 1) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
+            if (done == gridDim.x - 1) { step_count[1] = 0; step_count[0] += 1; }
+        }
+    }
 }
 
 static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws, unsigned which = 0x1f) {
@@ -203,7 +235,7 @@ int hl_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s) {
     if (int rc = check_set(set)) return rc;
     {
         HL_PROF("shadow_cast", s);
-        k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0);
+        k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0);
         HL_LAUNCH_CHECK();
     }
     if (p->d.conv) return hl_conv_pack_weights(p, ws, s);
@@ -216,7 +248,7 @@ int hl_adam_early_wy(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* 
     const ShadowSet set = make_set(p, ws, 0x01);
     if (int rc = check_set(set)) return rc;
     HL_PROF("adam_wy_early", s);
-    k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 2);
+    k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 2, 0);
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -229,18 +261,14 @@ int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64
     int blocks = (int)((n4 + HL_THREADS - 1) / HL_THREADS);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    // the two launches touch disjoint parts of the arena; k_adam_tiled only needs step_count[1] from k_adam_flat,
-    // so the (tiny) flat launch goes first on the same stream and costs one boundary, no fork needed
-    {
-        HL_PROF("adam_small", s);
-        k_adam_flat<<<blocks, HL_THREADS, 0, s>>>(ws->P, ws->G, m1, m2, n4, step_count, lr, b1, b2, eps, gscale, 1);
-    }
-    HL_LAUNCH_CHECK();
+    // ONE launch: the weight tiles plus `blocks` workgroups for the small flat region (disjoint parts of the arena)
+    if (blocks > 64) blocks = 64;
     const ShadowSet set = make_set(p, ws, skip_wy ? 0x1e : 0x1f);
     if (int rc = check_set(set)) return rc;
     {
         HL_PROF("adam_weights_shadows", s);
-        k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 1);
+        k_adam_tiled<<<set.total_tiles + blocks, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale,
+                                                                    1, n4);
     }
     HL_LAUNCH_CHECK();
     if (d.conv) return hl_conv_pack_weights(p, ws, s);       // the convolution weights live in the small (atomic) region
