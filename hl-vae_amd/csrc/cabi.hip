@@ -141,8 +141,10 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
         const hlvae_var& v = vars[i];
         HL_REQUIRE(v.kind >= HLVAE_REAL && v.kind <= HLVAE_ORDINAL, HLVAE_EINVAL, "variable %d: kind %d", i, v.kind);
         const bool disc = v.kind == HLVAE_CAT || v.kind == HLVAE_ORDINAL;
-        HL_REQUIRE(disc ? (v.ncls >= 2 && v.ncls <= 8) : v.ncls == 1, HLVAE_EINVAL,
-                   "variable %d: nclass %d unsupported (cat/ordinal: 2..8)", i, v.ncls);
+        HL_REQUIRE(disc ? (v.ncls >= 2 && v.ncls <= 16) : v.ncls == 1, HLVAE_EINVAL,
+                   "variable %d: nclass %d unsupported (cat/ordinal: 2..16)", i, v.ncls);
+        HL_REQUIRE(!(disc && v.ncls > 8) || d.y_dim == 5, HLVAE_EINVAL, "variable %d: more than 8 classes is instantiated for "
+                   "y_dim = 5 only", i);
         HL_REQUIRE(v.xoff == x, HLVAE_EINVAL, "variable %d: xoff %d, expected %d", i, v.xoff, x);
         HL_REQUIRE(v.w_off >= 0 && v.b_off >= 0 && v.w_off < d.atomic_region && v.b_off < d.atomic_region,
                    HLVAE_EINVAL, "variable %d: head offsets outside the atomic gradient region", i);

@@ -783,7 +783,8 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
         } else
         if (p->kmax <= 3) { if (big) HL_LAUNCH_HEADS(128, 3); else HL_LAUNCH_HEADS(64, 3); }
         else if (p->kmax <= 5) { if (big) HL_LAUNCH_HEADS(128, 5); else HL_LAUNCH_HEADS(64, 5); }
-        else { if (big) HL_LAUNCH_HEADS(128, 8); else HL_LAUNCH_HEADS(64, 8); }
+        else if (p->kmax <= 8) { if (big) HL_LAUNCH_HEADS(128, 8); else HL_LAUNCH_HEADS(64, 8); }
+        else { const int g64 = NT * (Bp / 64); const int grid = g64; HL_LAUNCH_HEADS(64, 16); }      // 9..16 classes: one instance
 #undef HL_LAUNCH_HEADS
 #undef HL_LAUNCH_HEADS_Y
     }

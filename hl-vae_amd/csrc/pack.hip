@@ -117,22 +117,24 @@ __global__ __launch_bounds__(HL_PACK_THREADS) void k_normalize_pack(
         if (first && b < B) {
             float tv = logk && kind == HLVAE_POS ? fr : raw;                  // real, count: raw x; pos: log1p x
             if (disc) {
-                float v[8];
+                float v[16];                              // K <= 16; columns past the 8th come straight from memory
                 v[0] = raw;
 #pragma unroll
                 for (int k = 1; k < 8; ++k)
                     v[k] = (k < K) ? (fits ? nb[k - 1] : (float)dcol[(size_t)bc * X + k]) : 0.f;
+#pragma unroll
+                for (int k = 8; k < 16; ++k) v[k] = (k < K) ? (float)dcol[(size_t)bc * X + k] : 0.f;
                 if (kind == HLVAE_CAT) {                  // one-hot -> class index, -1 if the row is all zero
                     int cls = -1;
                     float best = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
+                    for (int k = 0; k < 16; ++k)
                         if (k < K && v[k] > best) { best = v[k]; cls = k; }
                     tv = (float)cls;
                 } else {                                  // thermometer -> sum(int(data)) - 1 (loglik.py:172)
                     int sum = 0;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
+                    for (int k = 0; k < 16; ++k)
                         if (k < K) sum += (int)v[k];
                     tv = (float)(sum - 1);
                 }

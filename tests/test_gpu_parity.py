@@ -690,3 +690,34 @@ def test_other_y_dim_against_oracle(y_dim):
               "obs_layer.2.weight_region", "obs_layer.2.weight_thresholds"):
         if k in sd and st[k].grad is not None:
             assert rel_err(sd[k].grad, st[k].grad) < 5e-2, k
+
+
+def test_wide_categorical_and_ordinal_against_oracle():
+    """class counts 9..16 (one extra head-kernel instance): a 12-class categorical and a 10-class ordinal variable among the
+    usual mix, forward + backward against the oracle."""
+    import hlvae_oracle as orc
+    dev = _dev()
+    spec = [("real", 1), ("cat", 12), ("pos", 1), ("ordinal", 10), ("count", 1), ("cat", 5), ("ordinal", 4), ("cat", 16),
+            ("real", 1), ("pos", 1)]          # X = 52 (the first Linear wants a multiple of 4)
+    src = synthetic.make_tabular(n_rows=60, T=6, seed=17, spec=spec)
+    dims = [src.cov_dim_ext, [16], 4, [16], 5]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=31, std=0.2)
+    model = _model_from_state(src, dims, state)
+    rows = np.arange(60)
+    eps = torch.randn(60, dims[2], generator=torch.Generator().manual_seed(8))
+    data, mask = torch.tensor(src.data[rows], device=dev), torch.tensor(src.mask[rows], device=dev)
+    out = model(data, mask, None, src.types_info, eps=eps.to(dev))
+    loss = 0.7 * model.loss_function(out[3]).sum() - 0.5 * torch.sum(1.0 + out[2] - out[1] ** 2 - torch.exp(out[2]))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref, ref_loss, st = _oracle_step(src, rows, dims, state, eps, 0.7)
+    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    e = np.abs(out[3].detach().double().cpu().numpy() - ref["log_p_x"].detach().numpy())
+    assert np.all(e <= 5e-2 + 3e-2 * np.abs(ref["log_p_x"].detach().numpy()))
+    sd = dict(model.named_parameters())
+    n = 0
+    for k, p in sd.items():
+        if k.startswith("obs_layer.") and st[k].grad is not None and st[k].grad.numel() and float(st[k].grad.abs().max()) > 0:
+            assert rel_err(p.grad, st[k].grad) < 5e-2, k
+            n += 1
+    assert n >= 8
