@@ -33,6 +33,28 @@ import torch
 from . import GP_model
 
 
+class _GroupCache:
+    """Subject grouping of resident batch tensors, computed once per tensor (torch.unique is a host sync and cannot be
+    captured in a HIP graph).  An entry keeps a reference to its tensor, so the allocator cannot hand the same address to a
+    different batch while the entry lives; least-recently-used entries are dropped beyond ``capacity``."""
+
+    def __init__(self, capacity: int = 32):
+        from collections import OrderedDict
+        self.capacity, self.d = capacity, OrderedDict()
+
+    def get(self, train_x: torch.Tensor, build):
+        key = (train_x.data_ptr(), tuple(train_x.shape), train_x._version)
+        hit = self.d.get(key)
+        if hit is not None:
+            self.d.move_to_end(key)
+            return hit[1]
+        val = build(train_x)
+        self.d[key] = (train_x, val)
+        while len(self.d) > self.capacity:
+            self.d.popitem(last=False)
+        return val
+
+
 def subject_groups(ids: torch.Tensor):
     """rows -> ([S, Tmax] row index, [S, Tmax] validity) for the subjects present in ``ids`` (sorted by id,
     as torch.unique does in the reference, elbo_functions.py:242)."""
@@ -145,7 +167,7 @@ class GPPrior:
         self.opt = torch.optim.Adam(params, lr=lr)                                         # :277-278
         self.last_kld = None
         self._grad_m = self._grad_H = None
-        self._groups = {}
+        self._groups = _GroupCache()
 
     @classmethod
     def from_reference_config(cls, model, src, P_total, dev, M=120):
@@ -157,10 +179,7 @@ class GPPrior:
                      groups=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """KL value (kept in ``last_kld``) and its gradients w.r.t. the encoder outputs, as fp32 [B, L]."""
         if groups is None:       # batch composition is static per resident batch tensor: group once, no host sync afterwards
-            key = (train_x.data_ptr(), train_x.shape[0])
-            if key not in self._groups:
-                self._groups[key] = subject_groups(train_x[:, self.id_covariate])
-            groups = self._groups[key]
+            groups = self._groups.get(train_x, lambda t: subject_groups(t[:, self.id_covariate]))
         mu_ = mu.detach().to(torch.float64).requires_grad_(True)
         lv_ = log_v.detach().to(torch.float64).requires_grad_(True)
         self.opt.zero_grad(set_to_none=True)
@@ -289,7 +308,7 @@ class GPPriorHIP:
         self.fail = torch.zeros(1, dtype=torch.int32, device=dev)
         self._xchg = torch.zeros(L * M * M + 2 * L * M + 1, **f64)    # [W | P1 | u | bound]: the one DP exchange buffer
         self.last_kld = self._xchg[-1:]
-        self._groups = {}
+        self._groups = _GroupCache()
         self._grad_m = self._grad_H = self._iH = None
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
             for t in (self._theta, self.m, self._KH):
@@ -331,12 +350,11 @@ class GPPriorHIP:
         return inv, logdet
 
     def _group(self, train_x):
-        key = (train_x.data_ptr(), train_x.shape[0])
-        if key not in self._groups:
-            idx, valid = subject_groups(train_x[:, self.id_covariate])
-            idx32 = torch.where(valid > 0, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
-            self._groups[key] = idx32
-        return self._groups[key]
+        def build(t):
+            idx, valid = subject_groups(t[:, self.id_covariate])
+            return torch.where(valid > 0, idx, torch.full_like(idx, -1)).to(torch.int32).contiguous()
+
+        return self._groups.get(train_x, build)
 
     # ---- the KL bound, its gradients, the natural-gradient terms ------------------------------------------------
     def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None):

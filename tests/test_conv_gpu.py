@@ -215,3 +215,38 @@ def test_conv_step_metrics_against_reference_fixture(golden_dir):
     assert np.allclose(eo[~disc], g["err_observed"][~disc], rtol=5e-2, atol=5e-3)
     assert np.allclose(em[~disc], g["err_missing"][~disc], rtol=5e-2, atol=5e-3)
     assert np.mean(np.abs(eo[disc] - g["err_observed"][disc]) <= 1.0 / 4) > 0.97
+
+
+def test_shipped_configuration_end_to_end():
+    """config/hlvae_config_file.txt as shipped: convolutional encoder/decoder + GP prior (natural-gradient m, H), whole
+    subjects per batch from the device-resident compact dataset, shuffled per epoch -- the hensman_training loop
+    (training.py:62-143) on the HIP path for a few epochs: finite everywhere, NLL and KL bound go down."""
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    from hlvae_amd.datafeed import CompactDataset, SubjectBatchSampler
+    from hlvae_amd.elbo_functions import GPPriorHIP
+    dev = torch.device("cuda:0")
+    src = synthetic.make_d4(n_subjects=12, T=10, seed=9)
+    ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate)
+    dsd = ds.to(dev)
+    torch.manual_seed(0)
+    model = HLVAE([src.cov_dim_ext, [64], 8, [64], 5], src.types_info, src.n_variables, conv=True, max_batch=128,
+                  materialize_samples=False).to(dev)
+    gp = GPPriorHIP(8, dsd.labels, 16, src.id_covariate, N_total=len(ds))
+    tr = ELBOTrainer(model, P_total=12, kl="gp", gp=gp, max_batch=128, metrics=True)
+    sampler = SubjectBatchSampler(ds.labels[:, src.id_covariate], subjects_per_batch=4, shuffle=True, seed=3)
+    hist = []
+    for epoch in range(6):
+        nll = kld = 0.0
+        for rows, P_b in sampler:
+            r = torch.as_tensor(rows, device=dev)
+            data, mask = ds.expand(rows)
+            tr.step(torch.tensor(data, device=dev), torch.tensor(mask, device=dev), P_b, train_x=dsd.labels[r.long()])
+            nll += float(tr.scalars()["nll_sum"])
+            kld += float(gp.last_kld)
+        hist.append((nll, kld))
+    assert all(np.isfinite(h).all() for h in hist), hist
+    assert hist[-1][0] < hist[0][0] and hist[-1][1] < hist[0][1], hist
+    assert int(gp.fail.item()) == 0
+    Zp = gp.batch_predict_varying_T(dsd.labels, dsd.labels[:7], torch.randn(len(ds), 8, device=dev))
+    assert tuple(Zp.shape) == (7, 8) and bool(torch.isfinite(Zp).all())
