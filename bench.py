@@ -124,12 +124,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # one rank per GPU.  Rehearsal on a box with fewer GPUs than ranks (HLVAE_BENCH_BACKEND=gloo): ranks share the devices
+    backend = os.environ.get("HLVAE_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dp = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
         from hlvae_amd.parallel import DataParallel
         dp = DataParallel(dist.group.WORLD)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
@@ -210,7 +213,10 @@ def main():
     if rank == 0:
         print(f"[bench] {world} GPU(s): {value:.0f} samples/s, {1e3 * dt / a.steps:.4f} ms/step", file=sys.stderr, flush=True)
     from hlvae_amd import roofline
-    roof = roofline.measure_dominant_kernel(trainer, ring[0], a.steps, ds=dsd if compact else None) if rank == 0 else None
+    # every rank runs the eager per-kernel pass (the data-parallel step contains collectives); rank 0 reports
+    roof = roofline.measure_dominant_kernel(trainer, ring[0], a.steps, ds=dsd if compact else None)
+    if rank != 0:
+        roof = None
     if roof is not None:      # HBM traffic from PMC counters is collected offline (separate rocprofv3 --pmc passes)
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]

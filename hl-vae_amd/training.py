@@ -80,6 +80,7 @@ class ELBOTrainer:
         m._ensure_device_state(B)
         m._run_normalize(data, mask, B, self.dp.allreduce_stats if self.dp is not None else None)
         m._packed_key = self._batch_key(data, mask)
+        self._pf_ref = (data, mask)
 
     def step(self, data: torch.Tensor, mask: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None,
              train_x: Optional[torch.Tensor] = None, prefetch=None, prepacked: Optional[bool] = None):
@@ -180,8 +181,10 @@ class ELBOTrainer:
             torch.cuda.current_stream(m.device).wait_stream(self._pf_stream)
             m._swap_input_buffers()
             m._packed_key = self._batch_key(prefetch[0], prefetch[1])
+            self._pf_ref = prefetch          # keep the tensors alive: their addresses identify the packed batch
         else:
             m._packed_key = None
+            self._pf_ref = None
 
     # -- captured -------------------------------------------------------------------------------
     def capture(self, key, data: torch.Tensor, mask: torch.Tensor, P_batch: int, train_x=None, prefetch=None):

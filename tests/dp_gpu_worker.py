@@ -60,12 +60,15 @@ def main():
         tr_s.step(t(src.data), t(src.mask), P_batch, eps=eps[i].to(dev), train_x=t(src.labels))
         nll_s.append(float(tr_s.scalars()["nll_sum"]))
         kld_s.append(float(gp_s.last_kld) if gp_s is not None else float(tr_s.scalars()["kl"]))
-    # data parallel, this rank's subjects
+    # data parallel, this rank's subjects, fed from the device-resident compact dataset (what bench.py --gpus N runs)
+    from hlvae_amd.datafeed import CompactDataset
+    dsd = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    rows_dev = torch.tensor(rows.astype(np.int32), device=dev)
     dp = DataParallel(dist.group.WORLD)
     model_d, gp_d, tr_d = build(dp)
     nll_d, kld_d = [], []
     for i in range(steps):
-        tr_d.step(t(src.data, rows), t(src.mask, rows), P_batch, eps=eps[i][rows].to(dev), train_x=t(src.labels, rows))
+        tr_d.step_rows(dsd, rows_dev, P_batch, eps=eps[i][rows].to(dev))
         part = torch.stack([tr_d.scalars()["nll_sum"].double().reshape(()), tr_d.scalars()["kl"].double().reshape(())])
         dist.all_reduce(part)
         nll_d.append(float(part[0]))
