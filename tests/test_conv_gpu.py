@@ -250,3 +250,18 @@ def test_shipped_configuration_end_to_end():
     assert int(gp.fail.item()) == 0
     Zp = gp.batch_predict_varying_T(dsd.labels, dsd.labels[:7], torch.randn(len(ds), 8, device=dev))
     assert tuple(Zp.shape) == (7, 8) and bool(torch.isfinite(Zp).all())
+
+
+def test_conv_test_samples_and_decode_against_fixture(golden_dir):
+    """row T with the convolutional model: get_test_samples (HLVAE.py:455-475) against the reference's output, and the
+    stand-alone decode(z) entry (HLVAE.py:326-349) reproducing the forward's log-likelihoods from its own z."""
+    g, src, dims, model, om, st, dev = _setup(golden_dir)
+    data, mask = torch.tensor(src.data[:8], device=dev), torch.tensor(g["mask"], device=dev)
+    qs, qp, ps, pp, lpt, lpmt = model.get_test_samples(data, mask, None)
+    assert max_abs_err(qp["z"][0].cpu(), g["test_mu"]) < 2e-2
+    ref = g["test_log_p_x"]
+    assert np.all(np.abs(lpt.detach().double().cpu().numpy() - ref) <= 3e-2 + 2e-2 * np.abs(ref))
+    with torch.no_grad():
+        out = model(data, mask, None, src.types_info, eps=torch.tensor(g["eps"], device=dev))
+        lp2, lpm2, _, _ = model.decode(out[6]["z"], data, mask, None)
+    assert max_abs_err(lp2.cpu(), out[3].cpu()) < 1e-4
