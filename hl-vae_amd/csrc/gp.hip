@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     double* __restrict__ part, float* __restrict__ g_mu, float* __restrict__ g_lv) {
     __shared__ double xs[GP_TMAX * GP_XS];
     __shared__ double ib[GP_TMAX * GP_TS];
-    __shared__ double ks[GP_TMAX * GP_MMAX];              // the subject's rows of K0xz
+    extern __shared__ __attribute__((aligned(16))) char dsm_fwd[];
+    double* ks = reinterpret_cast<double*>(dsm_fwd);      // the subject's rows of K0xz, [T][M] (sized for the actual T, M:
+                                                          // 19 KB at T = 20, M = 120 -> five workgroups per CU instead of three)
     __shared__ double gjrow[2 * GP_TMAX], gjcol[2 * GP_TMAX], pv[GP_TMAX], rs[GP_TMAX];
     __shared__ int rows[GP_TMAX];
     __shared__ double red[3][4];
@@ -665,7 +667,7 @@ int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, c
     HL_REQUIRE(T >= 1 && T <= GP_TMAX && S >= 1 && Q <= 8 && M <= GP_MMAX, HLVAE_ESHAPE,
                "gp_subject_fwd: T=%d (max %d), M=%d (max %d)", T, GP_TMAX, M, GP_MMAX);
     HL_PROF("gp_subject_fwd", (hipStream_t)s);
-    k_gp_subject_fwd<<<dim3(S, L), 256, 0, (hipStream_t)s>>>(*k0, *k1, hyp, n_slots, L, Q, x, noise, idx, T, Kxz, B, M, resid,
+    k_gp_subject_fwd<<<dim3(S, L), 256, (size_t)T * M * sizeof(double), (hipStream_t)s>>>(*k0, *k1, hyp, n_slots, L, Q, x, noise, idx, T, Kxz, B, M, resid,
                                                            lv, c, iB, K0s, V, v, part, g_mu, g_lv);
     HL_LAUNCH_CHECK();
     return 0;

@@ -306,6 +306,13 @@ class GPPriorHIP:
         self.H.copy_(Hh @ Hh.transpose(-1, -2) + 1e-6 * torch.eye(M, **f64))
         self.noise = torch.ones(L, **f64)                                                           # HLVAE_main.py:211-213
         self.fail = torch.zeros(1, dtype=torch.int32, device=dev)
+        # factorisation cache: the end of a step inverts [iH_new | K0zz of the UPDATED hyper-parameters] in one launch, so
+        # the next step starts with iK, iH and both log-determinants in hand (one batched inversion per step, not two)
+        self._KH2, self._inv2 = torch.zeros(2 * L, M, M, **f64), torch.zeros(2 * L, M, M, **f64)
+        self._ld2 = torch.zeros(2 * L, **f64)
+        self._iK, self._iHb = torch.zeros(L, M, M, **f64), torch.zeros(L, M, M, **f64)
+        self._ldK, self._ldH = torch.zeros(L, **f64), torch.zeros(L, **f64)
+        self._fact_key = None
         self._xchg = torch.zeros(L * M * M + 2 * L * M + 1, **f64)    # [W | P1 | u | bound]: the one DP exchange buffer
         self.last_kld = self._xchg[-1:]
         self._groups = _GroupCache()
@@ -341,10 +348,9 @@ class GPPriorHIP:
                    "gp_kernel_matrix")
         return out
 
-    def chol_inv(self, A):
+    def chol_inv(self, A, out=None):
         n, N = A.shape[0], A.shape[-1]
-        inv = torch.empty_like(A)
-        logdet = torch.empty(n, dtype=torch.float64, device=A.device)
+        inv, logdet = out if out is not None else (torch.empty_like(A), torch.empty(n, dtype=torch.float64, device=A.device))
         _lib.check(_lib.load().hlvae_gp_chol_inv(_lib.ptr(A), n, N, _lib.ptr(inv), _lib.ptr(logdet), _lib.ptr(self.fail),
                                                  self._stream()), "gp_chol_inv")
         return inv, logdet
@@ -370,11 +376,14 @@ class GPPriorHIP:
         k0, k1, z = self.k0, self.k1, self.zt_list
         hyp = self._transform()
         f64 = dict(dtype=torch.float64, device=dev)
-        # kernel matrices and the two M x M inversions (both in ONE batched launch: K0zz is written next to H)
-        self.kernel_matrix(k0, z, z, jitter=self.eps, out=self._KH[:L])
         Kxz = self.kernel_matrix(k0, x, z)
-        inv, logdet = self.chol_inv(self._KH)
-        iK, iH, ldK, ldH = inv[:L], inv[L:], logdet[:L], logdet[L:]
+        if self._fact_key != (self._theta._version, self._KH._version):
+            # no factorisation left behind by the previous optimiser step (first step, or parameters touched since):
+            # K0zz (written next to H) and H inverted in one batched launch
+            self.kernel_matrix(k0, z, z, jitter=self.eps, out=self._KH[:L])
+            inv, logdet = self.chol_inv(self._KH)
+            self._iK.copy_(inv[:L]); self._iHb.copy_(inv[L:]); self._ldK.copy_(logdet[:L]); self._ldH.copy_(logdet[L:])
+        iK, iH, ldK, ldH = self._iK, self._iHb, self._ldK, self._ldH
         self._iH = iH
         mu64 = mu.to(torch.float64)
         iKm = iK @ self.m                                                    # [L,M,1]
@@ -491,13 +500,22 @@ class GPPriorHIP:
                                              _lib.ptr(self._adam_v), self._theta.numel(), _lib.ptr(self._adam_step),
                                              _C.c_double(self.lr), _C.c_double(0.9), _C.c_double(0.999), _C.c_double(1e-8),
                                              self._stream()), "gp_adam")
-        # natural-gradient update of (m, H), training.py:130-137, with the register Gauss-Jordan inverse kernel
+        # natural-gradient update of (m, H), training.py:130-137, with the register Gauss-Jordan inverse kernel; the same
+        # launch inverts K0zz of the hyper-parameters / inducing points Adam has just produced, for the next step
+        L = self.L
         iH = self._iH if self._iH is not None else self.chol_inv(self.H.contiguous())[0]
         self._iH = None
         gH = self._grad_H
-        iH_new = torch.add(iH, gH + gH.transpose(-1, -2), alpha=self.ng_lr)
-        H_new, _ = self.chol_inv(iH_new)
+        torch.add(iH, gH + gH.transpose(-1, -2), alpha=self.ng_lr, out=self._KH2[:L])           # iH_new
+        self._transform()
+        self.kernel_matrix(self.k0, self.zt_list, self.zt_list, jitter=self.eps, out=self._KH2[L:])
+        self.chol_inv(self._KH2, out=(self._inv2, self._ld2))
+        H_new = self._inv2[:L]
         rhs = torch.baddbmm(self._grad_m, gH, self.m, alpha=-2.0)            # grad_m - 2 grad_H m
         # in place: a captured HIP graph keeps reading the same buffers
         self.m.copy_(H_new @ torch.baddbmm(rhs, iH, self.m, beta=-self.ng_lr))
         self.H.copy_(H_new)
+        self._KH[:L].copy_(self._KH2[L:])                                    # K0zz that belongs to the cached inverse
+        self._iHb.copy_(self._KH2[:L]); self._iK.copy_(self._inv2[L:])
+        self._ldK.copy_(self._ld2[L:]); torch.neg(self._ld2[:L], out=self._ldH)    # log det H_new = - log det iH_new
+        self._fact_key = (self._theta._version, self._KH._version)

@@ -721,3 +721,38 @@ def test_wide_categorical_and_ordinal_against_oracle():
             assert rel_err(p.grad, st[k].grad) < 5e-2, k
             n += 1
     assert n >= 8
+
+
+def test_gp_factorisation_carried_across_steps():
+    """GPPriorHIP inverts K0zz of the UPDATED hyper-parameters together with iH_new at the end of a step; the next step must
+    be identical to recomputing both factorizations from scratch."""
+    from hlvae_amd.elbo_functions import GPPriorHIP
+    dev = _dev()
+    torch.manual_seed(0)
+    L, M = 6, 20
+    rows = []
+    for s_ in range(8):
+        for t in range(6):
+            rows.append([float(t), float(t - 2) if s_ % 2 else 0.0, float(s_ + 3), float(s_ % 2), float(s_ % 2), float((s_ // 2) % 2)])
+    x = torch.tensor(rows, dtype=torch.float64, device=dev)
+    mus = [torch.randn(48, L, device=dev) for _ in range(3)]
+    lvs = [0.5 * torch.randn(48, L, device=dev) - 1.0 for _ in range(3)]
+
+    def run(carry):
+        gp = GPPriorHIP(L, x, M, 2, N_total=777, seed=4)
+        out = []
+        for i in range(3):
+            if not carry:
+                gp._fact_key = None
+            g_mu, g_lv = gp.kl_and_grads(mus[i], lvs[i], x, 40, 8)
+            out.append((float(gp.last_kld), g_mu.clone()))
+            gp.optimizer_step()
+        torch.cuda.synchronize()
+        assert int(gp.fail.item()) == 0
+        return out, gp.m.clone(), gp.H.clone(), gp.prm.clone()
+
+    a, b = run(True), run(False)
+    # (the carried iH is iH_old + lr * (...) exactly; the recomputed one is inv(inv(.)) of a matrix with condition ~1e6)
+    for (ka, ga), (kb, gb) in zip(a[0], b[0]):
+        assert abs(ka - kb) <= 1e-7 * abs(kb) and rel_err(ga, gb) < 1e-6
+    assert rel_err(a[1], b[1]) < 1e-6 and rel_err(a[2], b[2]) < 1e-6 and rel_err(a[3], b[3]) < 1e-8
