@@ -20,10 +20,6 @@ struct HeadAcc {
     static constexpr int N = (YD + 1) * (KM - 1) > (YD + KM) ? (YD + 1) * (KM - 1) : (YD + KM);
 };
 
-struct RowIO {
-    const float* Cs;   // set per call
-};
-
 // ---- real / pos:  HL_VAE/loglik.py:27-70 and :73-121 -------------------------------------------
 template <int YD, int BM, int CLD, int NACC>
 __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int rg, int m0, int B, int D, int d,

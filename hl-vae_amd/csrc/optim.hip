@@ -2,12 +2,13 @@
 // refresh of the bf16 shadow copies that the MFMA kernels read.  HBM-bound: per parameter 4 B grad +
 // 3 x (4 B read + 4 B write) state (+ 2-4 B of shadow).
 //
-// Two launches cover the arena:
-//   k_adam_flat   the "small" region [0, atomic_region): head parameters and biases, float4 per lane.
-//                 It also ZEROES the gradients it has consumed: that region is accumulated with atomics by
-//                 the next step, so no separate memset is needed.
-//   k_adam_tiled  the five dense weight matrices in 64 x 64 tiles: the updated tile is staged in LDS and
-//                 written as padded bf16 in both layouts (row-major shadow + transposed shadow).
+// k_adam_tiled covers the arena in one launch:
+//   tiles        the dense weight matrices in 64 x 64 tiles: the updated tile is staged in LDS and written as padded
+//                bf16 in both layouts (row-major shadow + transposed shadow);
+//   flat blocks  the "small" region [0, atomic_region): head parameters, biases, convolution weights, float4 per
+//                lane.  They also ZERO the gradients they have consumed: that region is accumulated with atomics by the
+//                next step, so no separate memset is needed.
+// hlvae_backward_adam launches y_layer's weight on its own, early (update mode 2), under the backward pass.
 #include "common.h"
 
 struct AdamScalars {
@@ -30,30 +31,6 @@ __device__ __forceinline__ float adam_one(float p, float g, float& m, float& v, 
     m = a.b1 * m + (1.f - a.b1) * g;
     v = a.b2 * v + (1.f - a.b2) * g * g;
     return p - a.step_size * m / (sqrtf(v) * a.rs_bc2 + a.eps);
-}
-
-__global__ __launch_bounds__(HL_THREADS) void k_adam_flat(float* __restrict__ P, float* __restrict__ G,
-                                                          float* __restrict__ M1, float* __restrict__ M2, long n4,
-                                                          int64_t* __restrict__ step_count, float lr, float b1,
-                                                          float b2, float eps, float gscale, int zero_grad) {
-    const int64_t done = step_count[0];
-    const AdamScalars a = adam_scalars((float)(done + 1), lr, b1, b2, eps, gscale);
-    if (blockIdx.x == 0 && threadIdx.x == 0) step_count[1] = done + 1;
-    float4* P4 = reinterpret_cast<float4*>(P);
-    float4* G4 = reinterpret_cast<float4*>(G);
-    float4* M14 = reinterpret_cast<float4*>(M1);
-    float4* M24 = reinterpret_cast<float4*>(M2);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        float4 p = P4[i], g = G4[i], m = M14[i], v = M24[i];
-        p.x = adam_one(p.x, g.x, m.x, v.x, a);
-        p.y = adam_one(p.y, g.y, m.y, v.y, a);
-        p.z = adam_one(p.z, g.z, m.z, v.z, a);
-        p.w = adam_one(p.w, g.w, m.w, v.w, a);
-        P4[i] = p;
-        M14[i] = m;
-        M24[i] = v;
-        if (zero_grad) G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
 }
 
 struct ShadowMat {

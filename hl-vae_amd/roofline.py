@@ -65,8 +65,15 @@ def algorithmic_work(model, B):
     w["dWd"] = ((hdp * Bp + Lp * Bp) * 2 + hd * L * 4, 2 * B * hd * L)
     w["dWmu_dWlv"] = ((2 * Lp * Bp + hep * Bp) * 2 + 2 * L * he * 4, 2 * B * 2 * L * he)
     w["dW1"] = ((hep * Bp + Xep * Bp) * 2 + he * Xe * 4, 2 * B * Xe * he)
-    n_w = he * Xe + 2 * L * he + hd * L + NYl * hd
-    shadow_bytes = ((2 if d.conv else 1) * he * Xe + 2 * (2 * L * he + hd * L + NYl * hd)) * 2
+    # optimiser: 28 B per parameter (grad read, master / m / v read + write) plus the bf16 shadows it writes; since
+    # hlvae_backward_adam y_layer's weight has its own early launch, the rest (and the small flat region) the final one
+    n_wy, n_rest = NYl * hd, he * Xe + 2 * L * he + hd * L
+    sh_wy = 2 * n_wy * 2
+    sh_rest = ((2 if d.conv else 1) * he * Xe + 2 * (2 * L * he + hd * L)) * 2
+    w["adam_wy_early"] = (n_wy * 28 + sh_wy, 0)
+    w["adam_weights_shadows"] = (n_rest * 28 + sh_rest + model._atomic_region * 32, 0)
+    w["adam_all_in_one"] = ((n_wy + n_rest) * 28 + sh_wy + sh_rest + model._atomic_region * 32, 0)     # data-parallel path
+    w["shadow_cast"] = ((n_wy + n_rest) * 4 + sh_wy + sh_rest, 0)
     if d.conv:      # csrc/conv.hip, per launch over the whole batch: activations in / out once; MACs x 2
         px = 36 * 36
         w["conv_enc_fwd"] = (B * (X + D) * 8 + B * px * 4 + 2 * B * Xe * 2 + B * D * 5, 2 * B * (px * 16 * 9 + 324 * 32 * 144))
