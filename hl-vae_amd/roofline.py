@@ -86,9 +86,6 @@ def algorithmic_work(model, B):
         w["dfeat"] = ((B * hep + Xe * hep) * 2 + B * Xe * 4, 2 * B * Xe * he)
         w["conv_enc_bwd"] = (B * px * 4 + B * Xe * 4 + B * D * 5, 2 * B * (3 * 324 * 32 * 144 + 2 * px * 16 * 9))
         w["conv_pack_weights"] = (32256 * 2 + 15000 * 4, 0)
-    w["adam_small"] = (model._atomic_region * 32, 0)
-    w["adam_weights_shadows"] = (n_w * 28 + shadow_bytes, 0)
-    w["shadow_cast"] = (n_w * 4 + shadow_bytes, 0)
     return w
 
 
@@ -118,6 +115,8 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None):
     buf = C.create_string_buffer(1 << 16)
     _lib.check(lib.hlvae_prof_report(buf, len(buf)), "hlvae_prof_report")
     work = algorithmic_work(m, B)
+    if getattr(trainer, "dp", None) is not None:        # data parallel: hlvae_adam_step updates all matrices in one launch
+        work["adam_weights_shadows"] = work["adam_all_in_one"]
     if ds is not None:      # compact feed: 5 B per entry in instead of the expanded fp64 matrices
         d_ = m._dims
         work["normalize_pack"] = (B * d_.D * 5 + 2 * B * d_.Xp * 2 + B * d_.D * 5, 0)
