@@ -114,6 +114,8 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HlvaeError(f"{LIB_PATH} not found: build it with `make -C hl-vae_amd/csrc` "
                          "(or __graft_entry__.build()); there is no CPU fallback for the HIP path")
+    import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch ships and initialises (a second
+    #                              copy of libamdhip64 loaded ahead of torch's sees no device)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)

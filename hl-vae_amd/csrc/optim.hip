@@ -100,19 +100,39 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
     float4 p[4], g[4], m[4], v[4];
     long o[4];
     bool in[4];
+    // rows are 16-byte aligned when C % 4 == 0 (block-uniform): one float4 per access; otherwise (an input width such as
+    // 38 expanded columns) element-wise accesses clipped to the row
+    const bool vec = (mt.C & 3) == 0;
+    const int nv = min(4, mt.C - (c0 + c4));
+    auto ld4 = [&](const float* b, long off) -> float4 {
+        if (vec) return *reinterpret_cast<const float4*>(b + off);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nv > 0) r.x = b[off];
+        if (nv > 1) r.y = b[off + 1];
+        if (nv > 2) r.z = b[off + 2];
+        if (nv > 3) r.w = b[off + 3];
+        return r;
+    };
+    auto st4 = [&](float* b, long off, const float4& x) {
+        if (vec) { *reinterpret_cast<float4*>(b + off) = x; return; }
+        if (nv > 0) b[off] = x.x;
+        if (nv > 1) b[off + 1] = x.y;
+        if (nv > 2) b[off + 2] = x.z;
+        if (nv > 3) b[off + 3] = x.w;
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = rq + 16 * i;
-        in[i] = r0 + r < mt.R && c0 + c4 < mt.C;              // C % 4 == 0: the float4 is entirely inside the row
+        in[i] = r0 + r < mt.R && c0 + c4 < mt.C;
         o[i] = in[i] ? mt.off + (long)(r0 + r) * mt.C + c0 + c4 : mt.off;
-        p[i] = *reinterpret_cast<const float4*>(P + o[i]);
+        p[i] = ld4(P, o[i]);
     }
     if (update) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            g[i] = *reinterpret_cast<const float4*>(G + o[i]);       // (non-temporal hints measured slower: 41 vs 38 us)
-            m[i] = *reinterpret_cast<const float4*>(M1 + o[i]);
-            v[i] = *reinterpret_cast<const float4*>(M2 + o[i]);
+            g[i] = ld4(G, o[i]);       // (non-temporal hints measured slower: 41 vs 38 us)
+            m[i] = ld4(M1, o[i]);
+            v[i] = ld4(M2, o[i]);
         }
     }
 #pragma unroll
@@ -124,9 +144,9 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
             p[i].y = adam_one(p[i].y, g[i].y, m[i].y, v[i].y, a);
             p[i].z = adam_one(p[i].z, g[i].z, m[i].z, v[i].z, a);
             p[i].w = adam_one(p[i].w, g[i].w, m[i].w, v[i].w, a);
-            *reinterpret_cast<float4*>(P + o[i]) = p[i];
-            *reinterpret_cast<float4*>(M1 + o[i]) = m[i];
-            *reinterpret_cast<float4*>(M2 + o[i]) = v[i];
+            st4(P, o[i], p[i]);
+            st4(M1, o[i], m[i]);
+            st4(M2, o[i], v[i]);
         }
         if (r0 + r < mt.Rcover && c0 + c4 < mt.Ccover) {        // row-major shadow: 4 bf16 = one 8-byte store
             uint2 pk;
@@ -197,7 +217,7 @@ static int check_set(const ShadowSet& s) {
     for (int i = 0; i < s.n; ++i) {
         const ShadowMat& m = s.m[i];
         // (a 4-row group of the transposed shadow may run past Rcover: it lands in the zero padding, ldT >= ru(Rcover, 4))
-        HL_REQUIRE(m.C % 4 == 0 && m.off % 4 == 0 && m.ldd % 4 == 0 && m.Ccover % 4 == 0 &&
+        HL_REQUIRE(m.off % 4 == 0 && m.ldd % 4 == 0 && m.Ccover % 4 == 0 &&
                        (m.dstT == nullptr || (m.ldT % 4 == 0 && m.row_off % 4 == 0 && m.ldT >= m.row_off + ru(m.Rcover, 4))),
                    HLVAE_ESHAPE, "weight matrix %d: hidden / latent / input widths must be multiples of 4 (C=%d off=%ld)", i,
                    m.C, m.off);

@@ -697,8 +697,8 @@ def test_wide_categorical_and_ordinal_against_oracle():
     usual mix, forward + backward against the oracle."""
     import hlvae_oracle as orc
     dev = _dev()
-    spec = [("real", 1), ("cat", 12), ("pos", 1), ("ordinal", 10), ("count", 1), ("cat", 5), ("ordinal", 4), ("cat", 16),
-            ("real", 1), ("pos", 1)]          # X = 52 (the first Linear wants a multiple of 4)
+    spec = [("real", 1), ("cat", 12), ("pos", 1), ("ordinal", 10), ("count", 1), ("cat", 5), ("ordinal", 4), ("cat", 16)]
+    # X = 50: not a multiple of 4 -> the optimiser's element-wise path for the first Linear's rows
     src = synthetic.make_tabular(n_rows=60, T=6, seed=17, spec=spec)
     dims = [src.cov_dim_ext, [16], 4, [16], 5]
     state = orc.init_state(dims, src.types_info, src.n_variables, seed=31, std=0.2)
@@ -721,6 +721,17 @@ def test_wide_categorical_and_ordinal_against_oracle():
             assert rel_err(p.grad, st[k].grad) < 5e-2, k
             n += 1
     assert n >= 8
+    assert rel_err(sd["VAE_encoder_common_layers.0.weight"].grad, st["VAE_encoder_common_layers.0.weight"].grad) < 5e-2
+    # two fused optimiser steps on the odd-width model against torch.optim.Adam on the same gradients
+    from hlvae_amd.training import ELBOTrainer
+    m2 = _model_from_state(src, dims, state)
+    tr = ELBOTrainer(m2, P_total=10, kl="normal", max_batch=128)
+    w0 = m2.VAE_encoder_common_layers[0].weight.detach().clone()
+    tr.step(data, mask, 10, eps=eps.to(dev))
+    torch.cuda.synchronize()
+    dw = (m2.VAE_encoder_common_layers[0].weight.detach() - w0).abs()
+    assert float(dw.max()) <= 1.001e-3 and float(dw.mean()) > 5e-4          # first Adam step: |delta| = lr wherever g != 0
+    assert bool(torch.isfinite(m2._arena).all())
 
 
 def test_gp_factorisation_carried_across_steps():
