@@ -767,3 +767,32 @@ def test_gp_factorisation_carried_across_steps():
     for (ka, ga), (kb, gb) in zip(a[0], b[0]):
         assert abs(ka - kb) <= 1e-7 * abs(kb) and rel_err(ga, gb) < 1e-6
     assert rel_err(a[1], b[1]) < 1e-6 and rel_err(a[2], b[2]) < 1e-6 and rel_err(a[3], b[3]) < 1e-8
+
+
+def test_odd_layer_widths_against_oracle():
+    """hidden 30 / 26, latent 6, X = 38: nothing in the path needs widths that are multiples of 4 or of a tile."""
+    import hlvae_oracle as orc
+    from hlvae_amd.training import ELBOTrainer
+    dev = _dev()
+    spec = synthetic.tabular_type_spec(n_real=3, n_pos=3, n_count=2, n_cat=4, n_ord=2, K=5)
+    src = synthetic.make_tabular(n_rows=80, T=8, seed=12, spec=spec)
+    dims = [src.cov_dim_ext, [30], 6, [26], 5]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=4, std=0.2)
+    model = _model_from_state(src, dims, state)
+    rows = np.arange(80)
+    eps = torch.randn(80, 6, generator=torch.Generator().manual_seed(2))
+    data, mask = torch.tensor(src.data[rows], device=dev), torch.tensor(src.mask[rows], device=dev)
+    out = model(data, mask, None, src.types_info, eps=eps.to(dev))
+    loss = 1.1 * model.loss_function(out[3]).sum() - 0.5 * torch.sum(1.0 + out[2] - out[1] ** 2 - torch.exp(out[2]))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref, ref_loss, st = _oracle_step(src, rows, dims, state, eps, 1.1)
+    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    sd = dict(model.named_parameters())
+    for k in ("y_layer.0.weight", "VAE_encoder_common_layers.0.weight", "d_layers.0.weight", "mean_layer.0.weight",
+              "log_var_layer.0.weight", "d_layers.0.bias", "mean_layer.0.bias"):
+        assert rel_err(sd[k].grad, st[k].grad) < 5e-2, k
+    tr = ELBOTrainer(_model_from_state(src, dims, state), P_total=10, kl="normal", max_batch=128)
+    for _ in range(3):
+        tr.step(data, mask, 10, eps=eps.to(dev))
+    assert np.isfinite(float(tr.scalars()["nll_sum"])) and bool(torch.isfinite(tr.model._arena).all())
