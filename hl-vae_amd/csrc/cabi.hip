@@ -21,7 +21,6 @@ int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
 int hl_launch_mid_fwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, int, uint64_t, int, int, hipStream_t);
 int hl_launch_mid_bwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, const float*, float, int, int, hipStream_t);
 int hl_adam(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t, int);
-int hl_adam_early_wy(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t);
 int hl_launch_conv_enc_fwd(const hlvae_plan*, const hlvae_ws*, const double*, const double*, const float*, const uint8_t*,
                            const int32_t*, int, int, hipStream_t);
 int hl_launch_stats_compact(const hlvae_plan*, const hlvae_ws*, const float*, const uint8_t*, const int32_t*, int, hipStream_t);
@@ -29,6 +28,10 @@ int hl_launch_pack_compact(const hlvae_plan*, const hlvae_ws*, const float*, con
 int hl_launch_conv_dec_fwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
 int hl_launch_conv_dec_bwd(const hlvae_plan*, const hlvae_ws*, int, int, hipStream_t);
 int hl_launch_conv_enc_bwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
+int hl_launch_gemm_f32_group(GemmGroup, const char*, hipStream_t);
+int hl_adam_grid(const hlvae_plan*, const hlvae_ws*, unsigned, int);
+int hl_adam_part(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, unsigned, int,
+                 unsigned, const char*, hipStream_t);
 
 static thread_local char g_err[512] = "";
 void hl_set_error(const char* fmt, ...) {
@@ -166,7 +169,7 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     p->d = d;
     p->vars_dev = nullptr; p->col2var_dev = nullptr; p->stat_var_dev = nullptr;
     p->kmax = 2;
-    p->metrics_pending = 0;
+    p->pend_flags = 0;
     for (int i = 0; i < d.D; ++i)
         if ((vars[i].kind == HLVAE_CAT || vars[i].kind == HLVAE_ORDINAL) && vars[i].ncls > p->kmax) p->kmax = vars[i].ncls;
     for (auto& st : p->side) st = nullptr;
@@ -295,10 +298,17 @@ int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_lo
                                      d.NYlp, nullptr, 0, B, nullptr, "y_layer_conv", st))) return rc;
         if ((rc = hl_launch_conv_dec_fwd(p, ws, B, st))) return rc;
     }
-    if ((rc = hl_launch_y_heads(p, ws, g_logpx, g_scale, want_grad, want_params, B, Bp, st))) return rc;
-    // (moving this one-workgroup kernel to the side stream was measured: the extra fork/join in the HIP graph costs more
-    // than the 8 us it takes off the critical path -- 0.229 vs 0.205 ms/step)
-    return hl_launch_elbo_finalize(p, ws, B, Bp, st);
+    if ((rc = hl_launch_y_heads(p, ws, g_logpx, g_scale, want_grad != 0, want_params, B, Bp, st))) return rc;
+    if (want_grad != 2) return hl_launch_elbo_finalize(p, ws, B, Bp, st);
+    // training step: nothing on the critical path reads the scalar reductions.  Only the dependency is recorded; the
+    // one-workgroup kernel is queued on a side stream by the next hlvae_backward* / hlvae_join, which forks ONCE for all
+    // its side work (a fork of its own here costs more in a HIP graph than the 7 us it saves: 0.229 vs 0.205 ms/step)
+    if ((rc = hlvae_join(p, s))) return rc;       // earlier deferred work of this plan
+    HL_CHECK(hipEventRecord(p->ev[5], st));
+    p->pend_fin_ws = *ws;
+    p->pend_fin_B = B;
+    p->pend_flags |= HL_PEND_FINALIZE;
+    return 0;
 }
 
 int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, int B, hlvae_stream s) {
@@ -307,24 +317,46 @@ int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx
     return hl_launch_scale_dy(p, ws, g_logpx, B, Bp, st);
 }
 
+static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered);
+
 int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* err, hlvae_stream s) {
     CHECK_B();
+    HL_REQUIRE(err, HLVAE_EINVAL, "step_metrics: null output");
     // metrics only READ what the decoder left behind: they run on a side stream beside whatever the caller queues next
-    // (normally the backward pass); the caller's stream re-joins in hlvae_backward or hlvae_join
+    // (normally the backward pass).  Only the dependency is recorded here; the launches themselves are queued by the next
+    // hlvae_backward* (after its critical path, see there) or hlvae_join, which also re-joins the caller's stream.
+    if (p->pend_flags & (HL_PEND_METRICS | HL_PEND_RUNNING))       // an earlier, un-joined call
+        if (int rc = hlvae_join(p, s)) return rc;
     HL_CHECK(hipEventRecord(p->ev[5], st));
-    HL_CHECK(hipStreamWaitEvent(p->side[0], p->ev[5], 0));
-    int rc = hl_launch_step_metrics(p, ws, B, err, p->side[0]);
-    if (rc) return rc;
-    HL_CHECK(hipEventRecord(p->ev[5], p->side[0]));
-    p->metrics_pending = 1;          // joined by the next hlvae_backward / hlvae_join on this plan
+    p->pend_ws = *ws;
+    p->pend_B = B;
+    p->pend_err = err;
+    p->pend_flags |= HL_PEND_METRICS;
+    return 0;
+}
+
+// queues the deferred launches on `side`.  side_is_ordered: the caller has just made `side` wait for a LATER point of
+// its stream than ev[5] (one fork point for all the side work of the backward pass)
+static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered) {
+    if (!(p->pend_flags & (HL_PEND_METRICS | HL_PEND_FINALIZE))) return 0;
+    if (!side_is_ordered) HL_CHECK(hipStreamWaitEvent(side, p->ev[5], 0));
+    if (p->pend_flags & HL_PEND_FINALIZE) {
+        const int B = p->pend_fin_B;
+        if (int rc = hl_launch_elbo_finalize(p, &p->pend_fin_ws, B, (B + 127) / 128 * 128, side)) return rc;
+    }
+    if (p->pend_flags & HL_PEND_METRICS)
+        if (int rc = hl_launch_step_metrics(p, &p->pend_ws, p->pend_B, p->pend_err, side)) return rc;
+    HL_CHECK(hipEventRecord(p->ev[5], side));
+    p->pend_flags = HL_PEND_RUNNING;
     return 0;
 }
 
 int hlvae_join(const hlvae_plan* p, hlvae_stream s) {
     HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
-    if (p->metrics_pending) {
+    if (int rc = hl_flush_deferred(p, p->side[1], false)) return rc;
+    if (p->pend_flags & HL_PEND_RUNNING) {
         HL_CHECK(hipStreamWaitEvent((hipStream_t)s, p->ev[5], 0));
-        p->metrics_pending = 0;
+        p->pend_flags = 0;
     }
     return 0;
 }
@@ -351,52 +383,70 @@ struct HlAdamArgs {
 };
 
 static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
-                            int skip_wy, int B, hlvae_stream s, const HlAdamArgs* early) {
+                            int skip_wy, int B, hlvae_stream s, const HlAdamArgs* opt) {
     CHECK_B();
     int rc;
     HL_REQUIRE(ws->splitk_dec >= 1, HLVAE_EINVAL, "splitk_dec");
-    // The weight-gradient GEMMs are leaves of the dependency graph: they run on two side streams (fork/join with
-    // events, so the structure is preserved under hipGraph capture) beside the critical path
-    //   dY -> dU -> d(mu, lv) -> dT -> dW1.
-    hipStream_t s0 = p->side[0], s1 = p->side[1];       // (everything on one stream was measured: 0.225 vs 0.207 ms/step)
+    // Critical path, all on the caller's stream:
+    //     dY -> dU -> d(mu, lv), dT -> {dW1, dWd, d[Wmu; Wlv]} (one grouped launch) -> [join] -> Adam of everything but Wy.
+    // Leaves of the dependency graph run on two side streams:
+    //     side 0:  d Wy = dY^T U (forks before dU_splitk), then -- behind dU_splitk, the last reader of its shadows --
+    //              y_layer's Adam update + shadow refresh: the largest slice of the HBM-bound optimiser runs under the
+    //              latency-bound middle of the backward pass instead of after it;
+    //     side 1:  whatever hlvae_decoder_fwd(want_grad = 2) / hlvae_step_metrics deferred (ELBO scalars, row-M metrics),
+    //              forked behind dU_splitk.
+    // Why this shape (rocprofv3 kernel traces of the replayed HIP graph on MI355X, tools/timeline.py):
+    //   * a node's FIRST-created child stays on its parent's hardware queue; every other child starts 6-20 us late
+    //     (cross-queue signal) -> the whole critical path is queued first, the side work afterwards, behind events
+    //     recorded along the way;
+    //   * two HBM-bound kernels running concurrently take far longer than back to back (the two Adam launches: 71 us
+    //     each together, 28 + 22 us apart) -> the second Adam launch waits for the join;
+    //   * three small GEMMs as one grouped launch instead of a third queue.
+    // Measured (ms/step, D4, batch 512): one stream 0.225; forks queued side-first 0.196; this order 0.170; also tried:
+    // Adam split three ways and fully concurrent 0.234, dWy forked behind dU 0.192, deferred kernels behind y_layer's
+    // Adam on side 0 0.186, deferred kernels forked before dU 0.183.
+    hipStream_t s0 = p->side[0], s1 = p->side[1];
     if (d.conv)     // d y_grouped -> d a2 -> d (y_layer output), weight gradients of the transposed convolutions
         if ((rc = hl_launch_conv_dec_bwd(p, ws, B, Bp, st))) return rc;
     const bf16_t* dyl = d.conv ? ws->dyc : ws->dy;          // gradient of y_layer's output, both layouts
     const bf16_t* dylT = d.conv ? ws->dycT : ws->dyT;
-    HL_CHECK(hipEventRecord(p->ev[0], st));
-    HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
-    // d Wy = dY^T U                                  [NYl][h_d]
-    if (!skip_wy)
-        if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
+    HL_CHECK(hipEventRecord(p->ev[0], st));        // dY is final
     // d U slabs = dY Wy (split-K), then the fused middle: dU -> dz -> d(mu, lv) -> dT, bias gradients
     if ((rc = hl_launch_gemm_splitk(dyl, d.NYlp, ws->wyTs, d.NYlp, ws->slab, d.hdp, Bp, d.hdp, d.NYlp, ws->splitk_dec, "dU_splitk", st))) return rc;
-    if (early != nullptr && !skip_wy) {
-        // y_layer's weight has its gradient (side stream) and its last reader of this step (dU_splitk, just queued) behind
-        // it: its Adam update + shadow refresh -- the largest slice of the HBM-bound optimiser -- runs on the side stream
-        // UNDER the latency-bound rest of the backward pass instead of after it
-        HL_CHECK(hipEventRecord(p->ev[2], st));
-        HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
-        if ((rc = hl_adam_early_wy(p, ws, early->m1, early->m2, early->step_count, early->lr, early->b1, early->b2, early->eps,
-                                   early->gscale, s0))) return rc;
-    }
+    HL_CHECK(hipEventRecord(p->ev[2], st));        // the last reader of y_layer's weight shadows is done
     if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st))) return rc;
-    HL_CHECK(hipEventRecord(p->ev[1], st));
-    HL_CHECK(hipStreamWaitEvent(s1, p->ev[1], 0));
-    // d Wd = dU^T z  [h_d][L];   d [Wmu; Wlv] = dml^T T  2 x [L][h_e]     (side stream)
-    if ((rc = hl_launch_gemm_f32(ws->duT, Bp, ws->zbT, Bp, ws->G + d.o_wd, d.L, d.h_d, d.L, Bp, 0, 0, nullptr, "dWd", s1))) return rc;
-    if ((rc = hl_launch_gemm_f32(ws->dmlT, Bp, ws->tT, Bp, ws->G + d.o_wmu, d.h_e, 2 * d.Lp, d.h_e, Bp, d.Lp, d.L,
-                                 ws->G + d.o_wlv, "dWmu_dWlv", s1))) return rc;
-    // d W1 = dT^T Xn                                 [h_e][X]   (no input gradient for layer 1)
-    if ((rc = hl_launch_gemm_f32(ws->dtT, Bp, ws->xnT, Bp, ws->G + d.o_w1, d.Xe, d.h_e, d.Xe, Bp, 0, 0, nullptr, "dW1", st))) return rc;
+    {   // d W1 = dT^T Xn [h_e][X] (no input gradient for layer 1);  d Wd = dU^T z [h_d][L];  d [Wmu; Wlv] = dml^T T 2 x [L][h_e]
+        GemmGroup g{};
+        g.n = 3;
+        g.K = Bp;
+        g.p[0] = GemmProb{ws->dtT, ws->xnT, ws->G + d.o_w1, nullptr, Bp, Bp, d.Xe, d.h_e, d.Xe, 0, 0};
+        g.p[1] = GemmProb{ws->duT, ws->zbT, ws->G + d.o_wd, nullptr, Bp, Bp, d.L, d.h_d, d.L, 0, 0};
+        g.p[2] = GemmProb{ws->dmlT, ws->tT, ws->G + d.o_wmu, ws->G + d.o_wlv, Bp, Bp, d.h_e, 2 * d.Lp, d.h_e, d.Lp, d.L};
+        if ((rc = hl_launch_gemm_f32_group(g, "dW1_dWd_dWmu", st))) return rc;
+    }
     if (d.conv) {   // the convolutional features receive a gradient: d feat = dT W1, then conv2 / conv1 / representation layer
         if ((rc = hl_launch_gemm_f32(ws->dt, d.hep, ws->w1Ts, d.hep, ws->dfeat, d.Xep, Bp, d.Xe, d.hep, 0, 0, nullptr, "dfeat", st))) return rc;
         if ((rc = hl_launch_conv_enc_bwd(p, ws, B, st))) return rc;
     }
-    HL_CHECK(hipEventRecord(p->ev[3], s0));
-    HL_CHECK(hipEventRecord(p->ev[4], s1));
-    HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
-    HL_CHECK(hipStreamWaitEvent(st, p->ev[4], 0));
-    return hlvae_join(p, s);
+    if (!skip_wy) {
+        HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
+        if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
+        if (opt != nullptr) {       // takes no completion ticket: the final launch below is ordered behind it by the join
+            HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
+            if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0x01, 0,
+                                   0u, "adam_wy_early", s0))) return rc;
+        }
+        HL_CHECK(hipEventRecord(p->ev[3], s0));
+    }
+    if (p->pend_flags & (HL_PEND_METRICS | HL_PEND_FINALIZE)) {
+        HL_CHECK(hipStreamWaitEvent(s1, p->ev[2], 0));
+        if ((rc = hl_flush_deferred(p, s1, true))) return rc;
+    }
+    if (!skip_wy) HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
+    if ((rc = hlvae_join(p, s))) return rc;
+    if (opt != nullptr)     // Adam of the other matrices + the small flat region; commits the step number
+        return hl_adam(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, st, skip_wy ? 0 : 1);
+    return 0;
 }
 
 int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
@@ -407,10 +457,9 @@ int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, c
 int hlvae_backward_adam(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
                         int B, float* m1, float* m2, int64_t* step_count, float lr, float beta1, float beta2, float eps,
                         float grad_scale, hlvae_stream s) {
-    HL_REQUIRE(m1 && m2 && step_count, HLVAE_EINVAL, "backward_adam: null optimiser state");
+    HL_REQUIRE(p && ws && m1 && m2 && step_count, HLVAE_EINVAL, "backward_adam: null argument");
     const HlAdamArgs a{m1, m2, step_count, lr, beta1, beta2, eps, grad_scale};
-    if (int rc = hl_backward_impl(p, ws, g_mu, g_lv, kl_std_weight, 0, B, s, &a)) return rc;
-    return hl_adam(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, (hipStream_t)s, 1);
+    return hl_backward_impl(p, ws, g_mu, g_lv, kl_std_weight, 0, B, s, &a);     // both optimiser launches are queued inside
 }
 
 int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr,

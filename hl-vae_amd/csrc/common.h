@@ -44,6 +44,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+// one product C[M][N] (fp32, row stride ldc) = A[M][K] B[N][K]^T of a grouped launch (dense.hip: k_gemm_f32_group).
+// band > 0: rows [0, band_rows) -> C, rows [band, band + band_rows) -> C2 (stacked [mu; log_var] operand).
+// tiles_* / n_fast / tile0 are filled by the launcher.
+struct GemmProb {
+    const bf16_t* A;
+    const bf16_t* B;
+    float* C;
+    float* C2;
+    int lda, ldb, ldc, M, N, band, band_rows, tiles_m, tiles_n, n_fast, tile0;
+};
+struct GemmGroup {
+    GemmProb p[3];
+    int n, K;
+};
+
+enum { HL_PEND_METRICS = 1, HL_PEND_FINALIZE = 2, HL_PEND_RUNNING = 4 };
+
 struct hlvae_plan {
     hlvae_dims d;
     hlvae_var* vars_dev;      // [D]
@@ -53,7 +70,12 @@ struct hlvae_plan {
     // fork/join side streams: independent weight-gradient GEMMs run beside the critical path of the backward
     hipStream_t side[2];
     hipEvent_t ev[6];
-    mutable int metrics_pending;   // hlvae_step_metrics forked onto side[0] and has not been joined yet
+    // deferred side work: hlvae_step_metrics and hlvae_decoder_fwd(want_grad = 2) only record their dependency (ev[5]); the
+    // launches are queued on a side stream by the next hlvae_backward* / hlvae_join (cabi.hip: hl_flush_deferred)
+    mutable int pend_flags;        // HL_PEND_*
+    mutable hlvae_ws pend_ws, pend_fin_ws;
+    mutable int pend_B, pend_fin_B;
+    mutable float* pend_err;
 };
 
 void hl_set_error(const char* fmt, ...);

@@ -64,6 +64,45 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32(const bf16_t* __restric
     }
 }
 
+// up to three independent products of the same depth K in ONE launch (the weight gradients that become computable at
+// the same moment of the backward pass: dW1, dWd, d[Wmu; Wlv]).  The two small ones are 8 workgroups each: as launches
+// of their own they cost a dependent ~10 us kernel (or a cross-queue graph edge) apiece, here they ride along.
+// (GemmProb / GemmGroup: common.h)
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(HL_THREADS) void k_gemm_f32_group(GemmGroup g) {
+    using G = GemmNT<BM, BN, BK, WM, WN>;
+    __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k)
+        if (k < g.n && (int)blockIdx.x >= g.p[k].tile0) pi = k;
+    const GemmProb& q = g.p[pi];
+    // problem 0 starts at workgroup 0, so its XCD-contiguous remap is exact; the small problems do not care
+    const int lid = pi == 0 ? xcd_remap(blockIdx.x, q.tiles_m * q.tiles_n) : (int)blockIdx.x - q.tile0;
+    const int tm = q.n_fast ? lid / q.tiles_n : lid % q.tiles_m, tn = q.n_fast ? lid % q.tiles_n : lid / q.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = q.M, N = q.N, ldc = q.ldc, band = q.band, band_rows = q.band_rows;
+    float* __restrict__ C = q.C;
+    float* __restrict__ C2 = q.C2;
+    typename G::Acc acc;
+    G::zero(acc);
+    G::run(q.A, q.lda, q.B, q.ldb, m0, n0, M, N, 0, g.K, smem, acc);
+    G::to_lds(acc, smem);
+    const float* Cs = reinterpret_cast<const float*>(smem);
+    for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
+        const int r = idx / BN, c = idx % BN;
+        const int gr = m0 + r, gc = n0 + c;
+        if (gr >= M || gc >= N) continue;
+        if (band <= 0) {
+            C[(size_t)gr * ldc + gc] = Cs[r * G::CLD + c];
+        } else {
+            if (gr < band_rows) C[(size_t)gr * ldc + gc] = Cs[r * G::CLD + c];
+            else if (gr >= band && gr < band + band_rows) C2[(size_t)(gr - band) * ldc + gc] = Cs[r * G::CLD + c];
+        }
+    }
+}
+
 // split-K partial products into fp32 slabs  slab[s][M][ldn]
 template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __restrict__ A, int lda,
@@ -157,6 +196,33 @@ int hl_launch_gemm_f32(const bf16_t* A, int lda, const bf16_t* B, int ldb, float
         if (K % 64 == 0) HL_GO(128, 64, 64, 2, 2) else HL_GO(128, 64, 32, 2, 2)
     }
 #undef HL_GO
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+// grouped launch: every problem uses the tile shape chosen for problem 0 (the large one)
+int hl_launch_gemm_f32_group(GemmGroup g, const char* label, hipStream_t s) {
+    HL_REQUIRE(g.n >= 1 && g.n <= 3 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm group: n=%d K=%d", g.n, g.K);
+    const bool big = !(g.p[0].M <= 64 || (long)((g.p[0].M + 127) / 128) * ((g.p[0].N + 63) / 64) < 192);
+    const int BMv = big ? 128 : 64;
+    int t = 0;
+    for (int i = 0; i < g.n; ++i) {
+        GemmProb& q = g.p[i];
+        HL_REQUIRE(q.lda % 8 == 0 && q.ldb % 8 == 0, HLVAE_ESHAPE, "gemm group: lda=%d ldb=%d", q.lda, q.ldb);
+        q.tiles_m = (q.M + BMv - 1) / BMv;
+        q.tiles_n = (q.N + 63) / 64;
+        q.n_fast = q.M >= q.N;
+        q.tile0 = t;
+        t += q.tiles_m * q.tiles_n;
+    }
+    HL_PROF(label, s);
+    if (big) {
+        if (g.K % 64 == 0) k_gemm_f32_group<128, 64, 64, 2, 2><<<t, HL_THREADS, 0, s>>>(g);
+        else k_gemm_f32_group<128, 64, 32, 2, 2><<<t, HL_THREADS, 0, s>>>(g);
+    } else {
+        if (g.K % 64 == 0) k_gemm_f32_group<64, 64, 64, 2, 2><<<t, HL_THREADS, 0, s>>>(g);
+        else k_gemm_f32_group<64, 64, 32, 2, 2><<<t, HL_THREADS, 0, s>>>(g);
+    }
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -8,16 +8,18 @@
 //   flat blocks  the "small" region [0, atomic_region): head parameters, biases, convolution weights, float4 per
 //                lane.  They also ZERO the gradients they have consumed: that region is accumulated with atomics by the
 //                next step, so no separate memset is needed.
-// hlvae_backward_adam launches y_layer's weight on its own, early (update mode 2), under the backward pass.
+// hlvae_backward_adam splits the step into launches that each start as soon as their gradients are final (y_layer's
+// weight on a side stream under the backward pass, ...); the launches share one completion ticket.
 #include "common.h"
 
 struct AdamScalars {
     float step_size, rs_bc2, b1, b2, eps, gscale;
 };
 
-// step_count[0] = completed steps; every Adam kernel of a step uses step_count[0] + 1; the launch that finishes the step
-// commits it through a ticket in step_count[1] (last workgroup to finish).  One writer,
-// ordered by the stream, so no separate "increment" launch is needed.
+// step_count[0] = completed steps; every Adam kernel of a step uses step_count[0] + 1.  The step number is committed
+// through a ticket in step_count[1]: every workgroup of every launch that belongs to the step takes one when it is done,
+// and the one that takes the last of `ticket_total` commits.  The launches of a step may therefore run concurrently on
+// different streams; no separate "increment" launch is needed.
 __device__ __forceinline__ AdamScalars adam_scalars(float t, float lr, float b1, float b2, float eps, float gscale) {
     AdamScalars a;
     a.step_size = lr / (1.f - powf(b1, t));
@@ -53,11 +55,11 @@ struct ShadowSet {
 __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float* __restrict__ P, const float* __restrict__ G,
                                                            float* __restrict__ M1, float* __restrict__ M2,
                                                            int64_t* __restrict__ step_count, float lr, float b1,
-                                                           float b2, float eps, float gscale, int update, long n4_flat) {
-    // update: 0 = shadows only; 1 or 2 = Adam with step number step_count[0] + 1.  1: this is the launch that finishes the
-    // optimiser step: workgroups past the tiles update the small flat region [0, 4 n4_flat) and zero its gradients, and
-    // the LAST workgroup to finish (ticket in step_count[1]) commits the step number.  2: nothing committed (a matrix
-    // updated EARLY, while the rest of the backward pass is still running: hlvae_backward_adam).
+                                                           float b2, float eps, float gscale, int update, long n4_flat,
+                                                           unsigned ticket_total) {
+    // update: 0 = shadows only; 1 = Adam with step number step_count[0] + 1.  Workgroups past the tiles (if the launch
+    // has any) update the small flat region [0, 4 n4_flat) and zero its gradients.  ticket_total = workgroups of ALL the
+    // launches of this optimiser step (0: this launch takes no tickets).
     constexpr int T = 64, CLD = T + 1;
     __shared__ float tile[T * CLD];
     if ((int)blockIdx.x >= set.total_tiles) {                       // flat region (update == 1 only)
@@ -79,9 +81,9 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
             G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);           // the atomically accumulated gradients start the next step at 0
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && ticket_total != 0) {
             const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
-            if (done == gridDim.x - 1) { step_count[1] = 0; step_count[0] += 1; }
+            if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
         }
         return;
     }
@@ -173,11 +175,11 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
             }
         }
     }
-    if (update == 1) {
+    if (update && ticket_total != 0) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
-            if (done == gridDim.x - 1) { step_count[1] = 0; step_count[0] += 1; }
+            if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
         }
     }
 }
@@ -232,42 +234,49 @@ int hl_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s) {
     if (int rc = check_set(set)) return rc;
     {
         HL_PROF("shadow_cast", s);
-        k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0);
+        k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 0u);
         HL_LAUNCH_CHECK();
     }
     if (p->d.conv) return hl_conv_pack_weights(p, ws, s);
     return 0;
 }
 
-// Adam + shadows of y_layer's weight alone (55 % of the MLP arena), with the step number taken as step_count[0] + 1
-int hl_adam_early_wy(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
-                     float b2, float eps, float gscale, hipStream_t s) {
-    const ShadowSet set = make_set(p, ws, 0x01);
+static int flat_blocks(const hlvae_dims& d) {
+    const long n4 = d.atomic_region / 4;
+    int blocks = (int)((n4 + HL_THREADS - 1) / HL_THREADS);
+    return blocks > 64 ? 64 : (blocks < 1 ? 1 : blocks);
+}
+
+// workgroups of the launch that covers the matrices `which` (bit i = matrix i of make_set) (+ the flat region)
+int hl_adam_grid(const hlvae_plan* p, const hlvae_ws* ws, unsigned which, int with_flat) {
+    return make_set(p, ws, which).total_tiles + (with_flat ? flat_blocks(p->d) : 0);
+}
+
+// One launch of the optimiser step: Adam + shadows of the matrices `which` (+ the small flat region).  `ticket_total` =
+// workgroups of all the launches that make up this step (hl_adam_grid), 0 = takes no ticket (the caller orders a later
+// launch of the same step behind this one).
+int hl_adam_part(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
+                 float b2, float eps, float gscale, unsigned which, int with_flat, unsigned ticket_total, const char* label,
+                 hipStream_t s) {
+    const hlvae_dims& d = p->d;
+    HL_REQUIRE(d.atomic_region % 4 == 0, HLVAE_ESHAPE, "atomic region %ld not a multiple of 4", (long)d.atomic_region);
+    const ShadowSet set = make_set(p, ws, which);
     if (int rc = check_set(set)) return rc;
-    HL_PROF("adam_wy_early", s);
-    k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 2, 0);
-    HL_LAUNCH_CHECK();
+    const int grid = set.total_tiles + (with_flat ? flat_blocks(d) : 0);
+    {
+        HL_PROF(label, s);
+        k_adam_tiled<<<grid, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 1,
+                                                 with_flat ? d.atomic_region / 4 : 0, ticket_total);
+        HL_LAUNCH_CHECK();
+    }
+    if (with_flat && d.conv) return hl_conv_pack_weights(p, ws, s);   // the convolution weights live in the flat region
     return 0;
 }
 
+// the whole step in ONE launch: weight tiles plus the workgroups of the small flat region (disjoint parts of the arena)
 int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
             float b2, float eps, float gscale, hipStream_t s, int skip_wy) {
-    const hlvae_dims& d = p->d;
-    HL_REQUIRE(d.atomic_region % 4 == 0, HLVAE_ESHAPE, "atomic region %ld not a multiple of 4", (long)d.atomic_region);
-    const long n4 = d.atomic_region / 4;
-    int blocks = (int)((n4 + HL_THREADS - 1) / HL_THREADS);
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    // ONE launch: the weight tiles plus `blocks` workgroups for the small flat region (disjoint parts of the arena)
-    if (blocks > 64) blocks = 64;
-    const ShadowSet set = make_set(p, ws, skip_wy ? 0x1e : 0x1f);
-    if (int rc = check_set(set)) return rc;
-    {
-        HL_PROF("adam_weights_shadows", s);
-        k_adam_tiled<<<set.total_tiles + blocks, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale,
-                                                                    1, n4);
-    }
-    HL_LAUNCH_CHECK();
-    if (d.conv) return hl_conv_pack_weights(p, ws, s);       // the convolution weights live in the small (atomic) region
-    return 0;
+    const unsigned which = skip_wy ? 0x1e : 0x1f;
+    return hl_adam_part(p, ws, m1, m2, step_count, lr, b1, b2, eps, gscale, which, 1, (unsigned)hl_adam_grid(p, ws, which, 1),
+                        skip_wy ? "adam_weights_shadows" : "adam_all_in_one", s);
 }

@@ -65,6 +65,7 @@ def algorithmic_work(model, B):
     w["dWd"] = ((hdp * Bp + Lp * Bp) * 2 + hd * L * 4, 2 * B * hd * L)
     w["dWmu_dWlv"] = ((2 * Lp * Bp + hep * Bp) * 2 + 2 * L * he * 4, 2 * B * 2 * L * he)
     w["dW1"] = ((hep * Bp + Xep * Bp) * 2 + he * Xe * 4, 2 * B * Xe * he)
+    w["dW1_dWd_dWmu"] = tuple(w["dW1"][i] + w["dWd"][i] + w["dWmu_dWlv"][i] for i in range(2))      # one grouped launch
     # optimiser: 28 B per parameter (grad read, master / m / v read + write) plus the bf16 shadows it writes; since
     # hlvae_backward_adam y_layer's weight has its own early launch, the rest (and the small flat region) the final one
     n_wy, n_rest = NYl * hd, he * Xe + 2 * L * he + hd * L

@@ -140,7 +140,7 @@ class ELBOTrainer:
             m._swap_input_buffers()
         if not m._grad_region_clean:     # normally the fused Adam leaves the atomically-accumulated region zeroed
             _lib.check(lib.hlvae_zero_grad(m._plan_handle, ws, s), "zero_grad")
-        _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 1, 2 if self.metrics else 0, 0, B, s), "decoder_fwd")
+        _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 2, 2 if self.metrics else 0, 0, B, s), "decoder_fwd")     # want_grad = 2: ELBO scalars deferred to the backward's side stream
         if self.metrics:     # row M: imputed values + per-variable errors (training.py:84-101), device resident
             _lib.check(lib.hlvae_step_metrics(m._plan_handle, ws, B, _lib.ptr(self.err), s), "step_metrics")
         g_mu = g_lv = None

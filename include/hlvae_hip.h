@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 16
+#define HLVAE_ABI_VERSION 17
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -188,6 +188,9 @@ int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps,
  * g_logpx: upstream gradient of log_p_x, per element [B][D] fp32, or NULL -> the scalar g_scale.
  * Writes ws->dy = g * d log_p_x / d Y (zero where unobserved: stop-gradient of HLVAE.py:435-452) and
  * accumulates the head-parameter gradients into ws->G when want_grad != 0.
+ * want_grad = 2 (training step): as 1, and the scalar reductions (ws->nll, ws->scal, RNG offset advance) are DEFERRED like
+ * hlvae_step_metrics: queued on a library-owned side stream by the next hlvae_backward* / hlvae_join on this plan, so
+ * that the backward pass forks once for all its side work.  ws must stay valid until then.
  * want_params = 1 additionally fills ws->pfull and ws->xhat (p_params / row M); 2 = ws->xhat only (training metrics).
  * trunk != 0 recomputes the decoder trunk U = relu(z Wd^T + bd) from ws->zb first (decode(z) with a caller-set z);
  * hlvae_encoder_fwd already leaves U in the workspace (it is fused with the reparameterisation). */
@@ -198,8 +201,9 @@ int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_lo
  * err [3][D] fp32 = per-variable error over observed / missing / all rows (0/1 mismatch for cat, |dx|/K for ordinal,
  * range-normalised RMSE otherwise) from ws->xhat (decoder_fwd with want_params != 0), ws->xt and ws->m8. */
 int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* err, hlvae_stream s);
-/* hlvae_step_metrics runs on a library-owned side stream (forked from s); `err` is ordered before later work on a stream
- * only after that stream called hlvae_backward or hlvae_join. */
+/* hlvae_step_metrics only records its dependency on s; the kernels are queued on a library-owned side stream by the next
+ * hlvae_backward* / hlvae_join on this plan (ws and err must stay valid until then), and `err` is ordered before later
+ * work on a stream only after that stream called hlvae_backward* or hlvae_join. */
 int hlvae_join(const hlvae_plan* p, hlvae_stream s);
 
 /* rescale ws->dy by a per-element upstream gradient after the fact (autograd path) */
