@@ -404,7 +404,8 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     //   * three small GEMMs as one grouped launch instead of a third queue.
     // Measured (ms/step, D4, batch 512): one stream 0.225; forks queued side-first 0.196; this order 0.170; also tried:
     // Adam split three ways and fully concurrent 0.234, dWy forked behind dU 0.192, deferred kernels behind y_layer's
-    // Adam on side 0 0.186, deferred kernels forked before dU 0.183.
+    // Adam on side 0 0.186, deferred kernels forked before dU 0.183, Adam applied in the epilogue of the weight-gradient
+    // GEMMs (no gradient round trip) 0.180-0.190.
     hipStream_t s0 = p->side[0], s1 = p->side[1];
     if (d.conv)     // d y_grouped -> d a2 -> d (y_layer output), weight gradients of the transposed convolutions
         if ((rc = hl_launch_conv_dec_bwd(p, ws, B, Bp, st))) return rc;
@@ -415,21 +416,21 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     if ((rc = hl_launch_gemm_splitk(dyl, d.NYlp, ws->wyTs, d.NYlp, ws->slab, d.hdp, Bp, d.hdp, d.NYlp, ws->splitk_dec, "dU_splitk", st))) return rc;
     HL_CHECK(hipEventRecord(p->ev[2], st));        // the last reader of y_layer's weight shadows is done
     if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st))) return rc;
-    {   // d W1 = dT^T Xn [h_e][X] (no input gradient for layer 1);  d Wd = dU^T z [h_d][L];  d [Wmu; Wlv] = dml^T T 2 x [L][h_e]
-        GemmGroup g{};
-        g.n = 3;
-        g.K = Bp;
-        g.p[0] = GemmProb{ws->dtT, ws->xnT, ws->G + d.o_w1, nullptr, Bp, Bp, d.Xe, d.h_e, d.Xe, 0, 0};
-        g.p[1] = GemmProb{ws->duT, ws->zbT, ws->G + d.o_wd, nullptr, Bp, Bp, d.L, d.h_d, d.L, 0, 0};
-        g.p[2] = GemmProb{ws->dmlT, ws->tT, ws->G + d.o_wmu, ws->G + d.o_wlv, Bp, Bp, d.h_e, 2 * d.Lp, d.h_e, d.Lp, d.L};
-        if ((rc = hl_launch_gemm_f32_group(g, "dW1_dWd_dWmu", st))) return rc;
-    }
+    // d W1 = dT^T Xn [h_e][X] (no input gradient for layer 1);  d Wd = dU^T z [h_d][L];  d [Wmu; Wlv] = dml^T T 2 x [L][h_e]
+    GemmGroup g{};
+    g.n = 3;
+    g.K = Bp;
+    g.p[0] = GemmProb{ws->dtT, ws->xnT, ws->G + d.o_w1, nullptr, Bp, Bp, d.Xe, d.h_e, d.Xe, 0, 0};
+    g.p[1] = GemmProb{ws->duT, ws->zbT, ws->G + d.o_wd, nullptr, Bp, Bp, d.L, d.h_d, d.L, 0, 0};
+    g.p[2] = GemmProb{ws->dmlT, ws->tT, ws->G + d.o_wmu, ws->G + d.o_wlv, Bp, Bp, d.h_e, 2 * d.Lp, d.h_e, d.Lp, d.L};
+    if ((rc = hl_launch_gemm_f32_group(g, "dW1_dWd_dWmu", st))) return rc;
     if (d.conv) {   // the convolutional features receive a gradient: d feat = dT W1, then conv2 / conv1 / representation layer
         if ((rc = hl_launch_gemm_f32(ws->dt, d.hep, ws->w1Ts, d.hep, ws->dfeat, d.Xep, Bp, d.Xe, d.hep, 0, 0, nullptr, "dfeat", st))) return rc;
         if ((rc = hl_launch_conv_enc_bwd(p, ws, B, st))) return rc;
     }
     if (!skip_wy) {
         HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
+        // d Wy = dY^T U  [NYl][h_d]
         if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
         if (opt != nullptr) {       // takes no completion ticket: the final launch below is ordered behind it by the join
             HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));

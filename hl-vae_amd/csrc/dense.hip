@@ -90,6 +90,9 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32_group(GemmGroup g) {
     G::run(q.A, q.lda, q.B, q.ldb, m0, n0, M, N, 0, g.K, smem, acc);
     G::to_lds(acc, smem);
     const float* Cs = reinterpret_cast<const float*>(smem);
+    // (applying Adam to the finished tile right here -- no gradient round trip through HBM, no optimiser launch -- was
+    // built and measured: 0.190 vs 0.166 ms/step.  1-2 workgroups per CU cannot keep enough bytes in flight for a streaming
+    // epilogue, and the two fused launches contend for HBM exactly when the critical path needs it.)
     for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
         const int r = idx / BN, c = idx % BN;
         const int gr = m0 + r, gc = n0 + c;

@@ -19,14 +19,30 @@ __global__ __launch_bounds__(256) void k_colstats_compact(const float* __restric
     if (sc < n_stat) {
         const int d = stat_var[sc];
         const int kind = vars[d].kind;
-        for (int b = b_lo + threadIdx.y; b < b_hi; b += 4) {
-            const size_t o = (size_t)rows[b] * D + d;
-            const double m = mk[o] ? 1.0 : 0.0;
-            double x = (double)vals[o] * m;                      // observed_data = d * m  (utils.py:98,124)
-            if (kind == HLVAE_POS) x = log1p(x);                 // :125
-            s0 += m;
-            s1 += x * m;
-            s2 += x * x * m;
+        // two dependent gathers per entry (row index, then value + mask): 8 entries in flight per lane -- at 512 rows the
+        // kernel is one such round, pure latency
+        constexpr int U = 8;
+        for (int bb = b_lo + threadIdx.y; bb < b_hi; bb += 4 * U) {
+            int rr[U];
+            float xv[U];
+            uint8_t mm[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) rr[u] = bb + 4 * u < b_hi ? rows[bb + 4 * u] : -1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t o = (size_t)max(rr[u], 0) * D + d;
+                xv[u] = vals[o];
+                mm[u] = mk[o];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double m = (rr[u] >= 0 && mm[u]) ? 1.0 : 0.0;
+                double x = (double)xv[u] * m;                    // observed_data = d * m  (utils.py:98,124)
+                if (kind == HLVAE_POS) x = log1p(x);             // :125
+                s0 += m;
+                s1 += x * m;
+                s2 += x * x * m;
+            }
         }
     }
     red[0][threadIdx.y][threadIdx.x] = s0;

@@ -209,19 +209,25 @@ class ELBOTrainer:
         self._graphs[key] = g
         return g
 
-    def capture_rows(self, key, ds, rows: torch.Tensor, P_batch: int):
+    def capture_rows(self, key, ds, rows, P_batch):
         """Capture ``step_rows`` reading the STATIC index tensor ``rows``: refill it in place (``rows.copy_(...)``) and
-        replay -- one graph serves every batch of that size and subject count."""
+        replay -- one graph serves every batch of that size and subject count.
+
+        ``rows`` / ``P_batch`` may be LISTS: that many consecutive steps (one per index tensor) go into ONE graph.  Inside a
+        graph the last kernel of a step and the first of the next are neighbours on one hardware queue (no gap); between
+        two graph launches the executor joins and re-forks its queues (~6 us on MI355X)."""
+        chain = list(zip(rows, P_batch)) if isinstance(rows, (list, tuple)) else [(rows, P_batch)]
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                self.step_rows(ds, rows, P_batch)
+                self.step_rows(ds, chain[0][0], chain[0][1])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.cuda.graph(g):
-            self.step_rows(ds, rows, P_batch)
+            for r, pb in chain:
+                self.step_rows(ds, r, pb)
         self._graphs[key] = g
         return g
 
