@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -69,6 +69,7 @@ _SIGS = {
     "hlvae_normalize_pack": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_int, _vp]),
     "hlvae_normalize_fused": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_int, _vp]),
     "hlvae_feed_fused": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_int, _vp]),
+    "hlvae_feed_prefetch": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_int, _vp]),
     "hlvae_feed_stats": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_int, _vp]),
     "hlvae_feed_pack": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_int, _vp]),
     "hlvae_encoder_fwd": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, C.c_uint64, C.c_int, _vp]),

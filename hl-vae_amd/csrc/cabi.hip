@@ -273,6 +273,27 @@ int hlvae_feed_fused(const hlvae_plan* p, const hlvae_ws* ws, const float* value
     return hlvae_feed_pack(p, ws, values, mask8, rows, B, s);
 }
 
+int hlvae_feed_prefetch(const hlvae_plan* p, const hlvae_ws* ws_next, const float* values, const uint8_t* mask8,
+                        const int32_t* rows, int B, hlvae_stream s) {
+    const hlvae_ws* ws = ws_next;
+    CHECK_B();
+    HL_REQUIRE(values && mask8 && rows, HLVAE_EINVAL, "feed_prefetch: null pointer");
+    HL_REQUIRE(!d.conv, HLVAE_EINVAL, "feed_prefetch: the convolutional input stage reads the weights (conv1 / conv2) -- it cannot "
+               "run ahead of the optimiser step");
+    // like hlvae_step_metrics: only the dependency is recorded; the two kernels are queued on a side stream by the next
+    // hlvae_backward* / hlvae_join (behind whatever else was deferred)
+    if (p->pend_flags & (HL_PEND_FEED | HL_PEND_RUNNING))
+        if (int rc = hlvae_join(p, s)) return rc;
+    HL_CHECK(hipEventRecord(p->ev[5], st));
+    p->pend_feed_ws = *ws_next;
+    p->pend_feed_B = B;
+    p->pend_feed_vals = values;
+    p->pend_feed_mask = mask8;
+    p->pend_feed_rows = rows;
+    p->pend_flags |= HL_PEND_FEED;
+    return 0;
+}
+
 int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int sample, uint64_t rng_host_offset,
                       int B, hlvae_stream s) {
     CHECK_B();
@@ -338,7 +359,7 @@ int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* er
 // queues the deferred launches on `side`.  side_is_ordered: the caller has just made `side` wait for a LATER point of
 // its stream than ev[5] (one fork point for all the side work of the backward pass)
 static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered) {
-    if (!(p->pend_flags & (HL_PEND_METRICS | HL_PEND_FINALIZE))) return 0;
+    if (!(p->pend_flags & HL_PEND_DEFERRED)) return 0;
     if (!side_is_ordered) HL_CHECK(hipStreamWaitEvent(side, p->ev[5], 0));
     if (p->pend_flags & HL_PEND_FINALIZE) {
         const int B = p->pend_fin_B;
@@ -346,6 +367,13 @@ static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is
     }
     if (p->pend_flags & HL_PEND_METRICS)
         if (int rc = hl_launch_step_metrics(p, &p->pend_ws, p->pend_B, p->pend_err, side)) return rc;
+    if (p->pend_flags & HL_PEND_FEED) {       // input stage of the NEXT batch into the other buffer set (data only, no weights)
+        const int B = p->pend_feed_B;
+        if (p->d.n_stat > 0)
+            if (int rc = hl_launch_stats_compact(p, &p->pend_feed_ws, p->pend_feed_vals, p->pend_feed_mask, p->pend_feed_rows, B, side)) return rc;
+        if (int rc = hl_launch_pack_compact(p, &p->pend_feed_ws, p->pend_feed_vals, p->pend_feed_mask, p->pend_feed_rows, B,
+                                            (B + 127) / 128 * 128, side)) return rc;
+    }
     HL_CHECK(hipEventRecord(p->ev[5], side));
     p->pend_flags = HL_PEND_RUNNING;
     return 0;
@@ -439,15 +467,17 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         }
         HL_CHECK(hipEventRecord(p->ev[3], s0));
     }
-    if (p->pend_flags & (HL_PEND_METRICS | HL_PEND_FINALIZE)) {
+    if (p->pend_flags & HL_PEND_DEFERRED) {
         HL_CHECK(hipStreamWaitEvent(s1, p->ev[2], 0));
         if ((rc = hl_flush_deferred(p, s1, true))) return rc;
     }
     if (!skip_wy) HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
-    if ((rc = hlvae_join(p, s))) return rc;
-    if (opt != nullptr)     // Adam of the other matrices + the small flat region; commits the step number
-        return hl_adam(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, st, skip_wy ? 0 : 1);
-    return 0;
+    if (opt != nullptr)     // Adam of the other matrices + the small flat region; commits the step number.  Behind side 0
+        // (two concurrent Adam launches thrash HBM), but NOT behind side 1: its deferred kernels only have to be done
+        // by the end of the step
+        if ((rc = hl_adam(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, st, skip_wy ? 0 : 1)))
+            return rc;
+    return hlvae_join(p, s);
 }
 
 int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,

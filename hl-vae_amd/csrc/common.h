@@ -59,7 +59,8 @@ struct GemmGroup {
     int n, K;
 };
 
-enum { HL_PEND_METRICS = 1, HL_PEND_FINALIZE = 2, HL_PEND_RUNNING = 4 };
+enum { HL_PEND_METRICS = 1, HL_PEND_FINALIZE = 2, HL_PEND_RUNNING = 4, HL_PEND_FEED = 8,
+       HL_PEND_DEFERRED = HL_PEND_METRICS | HL_PEND_FINALIZE | HL_PEND_FEED };
 
 struct hlvae_plan {
     hlvae_dims d;
@@ -76,6 +77,11 @@ struct hlvae_plan {
     mutable hlvae_ws pend_ws, pend_fin_ws;
     mutable int pend_B, pend_fin_B;
     mutable float* pend_err;
+    mutable hlvae_ws pend_feed_ws;
+    mutable int pend_feed_B;
+    mutable const float* pend_feed_vals;
+    mutable const uint8_t* pend_feed_mask;
+    mutable const int32_t* pend_feed_rows;
 };
 
 void hl_set_error(const char* fmt, ...);

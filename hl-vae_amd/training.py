@@ -102,26 +102,45 @@ class ELBOTrainer:
             m._run_normalize(data, mask, B, hook)
         self._step_core(B, scale, eps, train_x, P_batch, prefetch, hook)
 
-    def step_rows(self, ds, rows: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None, groups=None):
+    def prime_rows(self, ds, rows: torch.Tensor):
+        """input stage of a batch of the compact dataset now, for a following ``step_rows(..., prepacked=True)``"""
+        m = self.model
+        B = rows.shape[0]
+        m._ensure_device_state(B)
+        _lib.check(_lib.load().hlvae_feed_fused(m._plan_handle, C.byref(m._ws), _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows),
+                                                B, m._stream()), "feed_fused")
+
+    def step_rows(self, ds, rows: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None, groups=None,
+                  prefetch_rows: Optional[torch.Tensor] = None, prepacked: bool = False):
         """One step on the rows ``rows`` (int32 device tensor) of a device-resident ``datafeed.DeviceDataset``: the input
         stage gathers from the compact form inside its kernels (csrc/feed.hip); nothing else crosses PCIe.  Capturable:
-        refill ``rows`` in place and replay."""
+        refill ``rows`` in place and replay.
+
+        prefetch_rows: the NEXT batch's rows.  Its input stage (statistics, normalise, pack: data only, no weights) is queued
+        by the library on the side stream of this step's backward pass, into the second buffer set; the next call passes
+        ``prepacked=True`` and starts at the first GEMM.  Single process, MLP model (the convolutional input stage reads
+        the weights; data-parallel runs all-reduce the statistics between the two kernels)."""
         m = self.model
         lib = _lib.load()
         B = rows.shape[0]
         m._ensure_device_state(B)
         m._packed_key = None
         ws, s = C.byref(m._ws), m._stream()
-        if self.dp is None:
+        if prefetch_rows is not None and (self.dp is not None or m.conv):
+            raise ValueError("step_rows(prefetch_rows=...): single-process MLP training only")
+        if prepacked:
+            pass
+        elif self.dp is None:
             _lib.check(lib.hlvae_feed_fused(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_fused")
         else:
             _lib.check(lib.hlvae_feed_stats(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_stats")
             self.dp.allreduce_stats(m._ws_t["sums"])
             _lib.check(lib.hlvae_feed_pack(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_pack")
         train_x = ds.labels.index_select(0, rows.long()) if self.kl == "gp" else None
-        self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None)
+        self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None,
+                        feed_next=None if prefetch_rows is None else (ds, prefetch_rows))
 
-    def _step_core(self, B, scale, eps, train_x, P_batch, prefetch, hook):
+    def _step_core(self, B, scale, eps, train_x, P_batch, prefetch, hook, feed_next=None):
         m = self.model
         lib = _lib.load()
         ws, s = C.byref(m._ws), m._stream()
@@ -143,6 +162,12 @@ class ELBOTrainer:
         _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 2, 2 if self.metrics else 0, 0, B, s), "decoder_fwd")     # want_grad = 2: ELBO scalars deferred to the backward's side stream
         if self.metrics:     # row M: imputed values + per-variable errors (training.py:84-101), device resident
             _lib.check(lib.hlvae_step_metrics(m._plan_handle, ws, B, _lib.ptr(self.err), s), "step_metrics")
+        if feed_next is not None:       # deferred: the backward pass queues it on its side stream (hlvae_feed_prefetch)
+            nds, nrows = feed_next
+            m._ensure_device_state(nrows.shape[0])
+            _lib.check(lib.hlvae_feed_prefetch(m._plan_handle, C.byref(m._ws_alt), _lib.ptr(nds.values), _lib.ptr(nds.mask),
+                                               _lib.ptr(nrows), nrows.shape[0], s), "feed_prefetch")
+            self._pf_ref = feed_next
         g_mu = g_lv = None
         kl_w = 1.0 if self.kl == "normal" else 0.0
         if self.kl == "gp":
@@ -182,6 +207,9 @@ class ELBOTrainer:
             m._swap_input_buffers()
             m._packed_key = self._batch_key(prefetch[0], prefetch[1])
             self._pf_ref = prefetch          # keep the tensors alive: their addresses identify the packed batch
+        elif feed_next is not None:              # joined by the backward call; its buffers become the front set
+            m._swap_input_buffers()
+            m._packed_key = None
         else:
             m._packed_key = None
             self._pf_ref = None
@@ -209,25 +237,34 @@ class ELBOTrainer:
         self._graphs[key] = g
         return g
 
-    def capture_rows(self, key, ds, rows, P_batch):
+    def capture_rows(self, key, ds, rows, P_batch, next_rows=None):
         """Capture ``step_rows`` reading the STATIC index tensor ``rows``: refill it in place (``rows.copy_(...)``) and
         replay -- one graph serves every batch of that size and subject count.
 
         ``rows`` / ``P_batch`` may be LISTS: that many consecutive steps (one per index tensor) go into ONE graph.  Inside a
         graph the last kernel of a step and the first of the next are neighbours on one hardware queue (no gap); between
-        two graph launches the executor joins and re-forks its queues (~6 us on MI355X)."""
-        chain = list(zip(rows, P_batch)) if isinstance(rows, (list, tuple)) else [(rows, P_batch)]
+        two graph launches the executor joins and re-forks its queues (~6 us on MI355X).
+
+        next_rows (a tensor, or a list for a chain): PIPELINED input stage -- the graph does not contain its batch's own
+        input stage (``prime_rows`` before the first replay, the previous step of the chain afterwards) and every step runs
+        the input stage of ``next_rows`` beside its backward pass.  The steps alternate between the two buffer sets, so a
+        ring of such graphs must hold an even number of steps and be replayed in capture order."""
+        many = isinstance(rows, (list, tuple))
+        chain = list(zip(rows, P_batch)) if many else [(rows, P_batch)]
+        nxt = [None] * len(chain) if next_rows is None else (list(next_rows) if many else [next_rows])
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(2):
+            for _ in range(2):                       # warm-up (an even number of steps: the buffer sets end where they began)
                 self.step_rows(ds, chain[0][0], chain[0][1])
+            if next_rows is not None:
+                self.prime_rows(ds, chain[0][0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.cuda.graph(g):
-            for r, pb in chain:
-                self.step_rows(ds, r, pb)
+            for (r, pb), nr in zip(chain, nxt):
+                self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None)
         self._graphs[key] = g
         return g
 

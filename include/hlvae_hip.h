@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 17
+#define HLVAE_ABI_VERSION 18
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -175,6 +175,14 @@ int hlvae_normalize_stats(const hlvae_plan* p, const hlvae_ws* ws, const double*
                           int B, hlvae_stream s);
 int hlvae_normalize_pack(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask,
                          int B, hlvae_stream s);
+
+/* The input stage of the NEXT batch, into another set of input-stage buffers (ws_next: a copy of the workspace whose xn,
+ * xnT, xt, m8, sums, norm point at the second set).  It depends on the data only, so it can run beside the backward pass of
+ * the current batch: deferred like hlvae_step_metrics -- queued on a library-owned side stream by the next hlvae_backward* /
+ * hlvae_join on this plan (all pointers must stay valid until then).  Not for the convolutional model (its input stage
+ * runs conv1 / conv2, i.e. reads the weights). */
+int  hlvae_feed_prefetch(const hlvae_plan* p, const hlvae_ws* ws_next, const float* values, const uint8_t* mask8,
+                         const int32_t* rows, int B, hlvae_stream s);
 
 /* rows B + C -- HLVAE.encode MLP branch (HLVAE.py:311-324) + sample_latent (:351-362).
  * noise: eps != NULL -> that [B][L] fp32 tensor;  eps == NULL && sample != 0 -> Philox4x32-10 normals generated in

@@ -645,6 +645,67 @@ def test_compact_feed_matches_expanded_inputs(conv):
     assert rel_err(b["P"], a["P"]) < 1e-6
 
 
+def test_compact_feed_pipelined_matches_serial():
+    """step_rows(prefetch_rows=next) -- the next batch's input stage deferred to the side stream of this step's backward pass
+    (hlvae_feed_prefetch), into the second buffer set -- follows the trajectory of steps that run their own input stage:
+    eagerly, and as ONE captured HIP graph of 4 chained steps replayed twice (ragged batch sizes, two alternating batches of
+    different length are not allowed in one static graph: same length, different rows)."""
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    from hlvae_amd.datafeed import CompactDataset
+    dev = _dev()
+    src = synthetic.make_tabular(n_rows=90, T=6, seed=8, spec=MIX_SPEC)
+    dims = [src.cov_dim_ext, [16], 4, [16], 5]
+    ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    rg = np.random.default_rng(3)
+    R = [torch.tensor(rg.permutation(90)[:37].astype(np.int32), device=dev) for _ in range(4)]
+    eps = [torch.randn(37, dims[2], generator=torch.Generator().manual_seed(20 + i)).to(dev) for i in range(8)]
+
+    def fresh():
+        torch.manual_seed(0)
+        model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=128, materialize_samples=False).to(dev)
+        return model, ELBOTrainer(model, P_total=15, kl="normal", max_batch=128)
+
+    def run(pipelined):
+        model, tr = fresh()
+        if pipelined:
+            tr.prime_rows(ds, R[0])
+        nll, err = [], []
+        for i in range(8):
+            tr.step_rows(ds, R[i % 4], 7, eps=eps[i], prefetch_rows=R[(i + 1) % 4] if pipelined else None, prepacked=pipelined)
+            nll.append(float(tr.scalars()["nll_sum"]))
+            err.append(tr.err.clone())
+        return nll, model._arena.clone(), torch.stack(err)
+
+    nll_a, P_a, e_a = run(False)
+    nll_b, P_b, e_b = run(True)
+    assert rel_err(np.array(nll_b), np.array(nll_a)) < 1e-6, (nll_a, nll_b)
+    assert rel_err(P_b, P_a) < 1e-6 and rel_err(e_b, e_a) < 1e-5
+    # one graph of 4 chained pipelined steps, replayed twice, against 8 eager serial steps with the same in-kernel noise
+    model, tr = fresh()
+    P0 = model._arena.clone()
+    tr.capture_rows("ring", ds, R, [7] * 4, next_rows=[R[(i + 1) % 4] for i in range(4)])
+
+    def reset():
+        model._arena.copy_(P0)
+        model._sync_shadows(force=True)
+        tr.opt.m1.zero_(); tr.opt.m2.zero_(); tr.opt.step_count.zero_()
+
+    reset()
+    rng0 = model._ws_t["rng"].clone()
+    tr.prime_rows(ds, R[0])
+    tr.replay("ring")
+    tr.replay("ring")
+    nll_g, P_g = float(tr.scalars()["nll_sum"]), model._arena.clone()
+    assert int(tr.opt.step_count[0]) == 8
+    reset()
+    model._ws_t["rng"].copy_(rng0)
+    for i in range(8):
+        tr.step_rows(ds, R[i % 4], 7)
+    assert abs(nll_g - float(tr.scalars()["nll_sum"])) <= 1e-6 * abs(nll_g)
+    assert rel_err(P_g, model._arena) < 1e-6
+
+
 def test_gp_posterior_prediction_against_reference_fixture(golden_dir):
     """GPPriorHIP.batch_predict_varying_T (HIP kernel matrices, per-subject blocks, M x M inverses) against the
     reference's utils.batch_predict_varying_T output stored in tests/golden/gp_predict.npz.  fp64: 1e-8."""
