@@ -603,6 +603,46 @@ def test_gp_prior_hip_against_autograd_statement(varying_T):
     assert rel_err(hip.zt_list, ref.zt_list) < 1e-9
 
 
+def test_gp_prior_config5_size_against_autograd_statement():
+    """BASELINE configs[4] (GP variant) at its full size: 32 latent GPs, 120 inducing points, 6 covariates, a 1024-row batch
+    of 51 whole subjects x 20 rows + 4 rows of a 52nd -- bound, gradients w.r.t. mu / log-variance, natural-gradient
+    statistics and hyper-parameter gradients of the HIP path against the torch-autograd statement on the CPU (LAPACK)."""
+    from hlvae_amd.elbo_functions import GPPrior, GPPriorHIP
+    dev = _dev()
+    torch.manual_seed(1)
+    L, M = 32, 120
+    Ts = [20] * 51 + [4]
+    rows = []
+    for s_, T in enumerate(Ts):
+        for t in range(T):
+            sick = s_ % 2
+            rows.append([float(t), float(t - 9) if sick else 0.0, float(s_), float(s_ % 2), float(sick), float((s_ // 2) % 2)])
+    x = torch.tensor(rows, dtype=torch.float64)
+    x = x[torch.randperm(x.shape[0])].to(dev)
+    B = x.shape[0]
+    assert B == 1024
+    hip = GPPriorHIP(L, x, M, 2, N_total=50000, seed=4)
+    ref = GPPrior(L, x.cpu(), M, 2, N_total=50000, seed=4)
+    with torch.no_grad():
+        hip.prm.add_(0.2 * torch.randn_like(hip.prm))
+        hip.zt_list.add_(0.05 * torch.randn_like(hip.zt_list))
+    _copy_hip_params_to_torch_gp(hip, ref)
+    mu = torch.randn(B, L, device=dev)
+    lv = (0.5 * torch.randn(B, L, device=dev) - 1.0)
+    g_mu_r, g_lv_r = ref.kl_and_grads(mu.cpu(), lv.cpu(), x.cpu(), 2500, len(Ts))
+    assert bool(torch.isfinite(ref.last_kld).all())
+    g_mu_h, g_lv_h = hip.kl_and_grads(mu, lv, x, 2500, len(Ts))
+    torch.cuda.synchronize()
+    assert int(hip.fail.item()) == 0
+    assert rel_err(hip.last_kld, ref.last_kld) < 1e-9
+    assert rel_err(g_mu_h, g_mu_r) < 1e-5 and rel_err(g_lv_h, g_lv_r) < 1e-5          # fp32 outputs
+    assert rel_err(hip._grad_m, ref._grad_m) < 1e-7 and rel_err(hip._grad_H, ref._grad_H) < 1e-7
+    assert rel_err(hip.zt_list.grad, ref.zt_list.grad) < 1e-6
+    hip.optimizer_step()
+    ref.optimizer_step()
+    assert rel_err(hip.m, ref.m) < 1e-7 and rel_err(hip.H, ref.H) < 1e-7
+
+
 @pytest.mark.parametrize("conv", [False, True])
 def test_compact_feed_matches_expanded_inputs(conv):
     """the input stage gathering from the device-resident compact dataset (csrc/feed.hip) leaves exactly the
