@@ -496,7 +496,13 @@ int hlvae_backward_adam(const hlvae_plan* p, const hlvae_ws* ws, const float* g_
 int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr,
                     float beta1, float beta2, float eps, float grad_scale, hlvae_stream s) {
     HL_REQUIRE(p && ws && m1 && m2 && step_count, HLVAE_EINVAL, "adam_step: null argument");
-    return hl_adam(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, (hipStream_t)s, 0);
+    // two launches back to back (y_layer's weight, then the rest + the flat region, which commits the step number): 46 us for
+    // the D4 model against 80 us as ONE launch over all five matrices.  A streaming kernel whose workgroups are all resident
+    // at once runs in lock-step (everyone reads, then everyone writes); past one wave of workgroups the phases interleave
+    // and HBM pays read/write turnarounds (the same effect makes two concurrent Adam launches crawl, hl_backward_impl).
+    if (int rc = hl_adam_part(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, 0x01, 0, 0u, "adam_wy_early", (hipStream_t)s))
+        return rc;
+    return hl_adam(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, (hipStream_t)s, 1);
 }
 
 int hlvae_gemm_nt_f32(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc, int M, int N, int K,

@@ -21,7 +21,8 @@ struct ShadowMat {
     bf16_t* dstT;      // [..][ldT] transposed bf16 or nullptr
     int ldT;
     int Rcover, Ccover;   // region of dst (rows, cols) to fill, zero outside [R][C]
-    int tiles_c, tile0;   // tiles per row of tiles, first block index
+    int tiles_c, tile0;   // tiles per row of tiles, first block index (a multiple of 8)
+    int npad, remap;      // workgroups owned (tiles rounded up to a multiple of 8); XCD-contiguous tile order
 };
 struct ShadowSet {
     ShadowMat m[5];
@@ -65,15 +66,19 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
         }
         return;
     }
-    // neighbouring column tiles of a row band share their boundary cache lines whenever the row stride is not a multiple
-    // of 128 B (y_layer: 2000 B): the XCD-contiguous remap puts them behind the same L2 (PMC: 1.45x -> x over-fetch)
-    const int bid = xcd_remap(blockIdx.x, set.total_tiles);
     int mi = 0;
 #pragma unroll
     for (int k = 1; k < 5; ++k)
-        if (k < set.n && bid >= set.m[k].tile0) mi = k;
+        if (k < set.n && (int)blockIdx.x >= set.m[k].tile0) mi = k;
     const ShadowMat mt = set.m[mi];
-    const int tl = bid - mt.tile0;
+    // Neighbouring column tiles of a row band share their boundary cache lines whenever the row stride is not a multiple of
+    // 128 B (y_layer: 2000 B).  For such a matrix the XCD-contiguous remap puts them behind the same L2 (PMC: 1.45x -> 1.0x
+    // of the algorithmic reads).  Matrices with aligned rows keep the round-robin placement: there the remap only
+    // multiplies the number of DRAM streams by 8 (all-in-one launch: 81 vs 37 us).  Every matrix starts at a workgroup
+    // index that is a multiple of 8 and owns a multiple of 8 workgroups, so the local index keeps the hardware XCD; the
+    // padding workgroups land beyond the last row band and do nothing.
+    int tl = blockIdx.x - mt.tile0;
+    if (mt.remap) tl = xcd_remap(tl, mt.npad);
     const int r0 = (tl / mt.tiles_c) * T, c0 = (tl % mt.tiles_c) * T;
     AdamScalars a;
     if (update) a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
@@ -190,7 +195,9 @@ static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws, unsigned whic
     int t = 0;
     for (int i = 0; i < n; ++i) {
         s.m[i].tile0 = t;
-        t += s.m[i].tiles_c * ((s.m[i].Rcover + 63) / 64);
+        s.m[i].npad = ru(s.m[i].tiles_c * ((s.m[i].Rcover + 63) / 64), 8);
+        s.m[i].remap = ((long)s.m[i].C * 4) % 128 != 0;
+        t += s.m[i].npad;
     }
     s.total_tiles = t;
     return s;

@@ -116,8 +116,6 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None):
     buf = C.create_string_buffer(1 << 16)
     _lib.check(lib.hlvae_prof_report(buf, len(buf)), "hlvae_prof_report")
     work = algorithmic_work(m, B)
-    if getattr(trainer, "dp", None) is not None:        # data parallel: hlvae_adam_step updates all matrices in one launch
-        work["adam_weights_shadows"] = work["adam_all_in_one"]
     if ds is not None:      # compact feed: 5 B per entry in instead of the expanded fp64 matrices
         d_ = m._dims
         work["normalize_pack"] = (B * d_.D * 5 + 2 * B * d_.Xp * 2 + B * d_.D * 5, 0)
