@@ -29,6 +29,7 @@ int hl_launch_conv_dec_fwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t)
 int hl_launch_conv_dec_bwd(const hlvae_plan*, const hlvae_ws*, int, int, hipStream_t);
 int hl_launch_conv_enc_bwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
 int hl_launch_gemm_f32_group(GemmGroup, const char*, hipStream_t);
+int hl_launch_transpose_bf16(const bf16_t*, int, bf16_t*, int, int, int, const char*, hipStream_t);
 int hl_adam_grid(const hlvae_plan*, const hlvae_ws*, unsigned, int);
 int hl_adam_part(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, unsigned, int,
                  unsigned, const char*, hipStream_t);
@@ -381,7 +382,7 @@ static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is
 
 int hlvae_join(const hlvae_plan* p, hlvae_stream s) {
     HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
-    if (int rc = hl_flush_deferred(p, p->side[1], false)) return rc;
+    if (int rc = hl_flush_deferred(p, g_prof_on ? (hipStream_t)s : p->side[1], false)) return rc;
     if (p->pend_flags & HL_PEND_RUNNING) {
         HL_CHECK(hipStreamWaitEvent((hipStream_t)s, p->ev[5], 0));
         p->pend_flags = 0;
@@ -434,7 +435,8 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     // Adam split three ways and fully concurrent 0.234, dWy forked behind dU 0.192, deferred kernels behind y_layer's
     // Adam on side 0 0.186, deferred kernels forked before dU 0.183, Adam applied in the epilogue of the weight-gradient
     // GEMMs (no gradient round trip) 0.180-0.190.
-    hipStream_t s0 = p->side[0], s1 = p->side[1];
+    // (per-kernel timing on: everything on the caller's stream, so that every kernel is timed alone)
+    hipStream_t s0 = g_prof_on ? st : p->side[0], s1 = g_prof_on ? st : p->side[1];
     if (d.conv)     // d y_grouped -> d a2 -> d (y_layer output), weight gradients of the transposed convolutions
         if ((rc = hl_launch_conv_dec_bwd(p, ws, B, Bp, st))) return rc;
     const bf16_t* dyl = d.conv ? ws->dyc : ws->dy;          // gradient of y_layer's output, both layouts
@@ -452,18 +454,27 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     g.p[1] = GemmProb{ws->duT, ws->zbT, ws->G + d.o_wd, nullptr, Bp, Bp, d.L, d.h_d, d.L, 0, 0};
     g.p[2] = GemmProb{ws->dmlT, ws->tT, ws->G + d.o_wmu, ws->G + d.o_wlv, Bp, Bp, d.h_e, 2 * d.Lp, d.h_e, d.Lp, d.L};
     if ((rc = hl_launch_gemm_f32_group(g, "dW1_dWd_dWmu", st))) return rc;
+    const bool conv_opt = d.conv && opt != nullptr && !skip_wy;
     if (d.conv) {   // the convolutional features receive a gradient: d feat = dT W1, then conv2 / conv1 / representation layer
         if ((rc = hl_launch_gemm_f32(ws->dt, d.hep, ws->w1Ts, d.hep, ws->dfeat, d.Xep, Bp, d.Xe, d.hep, 0, 0, nullptr, "dfeat", st))) return rc;
+        if (conv_opt) HL_CHECK(hipEventRecord(p->ev[1], st));      // dense gradients final, W1's transposed shadow read
         if ((rc = hl_launch_conv_enc_bwd(p, ws, B, st))) return rc;
     }
     if (!skip_wy) {
         HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
+        if (d.conv)     // the batch-contiguous copy of d(y_layer output) that the weight-gradient GEMM reads
+            if ((rc = hl_launch_transpose_bf16(ws->dyc, d.NYlp, ws->dycT, Bp, Bp, d.NYl, "dyc_transpose", s0))) return rc;
         // d Wy = dY^T U  [NYl][h_d]
         if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
         if (opt != nullptr) {       // takes no completion ticket: the final launch below is ordered behind it by the join
             HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
             if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0x01, 0,
                                    0u, "adam_wy_early", s0))) return rc;
+            if (conv_opt) {     // convolutional model: the other dense matrices too, under the 56 us of the encoder's backward
+                HL_CHECK(hipStreamWaitEvent(s0, p->ev[1], 0));
+                if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0x1e,
+                                       0, 0u, "adam_dense_early", s0))) return rc;
+            }
         }
         HL_CHECK(hipEventRecord(p->ev[3], s0));
     }
@@ -475,7 +486,10 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     if (opt != nullptr)     // Adam of the other matrices + the small flat region; commits the step number.  Behind side 0
         // (two concurrent Adam launches thrash HBM), but NOT behind side 1: its deferred kernels only have to be done
         // by the end of the step
-        if ((rc = hl_adam(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, st, skip_wy ? 0 : 1)))
+        if ((rc = conv_opt ? hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1,
+                                          (unsigned)hl_adam_grid(p, ws, 0u, 1), "adam_small", st)
+                           : hl_adam(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, st,
+                                     skip_wy ? 0 : 1)))
             return rc;
     return hlvae_join(p, s);
 }

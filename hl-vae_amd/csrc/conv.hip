@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_conv_enc_fwd(
     const double* __restrict__ data, const double* __restrict__ mask, const float* __restrict__ cvals,
     const uint8_t* __restrict__ cmask, const int32_t* __restrict__ crows, const hlvae_var* __restrict__ vars,
     const float* __restrict__ P, hlvae_dims d, const double* __restrict__ sums, float* __restrict__ norm,
-    const bf16_t* __restrict__ cp, bf16_t* __restrict__ xn, bf16_t* __restrict__ xnT, float* __restrict__ xt,
+    const bf16_t* __restrict__ cp, bf16_t* __restrict__ xn, float* __restrict__ xt,
     uint8_t* __restrict__ m8, float* __restrict__ img_out, int B, int Bp) {
     __shared__ float img[IMG_LD * IMG_LD];
     __shared__ __attribute__((aligned(16))) bf16_t a1[A1_LD * A1_LD * CV_C1];
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void k_conv_enc_fwd(
     __syncthreads();
     for (int i = tid; i < CV_FEAT / 2; i += 256)
         reinterpret_cast<uint32_t*>(xn + (size_t)b * d.Xep)[i] = reinterpret_cast<const uint32_t*>(feat)[i];
-    for (int i = tid; i < CV_FEAT; i += 256) xnT[(size_t)i * Bp + b] = feat[i];
+    // (the transposed copy is made by k_transpose_bf16: from here it would be 2592 two-byte stores per image, each to a
+    // line of its own -- 28 MB of HBM write transactions for 2.6 MB of data, PMC)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256) void k_convT2_bwd(const bf16_t* __restrict__ d
 // d yc = ConvTranspose^T(d a2);  d W_t1 += yc (x) d a2;  d b_t1 += sum d a2
 __global__ __launch_bounds__(256) void k_convT1_bwd(const bf16_t* __restrict__ da2, const bf16_t* __restrict__ yc, int ldy,
                                                     const bf16_t* __restrict__ cp, bf16_t* __restrict__ dyc,
-                                                    bf16_t* __restrict__ dycT, int Bp, float* __restrict__ part,
+                                                    float* __restrict__ part,
                                                     long part_stride, long part_lo, long o_w, long o_b, long o_by, int B) {
     float* __restrict__ prow = part + (size_t)blockIdx.x * part_stride - part_lo;
     float* __restrict__ gw = prow + o_w;
@@ -531,7 +532,6 @@ __global__ __launch_bounds__(256) void k_convT1_bwd(const bf16_t* __restrict__ d
         __syncthreads();
         for (int i = tid; i < CV_FEAT / 2; i += 256)
             reinterpret_cast<uint32_t*>(dyc + (size_t)b * ldy)[i] = reinterpret_cast<const uint32_t*>(outs)[i];
-        for (int i = tid; i < CV_FEAT; i += 256) dycT[(size_t)i * Bp + b] = outs[i];
 #pragma unroll
         for (int k = 0; k < (CV_FEAT + 255) / 256; ++k)
             if (tid + 256 * k < CV_FEAT) yacc[k] += bf2f(outs[tid + 256 * k]);
@@ -808,14 +808,14 @@ __global__ __launch_bounds__(512) void k_conv_enc_bwd(const float* __restrict__ 
 
 // representation layer (HLVAE.py:91-102): d w[d][k] = sum_b g[b][d] x_k[b][d], d bias[d] = sum_b g[b][d] over the observed
 // rows, x = one-hot (cat) or thermometer (ordinal) of the packed class index.  grid (ceil(D / 256), row chunks)
-__global__ __launch_bounds__(256) void k_conv_rep_grad(const float* __restrict__ dimg, const float* __restrict__ xt,
-                                                       const uint8_t* __restrict__ m8, const hlvae_var* __restrict__ vars, int D,
-                                                       int B, float* __restrict__ G) {
-    const int dd = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void conv_rep_grad(int bx, int by, int ny, const float* __restrict__ dimg, const float* __restrict__ xt,
+                                              const uint8_t* __restrict__ m8, const hlvae_var* __restrict__ vars, int D,
+                                              int B, float* __restrict__ G) {
+    const int dd = bx * 256 + threadIdx.x;
     if (dd >= D) return;
     const hlvae_var var = vars[dd];
     if (var.kind != HLVAE_CAT && var.kind != HLVAE_ORDINAL) return;
-    const int rows = (B + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * rows, b1 = min(B, b0 + rows);
+    const int rows = (B + ny - 1) / ny, b0 = by * rows, b1 = min(B, b0 + rows);
     float acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
@@ -835,12 +835,13 @@ __global__ __launch_bounds__(256) void k_conv_rep_grad(const float* __restrict__
 
 // G[lo + i] += sum over the workgroups' partial rows (coalesced across i): replaces one atomic per weight and workgroup,
 // which on MI355X serialises in the fabric when 256 workgroups on 8 XCDs hit the same address
-__global__ __launch_bounds__(256) void k_conv_wgrad_reduce(const float* __restrict__ part, int nrows, long n, float* __restrict__ G) {
-    // grid (ceil(n / 256), 8): workgroup (x, y) sums rows y, y + 8, ... of its 256 columns, then 8-way atomics
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void conv_wgrad_reduce(int bx, int by, const float* __restrict__ part, int nrows, long n,
+                                                  float* __restrict__ G) {
+    // (ceil(n / 256), 8) workgroups: workgroup (x, y) sums rows y, y + 8, ... of its 256 columns, then 8-way atomics
+    const long i = (long)bx * 256 + threadIdx.x;
     if (i >= n) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = blockIdx.y;
+    int r = by;
     for (; r + 24 < nrows; r += 32) {
         s0 += part[(size_t)r * n + i];
         s1 += part[(size_t)(r + 8) * n + i];
@@ -850,6 +851,60 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_reduce(const float* __restri
     for (; r < nrows; r += 8) s0 += part[(size_t)r * n + i];
     const float v = (s0 + s1) + (s2 + s3);
     if (v != 0.f) atomicAdd(G + i, v);
+}
+
+// the two independent tails of the convolutional backward pass in ONE launch (as launches of their own they are two
+// dependent ~10 us kernels): workgroups [0, 8 nx) fold the partial rows, the rest reduce the representation layer
+#define CV_REP_CHUNKS 64
+__global__ __launch_bounds__(256) void k_conv_grad_finish(const float* __restrict__ part, int nrows, long n, float* __restrict__ Gcv,
+                                                          const float* __restrict__ dimg, const float* __restrict__ xt,
+                                                          const uint8_t* __restrict__ m8, const hlvae_var* __restrict__ vars, int D,
+                                                          int B, float* __restrict__ G) {
+    const int nx = (int)((n + 255) / 256), nred = 8 * nx;
+    if ((int)blockIdx.x < nred) {
+        conv_wgrad_reduce(blockIdx.x % nx, blockIdx.x / nx, part, nrows, n, Gcv);
+    } else {
+        const int id = blockIdx.x - nred, nbx = (D + 255) / 256;
+        conv_rep_grad(id % nbx, id / nbx, CV_REP_CHUNKS, dimg, xt, m8, vars, D, B, G);
+    }
+}
+
+// out[c][r] = in[r][c] for a [rows][cols] bf16 matrix (row strides ld_in / ld_out), 64 x 64 tiles through LDS: 16-byte
+// loads along the input rows, 16-byte stores along the output rows.  rows, cols need not be multiples of 64; ld_in, ld_out
+// multiples of 8.
+__global__ __launch_bounds__(256) void k_transpose_bf16(const bf16_t* __restrict__ in, int ld_in, bf16_t* __restrict__ out, int ld_out,
+                                                        int rows, int cols) {
+    __shared__ bf16_t tile[64][66];
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = tid + 256 * k, r = idx >> 3, c8 = (idx & 7) * 8;
+        u16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+        // (columns up to ru(cols, 8) <= ld_in are the caller's padding)
+        if (r0 + r < rows && c0 + c8 < cols) v = *reinterpret_cast<const u16x8_t*>(in + (size_t)(r0 + r) * ld_in + c0 + c8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[r][c8 + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = tid + 256 * k, c = idx >> 3, r8 = (idx & 7) * 8;
+        if (c0 + c < cols && r0 + r8 < rows) {
+            u16x8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[r8 + e][c];
+            *reinterpret_cast<u16x8_t*>(out + (size_t)(c0 + c) * ld_out + r0 + r8) = v;
+        }
+    }
+}
+
+int hl_launch_transpose_bf16(const bf16_t* in, int ld_in, bf16_t* out, int ld_out, int rows, int cols, const char* label, hipStream_t s) {
+    HL_REQUIRE(ld_in % 8 == 0 && ld_out % 8 == 0 && rows % 8 == 0, HLVAE_ESHAPE, "transpose: ld_in=%d ld_out=%d rows=%d", ld_in, ld_out, rows);
+    HL_PROF(label, s);
+    k_transpose_bf16<<<dim3((cols + 63) / 64, (rows + 63) / 64), 256, 0, s>>>(in, ld_in, out, ld_out, rows, cols);
+    HL_LAUNCH_CHECK();
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -865,10 +920,10 @@ int hl_conv_pack_weights(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s)
 int hl_launch_conv_enc_fwd(const hlvae_plan* p, const hlvae_ws* ws, const double* data, const double* mask, const float* cvals,
                            const uint8_t* cmask, const int32_t* crows, int B, int Bp, hipStream_t s) {
     HL_PROF("conv_enc_fwd", s);
-    k_conv_enc_fwd<<<B, 256, 0, s>>>(data, mask, cvals, cmask, crows, p->vars_dev, ws->P, p->d, ws->sums, ws->norm, ws->cpack, ws->xn, ws->xnT,
+    k_conv_enc_fwd<<<B, 256, 0, s>>>(data, mask, cvals, cmask, crows, p->vars_dev, ws->P, p->d, ws->sums, ws->norm, ws->cpack, ws->xn,
                                      ws->xt, ws->m8, ws->img, B, Bp);
     HL_LAUNCH_CHECK();
-    return 0;
+    return hl_launch_transpose_bf16(ws->xn, p->d.Xep, ws->xnT, Bp, Bp, CV_FEAT, "xn_transpose", s);
 }
 
 int hl_launch_conv_dec_fwd(const hlvae_plan* p, const hlvae_ws* ws, int B, hipStream_t s) {
@@ -897,7 +952,7 @@ int hl_launch_conv_dec_bwd(const hlvae_plan* p, const hlvae_ws* ws, int B, int B
     }
     {
         HL_PROF("convT1_bwd", s);
-        k_convT1_bwd<<<grid, 256, 0, s>>>(ws->da2, ws->yc, d.NYlp, ws->cpack, ws->dyc, ws->dycT, Bp, ws->cvpart, d.cv_n,
+        k_convT1_bwd<<<grid, 256, 0, s>>>(ws->da2, ws->yc, d.NYlp, ws->cpack, ws->dyc, ws->cvpart, d.cv_n,
                                           d.o_cv_lo, d.o_t1w, d.o_t1b, d.o_by, B);
         HL_LAUNCH_CHECK();
     }
@@ -922,14 +977,12 @@ int hl_launch_conv_enc_bwd(const hlvae_plan* p, const hlvae_ws* ws, int B, hipSt
                                                              ws->dimg, ws->cvpart, d.cv_n, d.o_cv_lo, B);
         HL_LAUNCH_CHECK();
     }
-    {
-        HL_PROF("conv_rep_grad", s);
-        k_conv_rep_grad<<<dim3((CV_D + 255) / 256, 64), 256, 0, s>>>(ws->dimg, ws->xt, ws->m8, p->vars_dev, d.D, B, ws->G);
-        HL_LAUNCH_CHECK();
-    }
-    {   // all three backward kernels have filled their columns of the partial rows: fold them into the gradient arena
-        HL_PROF("conv_wgrad_reduce", s);
-        k_conv_wgrad_reduce<<<dim3((unsigned)((d.cv_n + 255) / 256), 8), 256, 0, s>>>(ws->cvpart, grid, d.cv_n, ws->G + d.o_cv_lo);
+    {   // all three backward kernels have filled their columns of the partial rows: fold them into the gradient arena;
+        // beside it, the representation layer's reduction over the batch
+        HL_PROF("conv_grad_finish", s);
+        const int nx = (int)((d.cv_n + 255) / 256);
+        k_conv_grad_finish<<<8 * nx + ((CV_D + 255) / 256) * CV_REP_CHUNKS, 256, 0, s>>>(ws->cvpart, grid, d.cv_n, ws->G + d.o_cv_lo, ws->dimg,
+                                                                                      ws->xt, ws->m8, p->vars_dev, d.D, B, ws->G);
         HL_LAUNCH_CHECK();
     }
     return 0;

@@ -148,7 +148,11 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_act(const bf16_t* __restric
                                                          float* __restrict__ gbias) {
     using G = GemmNT<64, 64, BK, 2, 2>;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    // 1-D grid, XCD-aware: the row blocks that share one 64-column panel of the weight get consecutive logical ids and
+    // therefore one L2 (2-D round-robin placement: every XCD pulled every panel, PMC 24.6 MB for a 2.7 MB weight)
+    const int tiles_m = M / 64;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid % tiles_m) * 64, n0 = (lid / tiles_m) * 64;
     typename G::Acc acc;
     G::zero(acc);
     G::run(A, lda, Bm, ldb, m0, n0, M, N, 0, K, smem, acc);
@@ -247,7 +251,7 @@ int hl_launch_gemm_act(int mode, const bf16_t* A, int lda, const bf16_t* Bm, int
                        const float* bias, int nvalid, const bf16_t* ref, bf16_t* out, int ldo, bf16_t* outT, int ldT,
                        int B, float* gbias, const char* label, hipStream_t s) {
     HL_REQUIRE(K % 32 == 0 && M % 64 == 0 && N % 64 == 0, HLVAE_ESHAPE, "gemm_act: M=%d N=%d K=%d", M, N, K);
-    dim3 grid(N / 64, M / 64);
+    const int grid = (N / 64) * (M / 64);
     HL_PROF(label, s);
     if (mode == 2) {
         if (K % 64 == 0)

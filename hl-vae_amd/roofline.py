@@ -86,6 +86,11 @@ def algorithmic_work(model, B):
         w["convT1_bwd"] = (B * 5184 * 2 + B * NYl * 2 + 2 * B * NYl * 2, 2 * 2 * B * 324 * 16 * 128)
         w["dfeat"] = ((B * hep + Xe * hep) * 2 + B * Xe * 4, 2 * B * Xe * he)
         w["conv_enc_bwd"] = (B * px * 4 + B * Xe * 4 + B * D * 5, 2 * B * (3 * 324 * 32 * 144 + 2 * px * 16 * 9))
+        w["xn_transpose"] = (2 * B * Xe * 2, 0)
+        w["dyc_transpose"] = (2 * B * NYl * 2, 0)
+        w["conv_grad_finish"] = (512 * 21800 * 4 + B * D * 9, 0)
+        w["adam_dense_early"] = (n_rest * 28 + sh_rest, 0)
+        w["adam_small"] = (model._atomic_region * 32, 0)
         w["conv_pack_weights"] = (32256 * 2 + 15000 * 4, 0)
     return w
 

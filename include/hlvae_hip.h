@@ -304,7 +304,8 @@ int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* 
                   double eps, hlvae_stream s);
 
 /* Per-kernel HIP-event timing (bench.py's roofline leg): while enabled every kernel launch of this library is
- * bracketed by hipEventRecord on its own stream.  hlvae_prof_report synchronises the device and writes one line
+ * bracketed by hipEventRecord on its stream, and the work the library normally forks onto its side streams is queued on
+ * the caller's stream instead, so that every kernel is timed ALONE.  hlvae_prof_report synchronises the device and writes one line
  * "<kernel-label> <launches> <total_ms>" per label into buf.  Do not enable during hipGraph capture. */
 void hlvae_prof_enable(int on);
 int  hlvae_prof_report(char* buf, int buflen);
