@@ -138,6 +138,9 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
                    "atomic region", (long)d.o_cv_lo, (long)d.cv_n);
         for (int i = 0; i < 8; ++i)
             HL_REQUIRE(offs[i] >= d.o_cv_lo, HLVAE_EINVAL, "plan_create: convolution parameter %d below the gradient range", i);
+        // 16-byte stores into the per-workgroup partial rows (csrc/conv.hip)
+        HL_REQUIRE(d.cv_n % 4 == 0 && (d.o_c2w - d.o_cv_lo) % 4 == 0 && (d.o_t1w - d.o_cv_lo) % 4 == 0, HLVAE_EINVAL,
+                   "plan_create: convolution weights must start at multiples of 4 floats inside the gradient range");
     }
     std::vector<int32_t> col2var(d.Xp, -1), stat_var(d.n_stat > 0 ? d.n_stat : 1, 0);
     int x = 0, nstat_seen = 0;

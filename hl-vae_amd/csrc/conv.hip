@@ -377,15 +377,41 @@ __global__ __launch_bounds__(256) void k_convT2_bwd(const bf16_t* __restrict__ d
     for (int s = 0; s < 4; ++s) bw[s] = ld8(cp + CP_T2D + r16 * 128 + s * 32 + q * 8);
     __syncthreads();
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        for (int e = tid; e < CV_D * 5; e += 256) {
-            const int pix = e / 5, c = e - pix * 5;
-            const bf16_t v = dy[(size_t)b * lddy + e];
-            dys[((pix / CV_W + 1) * DY_LD + pix % CV_W + 1) * 8 + c] = v;
+        // every global load of the image in flight before the first LDS store (16-byte pieces: 8 bf16)
+        constexpr int NDY = CV_D * 5 / 8, NA2 = CV_H1 * CV_H1 * 2;
+        static_assert(CV_D * 5 % 8 == 0, "dY row in 16-byte pieces");
+        typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+        u16x8_t dv[(NDY + 255) / 256];
+        uint4 av[(NA2 + 255) / 256];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) bacc[k] += (c == k) ? bf2f(v) : 0.f;
+        for (int k = 0; k < (NDY + 255) / 256; ++k) {
+            const int i8 = tid + 256 * k;
+            dv[k] = i8 < NDY ? reinterpret_cast<const u16x8_t*>(dy + (size_t)b * lddy)[i8] : u16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
-        for (int i = tid; i < CV_H1 * CV_H1 * 2; i += 256)
-            reinterpret_cast<uint4*>(a2s)[i] = reinterpret_cast<const uint4*>(a2 + (size_t)b * CV_H1 * CV_H1 * 16)[i];
+#pragma unroll
+        for (int k = 0; k < (NA2 + 255) / 256; ++k) {
+            const int i = tid + 256 * k;
+            av[k] = i < NA2 ? reinterpret_cast<const uint4*>(a2 + (size_t)b * CV_H1 * CV_H1 * 16)[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < (NDY + 255) / 256; ++k) {
+            const int i8 = tid + 256 * k;
+            if (i8 < NDY) {
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = 8 * i8 + e8, pix = e / 5, c = e - pix * 5;
+                    const bf16_t v = dv[k][e8];
+                    dys[((pix / CV_W + 1) * DY_LD + pix % CV_W + 1) * 8 + c] = v;
+#pragma unroll
+                    for (int kk = 0; kk < 5; ++kk) bacc[kk] += (c == kk) ? bf2f(v) : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < (NA2 + 255) / 256; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NA2) reinterpret_cast<uint4*>(a2s)[i] = av[k];
+        }
         __syncthreads();
         // data gradient: d in[ci][y][x] = sum_{ky,kx,co} dY[co][2y-1+ky][2x-1+kx] w[ci][co][ky][kx]
         for (int mt = wave; mt < 21; mt += 4) {
@@ -459,6 +485,7 @@ __global__ __launch_bounds__(256) void k_convT1_bwd(const bf16_t* __restrict__ d
     __shared__ __attribute__((aligned(16))) bf16_t das[A1_LD * A1_LD * 16];
     __shared__ __attribute__((aligned(16))) bf16_t ycs[82 * 32];                  // NHWC, row 81 = zeros
     __shared__ __attribute__((aligned(16))) bf16_t outs[CV_FEAT];
+    __shared__ __attribute__((aligned(16))) float wstage[32 * 16 * 16];         // d W_t1 on its way out
     __shared__ float bred[16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, r16 = lane & 15;
     for (int i = tid; i < A1_LD * A1_LD * 16 / 2; i += 256) reinterpret_cast<uint32_t*>(das)[i] = 0u;
@@ -474,12 +501,39 @@ __global__ __launch_bounds__(256) void k_convT1_bwd(const bf16_t* __restrict__ d
     for (int k = 0; k < (CV_FEAT + 255) / 256; ++k) yacc[k] = 0.f;
     __syncthreads();
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        for (int i = tid; i < CV_H1 * CV_H1 * 2; i += 256) {
-            const int pix = i >> 1, h = i & 1;
-            *reinterpret_cast<uint4*>(das + ((pix / CV_H1 + 1) * A1_LD + pix % CV_H1 + 1) * 16 + h * 8) =
-                *reinterpret_cast<const uint4*>(da2 + ((size_t)b * CV_H1 * CV_H1 + pix) * 16 + h * 8);
+        // every global load of the image in flight before the first LDS store
+        constexpr int NDA = CV_H1 * CV_H1 * 2, NYC = CV_FEAT / 8;
+        static_assert(CV_FEAT % 8 == 0, "yc row in 16-byte pieces");
+        typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+        uint4 dv[(NDA + 255) / 256];
+        u16x8_t yv[(NYC + 255) / 256];
+#pragma unroll
+        for (int k = 0; k < (NDA + 255) / 256; ++k) {
+            const int i = tid + 256 * k;
+            dv[k] = i < NDA ? *reinterpret_cast<const uint4*>(da2 + ((size_t)b * CV_H1 * CV_H1 + (i >> 1)) * 16 + (i & 1) * 8)
+                            : make_uint4(0u, 0u, 0u, 0u);
         }
-        for (int e = tid; e < CV_FEAT; e += 256) ycs[(e % 81) * 32 + e / 81] = yc[(size_t)b * ldy + e];
+#pragma unroll
+        for (int k = 0; k < (NYC + 255) / 256; ++k) {
+            const int i8 = tid + 256 * k;
+            yv[k] = i8 < NYC ? reinterpret_cast<const u16x8_t*>(yc + (size_t)b * ldy)[i8] : u16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int k = 0; k < (NDA + 255) / 256; ++k) {
+            const int i = tid + 256 * k, pix = i >> 1, h = i & 1;
+            if (i < NDA) *reinterpret_cast<uint4*>(das + ((pix / CV_H1 + 1) * A1_LD + pix % CV_H1 + 1) * 16 + h * 8) = dv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < (NYC + 255) / 256; ++k) {
+            const int i8 = tid + 256 * k;
+            if (i8 < NYC) {
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = 8 * i8 + e8;
+                    ycs[(e % 81) * 32 + e / 81] = yv[k][e8];
+                }
+            }
+        }
         __syncthreads();
         for (int pix = tid >> 4; pix < CV_H1 * CV_H1; pix += 16)
             bacc += bf2f(das[((pix / CV_H1 + 1) * A1_LD + pix % CV_H1 + 1) * 16 + r16]);          // channel = tid & 15
@@ -540,16 +594,26 @@ __global__ __launch_bounds__(256) void k_convT1_bwd(const bf16_t* __restrict__ d
 #pragma unroll
     for (int k = 0; k < (CV_FEAT + 255) / 256; ++k)
         if (tid + 256 * k < CV_FEAT) gby[tid + 256 * k] = yacc[k];
+    // d W_t1 in arena order [ci][co][tap] through LDS (the accumulator layout would be 32 scattered 4-byte stores per lane)
+    __syncthreads();
+    float* stage = wstage;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int tap = wave + 4 * j;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gw[((i * 16 + 4 * q + r) * 16 + r16) * 16 + tap] = wacc[i][j][r];
+            for (int r = 0; r < 4; ++r) stage[((i * 16 + 4 * q + r) * 16 + r16) * 16 + tap] = wacc[i][j][r];
         }
-    atomicAdd(&bred[r16], bacc);
+    {   // d b_t1[co = r16]: the four lane groups of a wave by shuffle, the four waves by LDS atomics
+        float v = bacc;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) atomicAdd(&bred[r16], v);
+    }
     __syncthreads();
+    for (int i4 = tid; i4 < 32 * 16 * 16 / 4; i4 += 256)
+        reinterpret_cast<float4*>(gw)[i4] = reinterpret_cast<const float4*>(stage)[i4];
     if (tid < 16) gb[tid] = bred[tid];
 }
 
@@ -607,14 +671,38 @@ __global__ __launch_bounds__(512) void k_conv_enc_bwd(const float* __restrict__ 
         const int b = (it * gridDim.x + blockIdx.x) * ngroups + gi;
         const bool live = b < B;
         const int bb = live ? b : 0;
-        for (int dd = tid; dd < CV_D; dd += 256) {
-            sm.img[(dd / CV_W + 1) * IMG_LD + dd % CV_W + 1] = img_in[(size_t)bb * CV_D + dd];
+        // all global loads of the image in flight before the first LDS store (a load-then-store loop waits for every load
+        // in turn: 15 k -> 9 k clocks for this stage, clock64() phase timing)
+        static_assert(CV_D % 4 == 0 && CV_FEAT % 4 == 0, "float4 staging");
+        float4 iv[(CV_D / 4 + 255) / 256], fv[(CV_FEAT / 4 + 255) / 256];
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < (CV_D / 4 + 255) / 256; ++k) {
+            const int i4 = tid + 256 * k;
+            iv[k] = i4 < CV_D / 4 ? reinterpret_cast<const float4*>(img_in + (size_t)bb * CV_D)[i4] : z4;
+        }
+#pragma unroll
+        for (int k = 0; k < (CV_FEAT / 4 + 255) / 256; ++k) {
+            const int i4 = tid + 256 * k;
+            fv[k] = (live && i4 < CV_FEAT / 4) ? reinterpret_cast<const float4*>(dfeat + (size_t)bb * ldf)[i4] : z4;
         }
         if (it > 0) {                                   // a1 / dz2 were reused as scratch: restore their zero halos
             for (int i = tid; i < A1_LD * A1_LD * CV_C1 / 2; i += 256) reinterpret_cast<uint32_t*>(sm.a1)[i] = 0u;
             for (int i = tid; i < A1_LD * A1_LD * CV_C2 / 2; i += 256) reinterpret_cast<uint32_t*>(sm.dz2)[i] = 0u;
         }
-        for (int i = tid; i < CV_FEAT; i += 256) sm.dfeat[i] = live ? dfeat[(size_t)bb * ldf + i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < (CV_D / 4 + 255) / 256; ++k) {
+            const int dd = 4 * (tid + 256 * k);
+            if (dd < CV_D) {                             // CV_W % 4 == 0: the four pixels are in one image row
+                float* dst = sm.img + (dd / CV_W + 1) * IMG_LD + dd % CV_W + 1;
+                dst[0] = iv[k].x; dst[1] = iv[k].y; dst[2] = iv[k].z; dst[3] = iv[k].w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < (CV_FEAT / 4 + 255) / 256; ++k) {
+            const int i4 = tid + 256 * k;
+            if (i4 < CV_FEAT / 4) reinterpret_cast<float4*>(sm.dfeat)[i4] = fv[k];
+        }
         __syncthreads();
         conv1_pool(sm.img, sm.w1s, sm.a1, sm.am1, tid);
         __syncthreads();
@@ -774,24 +862,40 @@ __global__ __launch_bounds__(512) void k_conv_enc_bwd(const float* __restrict__ 
         v += __shfl_xor(v, 32, 64);
         if (q == 0) atomicAdd(&sm.red2[i * 16 + r16], v);          // the four waves own different pooling windows
     }
+    // d conv1.{weight, bias}: the 4 lane groups of a wave share co = tid & 15 -> shuffles, then one LDS slot per wave
+    // (256 x 10 same-address LDS float atomics cost ~6 k clocks here)
+    float* w1red = sm.dfeat;                                         // [4 waves][160], free at this point
 #pragma unroll
-    for (int t = 0; t < 10; ++t) atomicAdd(&sm.red[(tid & 15) * 10 + t], w1acc[t]);
+    for (int t = 0; t < 10; ++t) {
+        float v = w1acc[t];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) w1red[wave * 160 + r16 * 10 + t] = v;
+    }
+    // d conv2.weight in arena order [co][ci][tap] through LDS: the accumulator layout would be 24 scattered 4-byte stores per lane
+    float* stage = reinterpret_cast<float*>(sm.a1);                 // 4608 floats <= a1 + dz2
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int tap = wave + 4 * j;
+            if (tap < 9)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stage[((i * 16 + 4 * q + r) * 16 + r16) * 9 + tap] = wacc[i][j][r];
+        }
+    __syncthreads();
+    if (tid < 160) sm.red[tid] = w1red[tid] + w1red[160 + tid] + w1red[320 + tid] + w1red[480 + tid];
     __syncthreads();
     for (int phase = 0; phase < ngroups; ++phase) {
         if (gi == phase) {
             const bool add = phase == 1;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int tap = wave + 4 * j;
-                    if (tap < 9)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float* dst = G + d.o_c2w + ((i * 16 + 4 * q + r) * 16 + r16) * 9 + tap;
-                            *dst = add ? *dst + wacc[i][j][r] : wacc[i][j][r];
-                        }
-                }
+            static_assert((CV_C2 * CV_C1 * 9) % 4 == 0, "float4 rows");
+            float4* dst4 = reinterpret_cast<float4*>(G + d.o_c2w);       // (o_c2w and the partial rows are 16-byte aligned: checked on the host)
+            for (int i4 = tid; i4 < CV_C2 * CV_C1 * 9 / 4; i4 += 256) {
+                float4 v = reinterpret_cast<const float4*>(stage)[i4];
+                if (add) { const float4 o = dst4[i4]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                dst4[i4] = v;
+            }
             if (tid < 160) {
                 float* dst = G + (tid % 10 < 9 ? d.o_c1w + (tid / 10) * 9 + tid % 10 : d.o_c1b + tid / 10);
                 *dst = add ? *dst + sm.red[tid] : sm.red[tid];
