@@ -89,13 +89,19 @@ __device__ __forceinline__ void conv1_pool(const float* img, const float* w1s, b
 #pragma unroll
     for (int t = 0; t < 9; ++t) w[t] = w1s[co * 9 + t];
     const float bias = w1s[144 + co];
+    // 324 windows / 16 per pass = 21 passes (the last one partial); unrolled by 3 so that the LDS reads of the next windows
+    // are in flight under the 36 FMAs of the current one (two waves per SIMD do not hide them: 13.5 k clocks before)
+    static_assert(IMG_LD % 2 == 0, "8-byte patch reads");
+#pragma unroll 3
     for (int pp = tid >> 4; pp < CV_H1 * CV_H1; pp += 16) {
         const int py = pp / CV_H1, px = pp % CV_H1;
         float pch[4][4];                                       // the 4 x 4 input patch of one pooling window (16-lane broadcast)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pch[i][j] = img[(2 * py + i) * IMG_LD + 2 * px + j];
+        for (int i = 0; i < 4; ++i) {
+            const float2 lo = *reinterpret_cast<const float2*>(img + (2 * py + i) * IMG_LD + 2 * px);
+            const float2 hi = *reinterpret_cast<const float2*>(img + (2 * py + i) * IMG_LD + 2 * px + 2);
+            pch[i][0] = lo.x; pch[i][1] = lo.y; pch[i][2] = hi.x; pch[i][3] = hi.y;
+        }
         float best = 0.f;
         int sel = 4;
 #pragma unroll
@@ -194,8 +200,12 @@ __device__ __forceinline__ float conv_input_value_compact(const hlvae_var& var, 
     if (var.kind == HLVAE_CAT || var.kind == HLVAE_ORDINAL) {
         float rep = P[var.rb_off];
         const int cls = (int)cv;
+        if (var.kind == HLVAE_CAT) {                      // one-hot: exactly one weight (none for an all-zero row, cls = -1)
+            if (cls >= 0 && cls < var.ncls) rep += P[var.r_off + cls];
+            return rep;
+        }
         for (int k = 0; k < var.ncls; ++k)
-            if (var.kind == HLVAE_CAT ? k == cls : k <= cls) rep += P[var.r_off + k];
+            if (k <= cls) rep += P[var.r_off + k];
         return rep;
     }
     double x = (double)cv;
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(256) void k_conv_enc_fwd(
     const float* __restrict__ P, hlvae_dims d, const double* __restrict__ sums, float* __restrict__ norm,
     const bf16_t* __restrict__ cp, bf16_t* __restrict__ xn, float* __restrict__ xt,
     uint8_t* __restrict__ m8, float* __restrict__ img_out, int B, int Bp) {
-    __shared__ float img[IMG_LD * IMG_LD];
+    __shared__ __attribute__((aligned(16))) float img[IMG_LD * IMG_LD];
     __shared__ __attribute__((aligned(16))) bf16_t a1[A1_LD * A1_LD * CV_C1];
     __shared__ float w1s[160];
     __shared__ __attribute__((aligned(16))) bf16_t feat[CV_FEAT];
@@ -218,7 +228,12 @@ __global__ __launch_bounds__(256) void k_conv_enc_fwd(
     for (int i = tid; i < A1_LD * A1_LD * CV_C1 / 2; i += 256) reinterpret_cast<uint32_t*>(a1)[i] = 0u;
     if (tid < 160) w1s[tid] = tid < 144 ? P[d.o_c1w + tid] : P[d.o_c1b + tid - 144];
     __syncthreads();
-    for (int dd = tid; dd < CV_D; dd += 256) {
+    // fully unrolled: the dependent chains (variable record -> value -> representation weights) of the six variables a
+    // thread owns overlap instead of running one after the other
+#pragma unroll
+    for (int kk = 0; kk < (CV_D + 255) / 256; ++kk) {
+        const int dd = tid + 256 * kk;
+        if (dd >= CV_D) break;
         const hlvae_var var = vars[dd];
         bool ob;
         float tv, rep;
@@ -277,11 +292,27 @@ __global__ __launch_bounds__(256) void k_convT1_fwd(const bf16_t* __restrict__ y
     __shared__ __attribute__((aligned(16))) bf16_t xin[T1_LD * T1_LD * 32];
     __shared__ __attribute__((aligned(16))) bf16_t outs[CV_H1 * CV_H1 * 16];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, r16 = lane & 15;
+    // the image's global loads are issued first and land while the tile is being zeroed (16-byte pieces: 8 bf16)
+    constexpr int NYC = CV_FEAT / 8;
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+    u16x8_t yv[(NYC + 255) / 256];
+#pragma unroll
+    for (int k = 0; k < (NYC + 255) / 256; ++k) {
+        const int i8 = tid + 256 * k;
+        yv[k] = i8 < NYC ? reinterpret_cast<const u16x8_t*>(yc + (size_t)b * ldy)[i8] : u16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     for (int i = tid; i < T1_LD * T1_LD * 32 / 2; i += 256) reinterpret_cast<uint32_t*>(xin)[i] = 0u;
     __syncthreads();
-    for (int e = tid; e < CV_FEAT; e += 256) {                                // y.view(-1, 32, 9, 9)  (HLVAE.py:339)
-        const int ci = e / 81, pix = e % 81;
-        xin[((pix / 9 + 1) * T1_LD + pix % 9 + 1) * 32 + ci] = yc[(size_t)b * ldy + e];
+#pragma unroll
+    for (int k = 0; k < (NYC + 255) / 256; ++k) {                             // y.view(-1, 32, 9, 9)  (HLVAE.py:339)
+        const int i8 = tid + 256 * k;
+        if (i8 < NYC) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int e = 8 * i8 + e8, ci = e / 81, pix = e % 81;
+                xin[((pix / 9 + 1) * T1_LD + pix % 9 + 1) * 32 + ci] = yv[k][e8];
+            }
+        }
     }
     __syncthreads();
     const float bv = bias[r16];
@@ -314,12 +345,19 @@ __global__ __launch_bounds__(256) void k_convT2_fwd(const bf16_t* __restrict__ a
     __shared__ __attribute__((aligned(16))) bf16_t ain[A1_LD * A1_LD * 16];
     __shared__ __attribute__((aligned(16))) float ys[CV_D * 5];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, r16 = lane & 15;
+    constexpr int NA2 = CV_H1 * CV_H1 * 2;                                    // 16 channels = two 16-byte pieces per pixel
+    uint4 av[(NA2 + 255) / 256];                                              // in flight while the tile is being zeroed
+#pragma unroll
+    for (int k = 0; k < (NA2 + 255) / 256; ++k) {
+        const int i = tid + 256 * k;
+        av[k] = i < NA2 ? reinterpret_cast<const uint4*>(a2 + (size_t)b * CV_H1 * CV_H1 * 16)[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
     for (int i = tid; i < A1_LD * A1_LD * 16 / 2; i += 256) reinterpret_cast<uint32_t*>(ain)[i] = 0u;
     __syncthreads();
-    for (int i = tid; i < CV_H1 * CV_H1 * 2; i += 256) {                      // 16 channels = two 16-byte pieces per pixel
-        const int pix = i >> 1, h = i & 1;
-        *reinterpret_cast<uint4*>(ain + ((pix / CV_H1 + 1) * A1_LD + pix % CV_H1 + 1) * 16 + h * 8) =
-            *reinterpret_cast<const uint4*>(a2 + ((size_t)b * CV_H1 * CV_H1 + pix) * 16 + h * 8);
+#pragma unroll
+    for (int k = 0; k < (NA2 + 255) / 256; ++k) {
+        const int i = tid + 256 * k, pix = i >> 1, h = i & 1;
+        if (i < NA2) *reinterpret_cast<uint4*>(ain + ((pix / CV_H1 + 1) * A1_LD + pix % CV_H1 + 1) * 16 + h * 8) = av[k];
     }
     __syncthreads();
     const float bv = r16 < 5 ? bias[r16] : 0.f;
