@@ -76,18 +76,34 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     const int m0 = blockIdx.x * MID_ROWS;
 
     // ---- stage 1: T tile = relu(sum_s slab + b1), rows >= B and columns >= h_e are zero
-    for (int idx = tid; idx < MID_ROWS * (hep / 4); idx += MID_THREADS) {
+    // (two elements per pass: the slab loads of both -- 2 x S float4 -- are requested before the first is consumed)
+    for (int idx0 = tid; idx0 < MID_ROWS * (hep / 4); idx0 += 2 * MID_THREADS) {
+      float4 v2[2];
+      {
+        const size_t ss = (size_t)Bp * hep;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = idx0 + e * MID_THREADS;
+            const int r = idx / (hep / 4), c4 = (idx % (hep / 4)) * 4;
+            v2[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < MID_ROWS * (hep / 4) && m0 + r < B) {
+                const float* src = slab + (size_t)(m0 + r) * hep + c4;
+#pragma unroll 8
+                for (int s = 0; s < S; ++s) {
+                    const float4 x = *reinterpret_cast<const float4*>(src + s * ss);
+                    v2[e].x += x.x; v2[e].y += x.y; v2[e].z += x.z; v2[e].w += x.w;
+                }
+            }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int idx = idx0 + e * MID_THREADS;
+        if (idx >= MID_ROWS * (hep / 4)) break;
         const int r = idx / (hep / 4), c4 = (idx % (hep / 4)) * 4;
         const int gr = m0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = v2[e];
         if (gr < B) {
-            const float* src = slab + (size_t)gr * hep + c4;
-            const size_t ss = (size_t)Bp * hep;
-#pragma unroll 8
-            for (int s = 0; s < S; ++s) {
-                const float4 x = *reinterpret_cast<const float4*>(src + s * ss);
-                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-            }
             float* vv = &v.x;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -100,6 +116,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
         *reinterpret_cast<uint2*>(Ta + r * lda + c4) = pk;
         *reinterpret_cast<uint2*>(t_out + (size_t)gr * hep + c4) = pk;
+      }
     }
     __syncthreads();
     // transposed copy of T (operand of the [Wmu;Wlv] weight gradient): lane -> (column, 4 rows) = 8 bytes
@@ -220,19 +237,38 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     const int m0 = blockIdx.x * MID_ROWS;
 
     // ---- stage 1: dU tile = sum_s slab * relu'(U); d bd column sums
-    for (int idx = tid; idx < MID_ROWS * (hdp / 4); idx += MID_THREADS) {
+    // (two elements per pass: the slab loads of both -- 2 x S float4 -- are requested before the first is consumed)
+    for (int idx0 = tid; idx0 < MID_ROWS * (hdp / 4); idx0 += 2 * MID_THREADS) {
+      float4 v2[2];
+      uint2 rf2[2];
+      {
+        const size_t ss = (size_t)Bp * hdp;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = idx0 + e * MID_THREADS;
+            const int r = idx / (hdp / 4), c4 = (idx % (hdp / 4)) * 4;
+            v2[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rf2[e] = make_uint2(0u, 0u);
+            if (idx < MID_ROWS * (hdp / 4) && m0 + r < B) {
+                const float* src = slab + (size_t)(m0 + r) * hdp + c4;
+                rf2[e] = *reinterpret_cast<const uint2*>(u + (size_t)(m0 + r) * hdp + c4);
+#pragma unroll 8
+                for (int s = 0; s < S; ++s) {
+                    const float4 x = *reinterpret_cast<const float4*>(src + s * ss);
+                    v2[e].x += x.x; v2[e].y += x.y; v2[e].z += x.z; v2[e].w += x.w;
+                }
+            }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int idx = idx0 + e * MID_THREADS;
+        if (idx >= MID_ROWS * (hdp / 4)) break;
         const int r = idx / (hdp / 4), c4 = (idx % (hdp / 4)) * 4;
         const int gr = m0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = v2[e];
         if (gr < B) {
-            const float* src = slab + (size_t)gr * hdp + c4;
-            const size_t ss = (size_t)Bp * hdp;
-#pragma unroll 8
-            for (int s = 0; s < S; ++s) {
-                const float4 x = *reinterpret_cast<const float4*>(src + s * ss);
-                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-            }
-            const uint2 rf = *reinterpret_cast<const uint2*>(u + (size_t)gr * hdp + c4);
+            const uint2 rf = rf2[e];
             const bf16_t rr[4] = {(bf16_t)(rf.x & 0xffff), (bf16_t)(rf.x >> 16), (bf16_t)(rf.y & 0xffff), (bf16_t)(rf.y >> 16)};
             float* vv = &v.x;
 #pragma unroll
@@ -242,6 +278,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
         pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
         pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
         *reinterpret_cast<uint2*>(Ua + r * lda + c4) = pk;
+      }
     }
     __syncthreads();
     for (int idx = tid; idx < hdp * (MID_ROWS / 4); idx += MID_THREADS) {     // transposed copy + column sums
@@ -256,6 +293,19 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
         s += __shfl_xor(s, 1, 64);
         s += __shfl_xor(s, 2, 64);
         if ((idx & 3) == 0 && c < h_d) atomicAdd(gbd + c, s);
+    }
+    // the ReLU gates (2-byte loads at row stride: four dependent-latency loads per lane and n-tile) are requested for the
+    // wave's first TG n-tiles HERE, three stages ahead of their use (clock64() phase timing: this stage was 12.6 k of the kernel's 28 k clocks)
+    constexpr int TG = 4;
+    bf16_t tg[TG][4];
+#pragma unroll
+    for (int i = 0; i < TG; ++i) {
+        const int col = (wave + i * (MID_THREADS / 64)) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + (lane >> 4) * 4 + r;
+            tg[i][r] = (col < h_e && row < B) ? t[(size_t)row * hep + col] : (bf16_t)0;
+        }
     }
     // ---- stage 2: dz = dU * Wd   (N = LP: n-tile = wave % (LP/16), K split over the remaining waves)
     {
@@ -307,7 +357,8 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
         }
     }
     // ---- stage 4: dT = dml * Wml * relu'(T)   (K = 2*LP, N = hep); only the transposed copy is needed
-    for (int nt = wave; nt < hep / 16; nt += MID_THREADS / 64) {
+    int it4 = 0;
+    for (int nt = wave; nt < hep / 16; nt += MID_THREADS / 64, ++it4) {
         const f32x4_t acc = mfma_lds_x_global(Ma, 2 * LP + 8, wmlT, 2 * LP, nt * 16, 0, 2 * LP, lane);
         const int col = nt * 16 + (lane & 15);
         float o4[4];
@@ -315,7 +366,14 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + (lane >> 4) * 4 + r;
-            const bool on = col < h_e && row < B && bf2f(t[(size_t)row * hep + col]) > 0.f;
+            bf16_t tv = 0;
+            if (it4 < TG) {
+#pragma unroll
+                for (int i = 0; i < TG; ++i) tv = it4 == i ? tg[i][r] : tv;        // (register select: no indexed array)
+            } else if (col < h_e && row < B) {
+                tv = t[(size_t)row * hep + col];
+            }
+            const bool on = col < h_e && row < B && bf2f(tv) > 0.f;
             o4[r] = on ? acc[r] : 0.f;
             s += o4[r];
         }
