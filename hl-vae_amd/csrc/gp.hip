@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     double* __restrict__ iB_out, double* __restrict__ K0_out, double* __restrict__ V_out, double* __restrict__ v_out,
     double* __restrict__ part, float* __restrict__ g_mu, float* __restrict__ g_lv) {
     __shared__ double xs[GP_TMAX * GP_XS];
-    __shared__ double ib[GP_TMAX * GP_TS];
+    __shared__ double ib[GP_TMAX * GP_TS], kzs[GP_TMAX * GP_TS];
     extern __shared__ __attribute__((aligned(16))) char dsm_fwd[];
     double* ks = reinterpret_cast<double*>(dsm_fwd);      // the subject's rows of K0xz, [T][M] (sized for the actual T, M:
                                                           // 19 KB at T = 20, M = 120 -> five workgroups per CU instead of three)
@@ -278,9 +278,18 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         const int t = e / Q, r = rows[t];
         xs[t * GP_XS + e % Q] = r >= 0 ? x[(size_t)r * Q + e % Q] : 0.0;
     }
-    for (int e = tid; e < T * M; e += 256) {              // stage Ks (coalesced along M), zero rows for padding
-        const int t = e / M, r = rows[t];
-        ks[e] = r >= 0 ? Kxz[((size_t)l * Bn + r) * M + e % M] : 0.0;
+    for (int e0 = tid; e0 < T * M; e0 += 4 * 256) {       // stage Ks (coalesced along M), zero rows for padding;
+        double tk[4];                                     // four loads in flight per lane
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + 256 * u, T * M - 1), t = e / M, r = rows[t];
+            tk[u] = Kxz[((size_t)l * Bn + (r >= 0 ? r : 0)) * M + e % M];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < T * M) ks[e] = rows[e / M] >= 0 ? tk[u] : 0.0;
+        }
     }
     if (tid < T) rs[tid] = rows[tid] >= 0 ? resid[(size_t)l * Bn + rows[tid]] : 0.0;
     GpHyp h0, h1;
@@ -288,20 +297,32 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     gp_hoist(k1, hyp, n_slots, L, l, h1);
     __syncthreads();
     const double nz = noise[l];
+    // covariance entries: the kernels are symmetric, so the T (T + 1) / 2 = 210 pairs i <= j are evaluated once, one per
+    // thread, into LDS (in the 2 x 2 register blocking of the Gauss-Jordan below 16 threads would evaluate 4 pairs each)
+    for (int p = tid; p < T * (T + 1) / 2; p += 256) {
+        int i = 0, rem = p;
+        while (rem >= T - i) { rem -= T - i; ++i; }
+        const int j = i + rem;
+        double kb = i == j ? 1.0 : 0.0, kz = 0.0;                 // padded rows: identity block
+        if (rows[i] >= 0 && rows[j] >= 0) {
+            kb = gp_value(k1, h1, xs + i * GP_XS, xs + j * GP_XS) + (i == j ? nz : 0.0);       // elbo_functions.py:249-250
+            kz = gp_value(k0, h0, xs + i * GP_XS, xs + j * GP_XS);                              // :248
+        }
+        ib[i * GP_TS + j] = kb; ib[j * GP_TS + i] = kb;
+        kzs[i * GP_TS + j] = kz; kzs[j * GP_TS + i] = kz;
+    }
+    __syncthreads();
     double a[2][2], k0v[2][2];
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int i = ti + 16 * ii, j = tj + 16 * jj;
-            double kb = i == j ? 1.0 : 0.0, kz = 0.0;             // padded rows: identity block
-            if (i < T && j < T && rows[i] >= 0 && rows[j] >= 0) {
-                kb = gp_value(k1, h1, xs + i * GP_XS, xs + j * GP_XS) + (i == j ? nz : 0.0);       // elbo_functions.py:249-250
-                kz = gp_value(k0, h0, xs + i * GP_XS, xs + j * GP_XS);                              // :248
-            }
-            a[ii][jj] = kb;
-            k0v[ii][jj] = kz;
+            const bool in = i < T && j < T;
+            a[ii][jj] = in ? ib[i * GP_TS + j] : (i == j ? 1.0 : 0.0);
+            k0v[ii][jj] = in ? kzs[i * GP_TS + j] : 0.0;
         }
+    __syncthreads();                                              // ib is reused for the inverse below
     gj_pivots<2, 0>(a, gjrow, gjcol, pv, T, ti, tj);
     gj_pivots<2, 1>(a, gjrow, gjcol, pv, T, ti, tj);
     // mask the inverse to the valid block, write iB and K0_st
@@ -383,11 +404,26 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
         const int t = e / Q, r = rows[t];
         xs[t * GP_XS + e % Q] = r >= 0 ? x[(size_t)r * Q + e % Q] : 0.0;
     }
-    for (int e = tid; e < T * M; e += 256) {
-        const int t = e / M, m = e - t * M, r = rows[t];
-        const size_t o = ((size_t)l * Bn + (r >= 0 ? r : 0)) * M + m;
-        vs[t * MS + m] = r >= 0 ? V[o] : 0.0;
-        ys[t * MS + m] = r >= 0 ? Y[o] : 0.0;
+    for (int e0 = tid; e0 < T * M; e0 += 4 * 256) {         // four elements per pass: 8 global loads in flight per lane
+        double tv[4], ty[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            const int t = min(e, T * M - 1) / M, m = min(e, T * M - 1) - t * M, r = rows[t];
+            const size_t o = ((size_t)l * Bn + (r >= 0 ? r : 0)) * M + m;
+            tv[u] = V[o];
+            ty[u] = Y[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < T * M) {
+                const int t = e / M, m = e - t * M;
+                const bool ok = rows[t] >= 0;
+                vs[t * MS + m] = ok ? tv[u] : 0.0;
+                ys[t * MS + m] = ok ? ty[u] : 0.0;
+            }
+        }
     }
     if (tid < T) {
         const int r = rows[tid];
@@ -434,23 +470,33 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
     GpAcc a0, a1;
     gp_acc_zero(a0);
     gp_acc_zero(a1);
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int i = ti + 16 * ii, j = tj + 16 * jj;
-            if (i < T && j < T && rows[i] >= 0 && rows[j] >= 0) {
-                double acc = 0.0;                                                 // (iB w iB)[i][j]
-                for (int k = 0; k < T; ++k) acc += w[i * GP_TS + k] * ib[k * GP_TS + j];
-                double yv = 0.0;                                                  // (Y V^T)[i][j]
-                for (int m = 0; m < M; ++m) yv += ys[i * MS + m] * vs[j * MS + m];
-                const double ibv = ib[i * GP_TS + j];
-                const double g1 = 0.5 * c * (ibv - vv[i] * vv[j] - acc + yv);     // dL / dB_st
-                const double g0 = 0.5 * c * ibv;                                  // dL / dK0_st
-                gp_pair_grad(k1, h1, xs + i * GP_XS, xs + j * GP_XS, g1, a1);
-                gp_pair_grad(k0, h0, xs + i * GP_XS, xs + j * GP_XS, g0, a0);
+    // the T x T pairs dealt round-robin to the 256 threads (T = 20: at most 2 pairs per thread; the 16 x 16 + 2 x 2 blocking
+    // of the stages above would give 16 threads 4 pairs each and this stage was 70 % of the kernel: 73 k clocks)
+    // Both gradient matrices are symmetric (iB, iB (E + K0) iB and Y V^T = V (iK - Q) V^T are) and so are the kernels: only
+    // the pairs i <= j are evaluated, off-diagonal ones with weight 2 -- T (T + 1) / 2 = 210 pairs, one per thread.
+    for (int p = tid; p < T * (T + 1) / 2; p += 256) {
+        int i = 0, rem = p;
+        while (rem >= T - i) { rem -= T - i; ++i; }
+        const int j = i + rem;
+        const double sym = i == j ? 1.0 : 2.0;
+        if (rows[i] >= 0 && rows[j] >= 0) {
+            double acc = 0.0;                                                 // (iB w iB)[i][j]
+            for (int k = 0; k < T; ++k) acc += w[i * GP_TS + k] * ib[k * GP_TS + j];
+            double y0 = 0.0, y1 = 0.0;                                        // (Y V^T)[i][j], two chains
+            int m = 0;
+            for (; m + 1 < M; m += 2) {
+                y0 += ys[i * MS + m] * vs[j * MS + m];
+                y1 += ys[i * MS + m + 1] * vs[j * MS + m + 1];
             }
+            if (m < M) y0 += ys[i * MS + m] * vs[j * MS + m];
+            const double yv = y0 + y1;
+            const double ibv = ib[i * GP_TS + j];
+            const double g1 = sym * 0.5 * c * (ibv - vv[i] * vv[j] - acc + yv);     // dL / dB_st
+            const double g0 = sym * 0.5 * c * ibv;                                  // dL / dK0_st
+            gp_pair_grad(k1, h1, xs + i * GP_XS, xs + j * GP_XS, g1, a1);
+            gp_pair_grad(k0, h0, xs + i * GP_XS, xs + j * GP_XS, g0, a0);
         }
+    }
     const double* dpos_l = hyp + (size_t)n_slots * L + l;
     gp_flush(k1, a1, dpos_l, L, gacc, tid & 63);
     gp_flush(k0, a0, dpos_l, L, gacc, tid & 63);
