@@ -299,8 +299,11 @@ class GPPriorHIP:
         self.prm.grad = self._gtheta[:n * L].view(n, L)
         self.zt_list.grad = self._gtheta[n * L:].view(L, M, Q)
         self._hyp = torch.zeros(3, n, L, **f64)
-        self._KH = torch.zeros(2 * L, M, M, **f64)                 # [K0zz + jitter | H]: inverted in one batched launch
-        self.H = self._KH[L:]
+        # one buffer [K0zz + jitter | H | iK]: [K0zz | H] is inverted in one batched launch when no factorisation is cached,
+        # and [H | iK] is where the end-of-step inversion writes its two results directly (no copies)
+        self._big = torch.zeros(3 * L, M, M, **f64)
+        self._KH = self._big[:2 * L]
+        self.H = self._big[L:2 * L]
         self.m = torch.randn(L, M, 1, generator=g, dtype=torch.float64).to(dev)
         Hh = (torch.randn(L, M, M, generator=g, dtype=torch.float64) / 10).to(dev)
         self.H.copy_(Hh @ Hh.transpose(-1, -2) + 1e-6 * torch.eye(M, **f64))
@@ -308,10 +311,11 @@ class GPPriorHIP:
         self.fail = torch.zeros(1, dtype=torch.int32, device=dev)
         # factorisation cache: the end of a step inverts [iH_new | K0zz of the UPDATED hyper-parameters] in one launch, so
         # the next step starts with iK, iH and both log-determinants in hand (one batched inversion per step, not two)
-        self._KH2, self._inv2 = torch.zeros(2 * L, M, M, **f64), torch.zeros(2 * L, M, M, **f64)
-        self._ld2 = torch.zeros(2 * L, **f64)
-        self._iK, self._iHb = torch.zeros(L, M, M, **f64), torch.zeros(L, M, M, **f64)
-        self._ldK, self._ldH = torch.zeros(L, **f64), torch.zeros(L, **f64)
+        self._KH2 = torch.zeros(2 * L, M, M, **f64)               # input of that inversion: [iH (updated in place) | K0zz]
+        self._HiK = self._big[L:]                                 # its output: [H_new | iK]
+        self._ld2 = torch.zeros(2 * L, **f64)                     # [log det iH_new | log det K0zz]
+        self._iK, self._iHb = self._big[2 * L:], self._KH2[:L]
+        self._ldK, self._ldH = self._ld2[L:], torch.zeros(L, **f64)
         self._fact_key = None
         self._xchg = torch.zeros(L * M * M + 2 * L * M + 1, **f64)    # [W | P1 | u | bound]: the one DP exchange buffer
         self.last_kld = self._xchg[-1:]
@@ -506,16 +510,14 @@ class GPPriorHIP:
         iH = self._iH if self._iH is not None else self.chol_inv(self.H.contiguous())[0]
         self._iH = None
         gH = self._grad_H
-        torch.add(iH, gH + gH.transpose(-1, -2), alpha=self.ng_lr, out=self._KH2[:L])           # iH_new
+        rhs = torch.baddbmm(self._grad_m, gH, self.m, alpha=-2.0)            # grad_m - 2 grad_H m
+        tmp = torch.baddbmm(rhs, iH, self.m, beta=-self.ng_lr)               # iH m - lr rhs  (the OLD iH: before its update)
+        torch.add(iH, gH + gH.transpose(-1, -2), alpha=self.ng_lr, out=self._iHb)               # iH_new, in place in _KH2[:L]
         self._transform()
         self.kernel_matrix(self.k0, self.zt_list, self.zt_list, jitter=self.eps, out=self._KH2[L:])
-        self.chol_inv(self._KH2, out=(self._inv2, self._ld2))
-        H_new = self._inv2[:L]
-        rhs = torch.baddbmm(self._grad_m, gH, self.m, alpha=-2.0)            # grad_m - 2 grad_H m
-        # in place: a captured HIP graph keeps reading the same buffers
-        self.m.copy_(H_new @ torch.baddbmm(rhs, iH, self.m, beta=-self.ng_lr))
-        self.H.copy_(H_new)
-        self._KH[:L].copy_(self._KH2[L:])                                    # K0zz that belongs to the cached inverse
-        self._iHb.copy_(self._KH2[:L]); self._iK.copy_(self._inv2[L:])
-        self._ldK.copy_(self._ld2[L:]); torch.neg(self._ld2[:L], out=self._ldH)    # log det H_new = - log det iH_new
+        # [iH_new | K0zz] -> [H_new | iK] straight into their homes (self.H, self._iK) and [. | log det K0zz] into _ldK:
+        # everything stays in place, a captured HIP graph keeps reading the same buffers
+        self.chol_inv(self._KH2, out=(self._HiK, self._ld2))
+        torch.bmm(self.H, tmp, out=self.m)
+        torch.neg(self._ld2[:L], out=self._ldH)                              # log det H_new = - log det iH_new
         self._fact_key = (self._theta._version, self._KH._version)
