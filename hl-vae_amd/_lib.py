@@ -96,6 +96,8 @@ _SIGS = {
     "hlvae_gp_param_grad": (C.c_int, [C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp,
                                       C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "hlvae_gp_transform": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "hlvae_gp_bmm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
+    "hlvae_gp_rsym": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_bound": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                  C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "hlvae_gp_adam": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),

@@ -593,6 +593,124 @@ __global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const 
 //        + rep { 1/2 [ sum(iK o H) + sum(m o iKm) + sum(ldK) - sum(ldH) ] + konst }
 // The first bracket is linear in per-subject sums: under data parallelism every rank passes its LOCAL part / W / lv and
 // rep = 1 / world for the replicated terms; the sum of the ranks' results is the bound of the global batch.
+// ------------------------------------------------------------------------------------------------------------
+// batched N x N fp64 products of the natural-gradient algebra (N = inducing points <= 128):
+//     C[l] = alpha A[l] B[l] + beta D[l]                 (row-major, dense; D may be null or alias C)
+// on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: A/B one double per lane, A[row l&15][k l>>4], B[k l>>4][col l&15];
+// C/D col = lane&15, row = (lane>>4) + 4 reg).  One workgroup = one 64 x 64 tile of one matrix; its 64 x K and K x 64
+// operand panels (K = N <= 128) sit whole in LDS, each wave owns 16 rows x 64 columns.  The library's batched GEMM takes
+// 11-32 us for these 120 x 120 x 120 x 32 products (3.5 TFLOP/s); seven of them per step were 18 % of the GP step.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) double f64x4_t;
+#define GP_BMM_T 64
+__global__ __launch_bounds__(256) void k_gp_bmm(const double* __restrict__ A, const double* __restrict__ B, const double* D,
+                                                double* C, int N, double alpha, double beta) {
+    extern __shared__ __attribute__((aligned(16))) char dsm_bmm[];
+    const int Kp = (N + 3) & ~3;                                  // k padded to the MFMA step with zeros
+    const int lda = Kp + 1, ldb = GP_BMM_T + 1;
+    double* As = reinterpret_cast<double*>(dsm_bmm);              // [64][Kp + 1]
+    double* Bs = As + GP_BMM_T * lda;                             // [Kp][65]
+    const int l = blockIdx.z, m0 = blockIdx.y * GP_BMM_T, n0 = blockIdx.x * GP_BMM_T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* Al = A + (size_t)l * N * N;
+    const double* Bl = B + (size_t)l * N * N;
+    // panels -> LDS, zero outside the matrix.  N even (rows 16-byte aligned): 16-byte loads, a whole panel (<= 16 per lane)
+    // requested before the first LDS store; otherwise 8-byte loads in batches of 8
+    if ((N & 1) == 0) {
+        typedef __attribute__((ext_vector_type(2))) double f64x2_t;
+        const int K2 = Kp >> 1, T2 = GP_BMM_T >> 1;
+        constexpr int NB = (GP_BMM_T * (GP_MMAX / 2) + 255) / 256;              // 16
+        f64x2_t t[NB], tb[NB];                                                  // both panels in flight: one memory latency
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = tid + 256 * u, r = e / K2, k = 2 * (e - r * K2);
+            t[u] = (e < GP_BMM_T * K2 && m0 + r < N && k < N) ? *reinterpret_cast<const f64x2_t*>(Al + (size_t)(m0 + r) * N + k)
+                                                              : f64x2_t{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = tid + 256 * u, k = e / T2, c = 2 * (e - k * T2);
+            tb[u] = (e < Kp * T2 && k < N && n0 + c < N) ? *reinterpret_cast<const f64x2_t*>(Bl + (size_t)k * N + n0 + c)
+                                                         : f64x2_t{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = tid + 256 * u, r = e / K2, k = 2 * (e - r * K2);
+            if (e < GP_BMM_T * K2) { As[r * lda + k] = t[u][0]; As[r * lda + k + 1] = t[u][1]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = tid + 256 * u, k = e / T2, c = 2 * (e - k * T2);
+            if (e < Kp * T2) { Bs[k * ldb + c] = tb[u][0]; Bs[k * ldb + c + 1] = tb[u][1]; }
+        }
+    } else {
+    for (int e0 = tid; e0 < GP_BMM_T * Kp; e0 += 8 * 256) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, r = e / Kp, k = e - r * Kp;
+            t[u] = (e < GP_BMM_T * Kp && m0 + r < N && k < N) ? Al[(size_t)(m0 + r) * N + k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, r = e / Kp, k = e - r * Kp;
+            if (e < GP_BMM_T * Kp) As[r * lda + k] = t[u];
+        }
+    }
+    for (int e0 = tid; e0 < Kp * GP_BMM_T; e0 += 8 * 256) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, k = e / GP_BMM_T, c = e - k * GP_BMM_T;
+            t[u] = (e < Kp * GP_BMM_T && k < N && n0 + c < N) ? Bl[(size_t)k * N + n0 + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, k = e / GP_BMM_T, c = e - k * GP_BMM_T;
+            if (e < Kp * GP_BMM_T) Bs[k * ldb + c] = t[u];
+        }
+    }
+    }
+    __syncthreads();
+    f64x4_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const double* ap = As + (wave * 16 + (lane & 15)) * lda + (lane >> 4);
+    const double* bp = Bs + (lane >> 4) * ldb + (lane & 15);
+#pragma unroll 2
+    for (int k = 0; k < Kp; k += 4) {
+        const double a = ap[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * ldb + 16 * j], acc[j], 0, 0, 0);
+    }
+    const double* Dl = D != nullptr ? D + (size_t)l * N * N : nullptr;
+    double* Cl = C + (size_t)l * N * N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wave * 16 + (lane >> 4) + 4 * r, col = n0 + 16 * j + (lane & 15);
+            if (row < N && col < N) {
+                double v = alpha * acc[j][r];
+                if (Dl != nullptr) v += beta * Dl[(size_t)row * N + col];
+                Cl[(size_t)row * N + col] = v;
+            }
+        }
+}
+
+// R + R^T of the inducing-point covariance gradient in one pass (elbo_functions.py of this package, kl_and_grads):
+//     out = c (u m^T + m u^T - W + X + X^T) + H + m m^T           per latent, N x N, u and m are N-vectors
+__global__ __launch_bounds__(256) void k_gp_rsym(const double* __restrict__ u, const double* __restrict__ m, const double* __restrict__ W,
+                                                 const double* __restrict__ X, const double* __restrict__ H, double c, int N, int n_total,
+                                                 double* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_total) return;
+    const int l = e / (N * N), ij = e - l * N * N, i = ij / N, j = ij - i * N;
+    const double ui = u[l * N + i], uj = u[l * N + j], mi = m[l * N + i], mj = m[l * N + j];
+    const size_t o = (size_t)l * N * N;
+    out[e] = c * (ui * mj + mi * uj - W[e] + X[e] + X[o + (size_t)j * N + i]) + H[e] + mi * mj;
+}
+
 __global__ __launch_bounds__(256) void k_gp_bound(const double* __restrict__ part, int n_part, const double* __restrict__ W,
                                                   const double* __restrict__ iK, const double* __restrict__ Qm,
                                                   const double* __restrict__ H, int LMM, const double* __restrict__ m,
@@ -749,6 +867,33 @@ int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots
     dim3 grid((n2 + 63) / 64, (n1 + GP_PG_ROWS - 1) / GP_PG_ROWS, L);
     k_gp_param_grad<<<grid, 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2, both_args, G, gprm,
                                                      gx2);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_bmm(const double* A, const double* B, const double* D, double* C, int N, int batch, double alpha, double beta,
+                 hlvae_stream s) {
+    HL_REQUIRE(A && B && C && N >= 1 && N <= GP_MMAX && batch >= 1, HLVAE_EINVAL, "gp_bmm: N=%d batch=%d", N, batch);
+    const int Kp = (N + 3) & ~3;
+    const size_t smem = ((size_t)GP_BMM_T * (Kp + 1) + (size_t)Kp * (GP_BMM_T + 1)) * sizeof(double);
+    static size_t attr_max = 0;
+    if (smem > attr_max) {
+        HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_bmm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_max = smem;
+    }
+    const int t = (N + GP_BMM_T - 1) / GP_BMM_T;
+    HL_PROF("gp_bmm", (hipStream_t)s);
+    k_gp_bmm<<<dim3(t, t, batch), 256, smem, (hipStream_t)s>>>(A, B, D, C, N, alpha, beta);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_rsym(const double* u, const double* m, const double* W, const double* X, const double* H, double c, int N, int batch,
+                  double* out, hlvae_stream s) {
+    HL_REQUIRE(u && m && W && X && H && out && N >= 1 && batch >= 1, HLVAE_EINVAL, "gp_rsym: null argument");
+    const int n = batch * N * N;
+    HL_PROF("gp_rsym", (hipStream_t)s);
+    k_gp_rsym<<<(n + 255) / 256, 256, 0, (hipStream_t)s>>>(u, m, W, X, H, c, N, n, out);
     HL_LAUNCH_CHECK();
     return 0;
 }

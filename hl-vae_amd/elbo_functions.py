@@ -367,6 +367,17 @@ class GPPriorHIP:
         return self._groups.get(train_x, build)
 
     # ---- the KL bound, its gradients, the natural-gradient terms ------------------------------------------------
+    def bmm(self, A, B, D=None, alpha=1.0, beta=1.0):
+        """alpha A @ B + beta D for dense [L, M, M] fp64 operands, on the fp64 matrix cores (csrc/gp.hip: k_gp_bmm)"""
+        L, M = self.L, self.M
+        for t in (A, B) + (() if D is None else (D,)):
+            if t.shape != (L, M, M) or not t.is_contiguous() or t.dtype != torch.float64:
+                raise ValueError("GPPriorHIP.bmm: dense contiguous [L, M, M] fp64 operands")
+        out = torch.empty(L, M, M, dtype=torch.float64, device=A.device)
+        _lib.check(_lib.load().hlvae_gp_bmm(_lib.ptr(A), _lib.ptr(B), _lib.ptr(D), _lib.ptr(out), M, L, _C.c_double(alpha),
+                                            _C.c_double(beta), self._stream()), "gp_bmm")
+        return out
+
     def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None):
         """mu, log_v: fp32 [B, L] (the workspace tensors of the VAE); returns fp32 [B, L] gradients.  Hyper-parameter
         and inducing-point gradients are left in ``prm.grad`` / ``zt_list.grad``."""
@@ -408,8 +419,8 @@ class GPPriorHIP:
         torch.bmm(KxzT, V, out=W)                                            # sum_s Ks^T iB Ks   [L,M,M]
         torch.bmm(V.transpose(1, 2), mu64.t().unsqueeze(2), out=P1)          # natural-gradient term (elbo_functions.py:262-266)
         torch.bmm(KxzT, v.unsqueeze(2), out=u)
-        HiK = self.H @ iK
-        Qm = iK @ HiK                                                        # iK H iK
+        HiK = self.bmm(self.H, iK)
+        Qm = self.bmm(iK, HiK)                                               # iK H iK
         world = 1 if self.dp is None else self.dp.world
         _lib.check(lib.hlvae_gp_bound(_lib.ptr(part), S, _lib.ptr(W), _lib.ptr(iK), _lib.ptr(Qm), _lib.ptr(self.H), _lib.ptr(self.m),
                                       _lib.ptr(iKm), _lib.ptr(ldK), _lib.ptr(ldH), _lib.ptr(lv32), B, L, M, _C.c_double(c),
@@ -418,20 +429,20 @@ class GPPriorHIP:
         if self.dp is not None:
             self.dp.allreduce_(self._xchg)                                   # W, P1, u, bound of the GLOBAL batch
         # natural-gradient terms (elbo_functions.py:279-283)
-        Bm = torch.baddbmm(iK, iK @ W, iK)                                   # iK W iK + iK
+        Bm = self.bmm(self.bmm(iK, W), iK, D=iK)                             # iK W iK + iK
         self._grad_m = torch.baddbmm(Bm @ self.m, iK, P1, alpha=-1.0)        # -(iK P1) + Bm m
         self._grad_H = 0.5 * (Bm - iH)
         # analytic gradients w.r.t. kernel matrices, chained into hyper-parameters / inducing points by the HIP kernels
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
         Y = V @ (iK - Qm)                                                    # [L,B,M]  (local rows)
         G_Kxz = torch.baddbmm(Y, v.unsqueeze(2), iKm.transpose(1, 2), beta=-c, alpha=c)   # c [ v (iK m)^T + V (Q - iK) ]
-        HiKW = HiK @ W
-        mT = self.m.transpose(1, 2)
+        HiKW = self.bmm(HiK, W)
         # R + R^T with R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T): K0zz's gradient is needed symmetrised.
         # It is built from global sums only, i.e. replicated: each rank contributes 1 / world of it
-        um = u @ mT
-        Rs = c * (um + um.transpose(1, 2) - W + HiKW + HiKW.transpose(1, 2)) + torch.baddbmm(self.H, self.m, mT)
-        G_Kzz_s = torch.baddbmm(iK, iK @ Rs, iK, alpha=-1.0)                 # (G + G^T),  G = -(iK R iK) + iK / 2
+        Rs = torch.empty_like(W)
+        _lib.check(lib.hlvae_gp_rsym(_lib.ptr(u), _lib.ptr(self.m), _lib.ptr(W), _lib.ptr(HiKW), _lib.ptr(self.H), _C.c_double(c), M, L,
+                                     _lib.ptr(Rs), st), "gp_rsym")
+        G_Kzz_s = self.bmm(self.bmm(iK, Rs), iK, D=iK, alpha=-1.0)           # (G + G^T),  G = -(iK R iK) + iK / 2
         if world > 1:
             G_Kzz_s = G_Kzz_s / world
         _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),

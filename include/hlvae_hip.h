@@ -298,6 +298,14 @@ int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots
 int hlvae_gp_bound(const double* part, int S, const double* W, const double* iK, const double* Qm, const double* H,
                    const double* m, const double* iKm, const double* ldK, const double* ldH, const float* lv, int B, int L,
                    int M, double c, double n_total, double rep, double* out, hlvae_stream s);
+/* batched dense N x N fp64 products  C[l] = alpha A[l] B[l] + beta D[l]  (row-major [batch][N][N], N <= 128, D may be NULL or
+ * alias C): the M x M algebra of the bound and of the natural gradient (elbo_functions.py:268-283) on the fp64 matrix cores. */
+int hlvae_gp_bmm(const double* A, const double* B, const double* D, double* C, int N, int batch, double alpha, double beta,
+                 hlvae_stream s);
+/* out[l] = c (u m^T + m u^T - W + X + X^T) + H + m m^T  per latent (u, m: [batch][N]; W, X, H, out: [batch][N][N]): the
+ * symmetrised gradient term of K0zz in one pass */
+int hlvae_gp_rsym(const double* u, const double* m, const double* W, const double* X, const double* H, double c, int N, int batch,
+                  double* out, hlvae_stream s);
 /* torch.optim.Adam step (HLVAE_main.py:277-278) on a flat fp64 arena (hyper-parameters + inducing points, n <= ~1e5);
  * step: device int64[2] = {completed steps, 0}, advanced by the kernel; the consumed gradients are zeroed. */
 int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,

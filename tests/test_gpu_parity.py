@@ -603,6 +603,30 @@ def test_gp_prior_hip_against_autograd_statement(varying_T):
     assert rel_err(hip.zt_list, ref.zt_list) < 1e-9
 
 
+@pytest.mark.parametrize("N,batch", [(120, 32), (128, 3), (37, 5), (66, 2)])
+def test_gp_bmm_and_rsym_against_torch(N, batch):
+    """csrc/gp.hip k_gp_bmm (fp64 MFMA, C = alpha A B + beta D with D aliasing nothing / an operand) and k_gp_rsym against
+    torch.float64 on the same operands: 1e-13 (different summation order only)."""
+    import ctypes as C
+    from hlvae_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(N)
+    A, B, D = (torch.randn(batch, N, N, generator=g, dtype=torch.float64).to(dev) for _ in range(3))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.full_like(A, float("nan"))
+    _lib.check(lib.hlvae_gp_bmm(_lib.ptr(A), _lib.ptr(B), None, _lib.ptr(out), N, batch, C.c_double(1.0), C.c_double(0.0), st), "bmm")
+    assert rel_err(out, A @ B) < 1e-13
+    _lib.check(lib.hlvae_gp_bmm(_lib.ptr(A), _lib.ptr(B), _lib.ptr(D), _lib.ptr(out), N, batch, C.c_double(-0.5), C.c_double(2.0), st), "bmm")
+    assert rel_err(out, -0.5 * (A @ B) + 2.0 * D) < 1e-13
+    u, m = (torch.randn(batch, N, 1, generator=g, dtype=torch.float64).to(dev) for _ in range(2))
+    _lib.check(lib.hlvae_gp_rsym(_lib.ptr(u), _lib.ptr(m), _lib.ptr(A), _lib.ptr(B), _lib.ptr(D), C.c_double(1.7), N, batch,
+                                 _lib.ptr(out), st), "rsym")
+    mT = m.transpose(1, 2)
+    ref = 1.7 * (u @ mT + m @ u.transpose(1, 2) - A + B + B.transpose(1, 2)) + D + m @ mT
+    assert rel_err(out, ref) < 1e-13
+
+
 def test_gp_prior_config5_size_against_autograd_statement():
     """BASELINE configs[4] (GP variant) at its full size: 32 latent GPs, 120 inducing points, 6 covariates, a 1024-row batch
     of 51 whole subjects x 20 rows + 4 rows of a 52nd -- bound, gradients w.r.t. mu / log-variance, natural-gradient
