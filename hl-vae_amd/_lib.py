@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p

@@ -588,11 +588,6 @@ __global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const 
     }
 }
 
-// every scalar of the bound in one launch (elbo_functions.py:268-285):
-//   out += c/2 [ sum(part) - sum(W o iK) + sum(Qm o W) - sum(log_var) ]
-//        + rep { 1/2 [ sum(iK o H) + sum(m o iKm) + sum(ldK) - sum(ldH) ] + konst }
-// The first bracket is linear in per-subject sums: under data parallelism every rank passes its LOCAL part / W / lv and
-// rep = 1 / world for the replicated terms; the sum of the ranks' results is the bound of the global batch.
 // ------------------------------------------------------------------------------------------------------------
 // batched N x N fp64 products of the natural-gradient algebra (N = inducing points <= 128):
 //     C[l] = alpha A[l] B[l] + beta D[l]                 (row-major, dense; D may be null or alias C)
@@ -711,6 +706,11 @@ __global__ __launch_bounds__(256) void k_gp_rsym(const double* __restrict__ u, c
     out[e] = c * (ui * mj + mi * uj - W[e] + X[e] + X[o + (size_t)j * N + i]) + H[e] + mi * mj;
 }
 
+// every scalar of the bound in one launch (elbo_functions.py:268-285):
+//   out += c/2 [ sum(part) - sum(W o iK) + sum(Qm o W) - sum(log_var) ]
+//        + rep { 1/2 [ sum(iK o H) + sum(m o iKm) + sum(ldK) - sum(ldH) ] + konst }
+// The first bracket is linear in per-subject sums: under data parallelism every rank passes its LOCAL part / W / lv and
+// rep = 1 / world for the replicated terms; the sum of the ranks' results is the bound of the global batch.
 __global__ __launch_bounds__(256) void k_gp_bound(const double* __restrict__ part, int n_part, const double* __restrict__ W,
                                                   const double* __restrict__ iK, const double* __restrict__ Qm,
                                                   const double* __restrict__ H, int LMM, const double* __restrict__ m,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 18
+#define HLVAE_ABI_VERSION 19
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
