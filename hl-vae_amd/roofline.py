@@ -15,6 +15,7 @@ from . import _lib
 
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_FP64_PEAK_TFLOPS = 78.6
 
 
 def _ru(v, m):
@@ -36,6 +37,9 @@ def gp_algorithmic_work(gp, B, S, T):
     w["gp_param_grad"] = ((L * B * M + L * M * M + 3 * L * M * Q + B * Q) * f // 2, 0)
     w["gp_bound"] = ((4 * L * M * M + 2 * L * M + S * L * 4) * f + B * L * 4, 0)
     w["gp_adam"] = ((n * L + L * M * Q) * 7 * f, 0)
+    # fp64 matrix-core products of the M x M algebra: priced against the dense fp64 MFMA peak (MI355X: 78.6 TFLOP/s)
+    w["gp_bmm"] = (4 * L * M * M * f, 2 * L * M * M * M, MFMA_FP64_PEAK_TFLOPS)
+    w["gp_rsym"] = (4 * L * M * M * f, 0)
     return w
 
 
@@ -134,22 +138,23 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None):
         cnt, tot = int(cnt), float(tot)
         per_step_launches = cnt / n
         avg_us = 1e3 * tot / cnt
-        by, fl = work.get(name, (0, 0))
+        wk = work.get(name, (0, 0))
+        by, fl = wk[0], wk[1]
         table[name] = dict(launches_per_step=per_step_launches, avg_us=avg_us, us_per_step=avg_us * per_step_launches,
-                           bytes=by, flops=fl)
+                           bytes=by, flops=fl, peak_tflops=wk[2] if len(wk) > 2 else MFMA_BF16_PEAK_TFLOPS)
     if not table:
         return None
     dom = max(table, key=lambda k: table[k]["us_per_step"])
     t = table[dom]
     t_hbm = t["bytes"] / (HBM_PEAK_GBS * 1e9)
-    t_mfma = t["flops"] / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+    pk = t["peak_tflops"]
+    t_mfma = t["flops"] / (pk * 1e12)
     if t_hbm >= t_mfma:
         ach = t["bytes"] / (t["avg_us"] * 1e-6) / 1e9
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
     else:
         ach = t["flops"] / (t["avg_us"] * 1e-6) / 1e12
-        roof = dict(bound="mfma", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_BF16_PEAK_TFLOPS,
-                    traffic=None)
+        roof = dict(bound="mfma", achieved=ach, peak=pk, unit="TFLOP/s", frac=ach / pk, traffic=None)
     roof["kernel"] = dom
     roof["avg_us"] = t["avg_us"]
     roof["algorithmic_per_launch"] = t["bytes"] if roof["bound"] == "hbm" else t["flops"]
