@@ -54,7 +54,9 @@ __device__ __forceinline__ f32x4_t mfma_lds_x_global(const bf16_t* As, int lda, 
 // ------------------------------------------------------------------------------------------------------------
 // forward.  LDS: tile_a bf16 [16][KA+8] (T, later z), ctile fp32 [16][NC+1] (accumulator staging)
 // ------------------------------------------------------------------------------------------------------------
-template <int LP>
+// MR = batch rows per workgroup (16, or 8 for small batches: twice the workgroups, half the slab bytes per CU; the MFMA tiles
+// stay 16 rows tall, rows MR..15 of the LDS tiles are zero and their results are dropped)
+template <int LP, int MR>
 __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     const float* __restrict__ slab, int S, int Bp, int hep, int h_e, const float* __restrict__ b1,
     bf16_t* __restrict__ t_out, bf16_t* __restrict__ tT_out,
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     float* Cp = reinterpret_cast<float*>(smem + MID_ROWS * lda * 2 + MID_ROWS * cmax * 4 + MID_ROWS * (LP + 8) * 2);   // [KS][16][2LP+1]
     __shared__ double klred[MID_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * MID_ROWS;
+    const int m0 = blockIdx.x * MR;
 
     // ---- stage 1: T tile = relu(sum_s slab + b1), rows >= B and columns >= h_e are zero
     // (two elements per pass: the slab loads of both -- 2 x S float4 -- are requested before the first is consumed)
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
             const int idx = idx0 + e * MID_THREADS;
             const int r = idx / (hep / 4), c4 = (idx % (hep / 4)) * 4;
             v2[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < MID_ROWS * (hep / 4) && m0 + r < B) {
+            if (idx < MID_ROWS * (hep / 4) && r < MR && m0 + r < B) {
                 const float* src = slab + (size_t)(m0 + r) * hep + c4;
 #pragma unroll 8
                 for (int s = 0; s < S; ++s) {
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         const int r = idx / (hep / 4), c4 = (idx % (hep / 4)) * 4;
         const int gr = m0 + r;
         float4 v = v2[e];
-        if (gr < B) {
+        if (r < MR && gr < B) {
             float* vv = &v.x;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -115,13 +117,13 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
         pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
         *reinterpret_cast<uint2*>(Ta + r * lda + c4) = pk;
-        *reinterpret_cast<uint2*>(t_out + (size_t)gr * hep + c4) = pk;
+        if (r < MR) *reinterpret_cast<uint2*>(t_out + (size_t)gr * hep + c4) = pk;
       }
     }
     __syncthreads();
     // transposed copy of T (operand of the [Wmu;Wlv] weight gradient): lane -> (column, 4 rows) = 8 bytes
-    for (int idx = tid; idx < hep * (MID_ROWS / 4); idx += MID_THREADS) {
-        const int c = idx / (MID_ROWS / 4), r4 = (idx % (MID_ROWS / 4)) * 4;
+    for (int idx = tid; idx < hep * (MR / 4); idx += MID_THREADS) {
+        const int c = idx / (MR / 4), r4 = (idx % (MR / 4)) * 4;
         uint2 pk;
         pk.x = (uint32_t)Ta[(r4 + 0) * lda + c] | ((uint32_t)Ta[(r4 + 1) * lda + c] << 16);
         pk.y = (uint32_t)Ta[(r4 + 2) * lda + c] | ((uint32_t)Ta[(r4 + 3) * lda + c] << 16);
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         const int r = idx / LP, j = idx % LP;
         const int gr = m0 + r;
         float zv = 0.f;
-        if (gr < B && j < L) {
+        if (r < MR && gr < B && j < L) {
             const size_t o = (size_t)gr * L + j;
             const float m = Ct[r * cmax + j] + bmu[j];
             float l = Ct[r * cmax + LP + j] + blv[j];
@@ -173,8 +175,10 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         }
         const bf16_t zbv = f2bf(zv);
         Za[r * (LP + 8) + j] = zbv;
-        zb[(size_t)gr * LP + j] = zbv;
-        zbT[(size_t)j * Bp + gr] = zbv;
+        if (r < MR) {
+            zb[(size_t)gr * LP + j] = zbv;
+            zbT[(size_t)j * Bp + gr] = zbv;
+        }
     }
     klacc = wave_sum_d(klacc);
     if (lane == 0) klred[wave] = klacc;
@@ -182,7 +186,9 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     if (tid == 0 && klpart != nullptr) {
         double k = 0.0;
         for (int w = 0; w < MID_THREADS / 64; ++w) k += klred[w];
-        klpart[blockIdx.x] = k;
+        // one partial per 8 rows (k_elbo_finalize sums Bp / 8 of them)
+        if (MR == 8) klpart[blockIdx.x] = k;
+        else { klpart[2 * blockIdx.x] = k; klpart[2 * blockIdx.x + 1] = 0.0; }
     }
     // ---- stage 4: U = relu(z Wd^T + bd)   (K = LP, N = hdp)
     for (int nt = wave; nt < hdp / 16; nt += MID_THREADS / 64) {
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         for (int r = 0; r < 4; ++r) {
             const int row = (lane >> 4) * 4 + r;
             float x = acc[r] + bias;
-            x = (x > 0.f && col < h_d && m0 + row < B) ? x : 0.f;
+            x = (x > 0.f && col < h_d && row < MR && m0 + row < B) ? x : 0.f;
             o4[r] = x;
             Ct[row * cmax + col] = x;
         }
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         uint2 pk;
         pk.x = (uint32_t)f2bf(o4[0]) | ((uint32_t)f2bf(o4[1]) << 16);
         pk.y = (uint32_t)f2bf(o4[2]) | ((uint32_t)f2bf(o4[3]) << 16);
-        *reinterpret_cast<uint2*>(uT_out + (size_t)col * Bp + m0 + (lane >> 4) * 4) = pk;
+        if ((lane >> 4) * 4 < MR) *reinterpret_cast<uint2*>(uT_out + (size_t)col * Bp + m0 + (lane >> 4) * 4) = pk;
     }
     __syncthreads();
-    for (int idx = tid; idx < MID_ROWS * (hdp / 4); idx += MID_THREADS) {
+    for (int idx = tid; idx < MR * (hdp / 4); idx += MID_THREADS) {
         const int r = idx / (hdp / 4), c4 = (idx % (hdp / 4)) * 4;
         uint2 pk;
         pk.x = (uint32_t)f2bf(Ct[r * cmax + c4]) | ((uint32_t)f2bf(Ct[r * cmax + c4 + 1]) << 16);
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
 // ------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------
-template <int LP>
+template <int LP, int MR>
 __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     const float* __restrict__ slab, int S, int Bp, int hdp, int h_d, const bf16_t* __restrict__ u,
     bf16_t* __restrict__ duT_out, float* __restrict__ gbd,
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     bf16_t* Ma = reinterpret_cast<bf16_t*>(smem + MID_ROWS * lda * 2 + KSZ * MID_ROWS * (LP + 1) * 4);   // dml [16][2LP+8]
     float* Gs = reinterpret_cast<float*>(smem + MID_ROWS * lda * 2 + KSZ * MID_ROWS * (LP + 1) * 4 + MID_ROWS * (2 * LP + 8) * 2);  // fp32 [16][2LP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * MID_ROWS;
+    const int m0 = blockIdx.x * MR;
 
     // ---- stage 1: dU tile = sum_s slab * relu'(U); d bd column sums
     // (two elements per pass: the slab loads of both -- 2 x S float4 -- are requested before the first is consumed)
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
             const int r = idx / (hdp / 4), c4 = (idx % (hdp / 4)) * 4;
             v2[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             rf2[e] = make_uint2(0u, 0u);
-            if (idx < MID_ROWS * (hdp / 4) && m0 + r < B) {
+            if (idx < MID_ROWS * (hdp / 4) && r < MR && m0 + r < B) {
                 const float* src = slab + (size_t)(m0 + r) * hdp + c4;
                 rf2[e] = *reinterpret_cast<const uint2*>(u + (size_t)(m0 + r) * hdp + c4);
 #pragma unroll 8
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
         const int r = idx / (hdp / 4), c4 = (idx % (hdp / 4)) * 4;
         const int gr = m0 + r;
         float4 v = v2[e];
-        if (gr < B) {
+        if (r < MR && gr < B) {
             const uint2 rf = rf2[e];
             const bf16_t rr[4] = {(bf16_t)(rf.x & 0xffff), (bf16_t)(rf.x >> 16), (bf16_t)(rf.y & 0xffff), (bf16_t)(rf.y >> 16)};
             float* vv = &v.x;
@@ -281,18 +287,18 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
       }
     }
     __syncthreads();
-    for (int idx = tid; idx < hdp * (MID_ROWS / 4); idx += MID_THREADS) {     // transposed copy + column sums
-        const int c = idx / (MID_ROWS / 4), r4 = (idx % (MID_ROWS / 4)) * 4;
+    for (int idx = tid; idx < hdp * (MR / 4); idx += MID_THREADS) {           // transposed copy + column sums
+        const int c = idx / (MR / 4), r4 = (idx % (MR / 4)) * 4;
         const bf16_t a0 = Ua[(r4 + 0) * lda + c], a1 = Ua[(r4 + 1) * lda + c], a2 = Ua[(r4 + 2) * lda + c],
                      a3 = Ua[(r4 + 3) * lda + c];
         uint2 pk;
         pk.x = (uint32_t)a0 | ((uint32_t)a1 << 16);
         pk.y = (uint32_t)a2 | ((uint32_t)a3 << 16);
         *reinterpret_cast<uint2*>(duT_out + (size_t)c * Bp + m0 + r4) = pk;
-        float s = bf2f(a0) + bf2f(a1) + bf2f(a2) + bf2f(a3);                 // 4 lanes of a column are adjacent
+        float s = bf2f(a0) + bf2f(a1) + bf2f(a2) + bf2f(a3);                 // the MR / 4 lanes of a column are adjacent
         s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        if ((idx & 3) == 0 && c < h_d) atomicAdd(gbd + c, s);
+        if (MR == 16) s += __shfl_xor(s, 2, 64);
+        if ((idx % (MR / 4)) == 0 && c < h_d) atomicAdd(gbd + c, s);
     }
     // the ReLU gates (2-byte loads at row stride: four dependent-latency loads per lane and n-tile) are requested for the
     // wave's first TG n-tiles HERE, three stages ahead of their use (clock64() phase timing: this stage was 12.6 k of the kernel's 28 k clocks)
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + (lane >> 4) * 4 + r;
-            tg[i][r] = (col < h_e && row < B) ? t[(size_t)row * hep + col] : (bf16_t)0;
+            tg[i][r] = (col < h_e && row < B && (lane >> 4) * 4 < MR) ? t[(size_t)row * hep + col] : (bf16_t)0;
         }
     }
     // ---- stage 2: dz = dU * Wd   (N = LP: n-tile = wave % (LP/16), K split over the remaining waves)
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
 #pragma unroll
         for (int q = 0; q < KSZ; ++q) d += Cz[(q * MID_ROWS + r) * (LP + 1) + j];
         float dm = 0.f, dl = 0.f;
-        if (gr < B && j < L) {
+        if (r < MR && gr < B && j < L) {
             const size_t o = (size_t)gr * L + j;
             const float l = lv[o];
             const float el = __expf(l);
@@ -341,8 +347,10 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
         const bf16_t bm = f2bf(dm), bl = f2bf(dl);
         Ma[r * (2 * LP + 8) + j] = bm;
         Ma[r * (2 * LP + 8) + LP + j] = bl;
-        dmlT_out[(size_t)j * Bp + gr] = bm;
-        dmlT_out[(size_t)(LP + j) * Bp + gr] = bl;
+        if (r < MR) {
+            dmlT_out[(size_t)j * Bp + gr] = bm;
+            dmlT_out[(size_t)(LP + j) * Bp + gr] = bl;
+        }
         Gs[r * 2 * LP + j] = dm;
         Gs[r * 2 * LP + LP + j] = dl;
     }
@@ -370,18 +378,18 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
             if (it4 < TG) {
 #pragma unroll
                 for (int i = 0; i < TG; ++i) tv = it4 == i ? tg[i][r] : tv;        // (register select: no indexed array)
-            } else if (col < h_e && row < B) {
+            } else if (col < h_e && row < B && (lane >> 4) * 4 < MR) {
                 tv = t[(size_t)row * hep + col];
             }
-            const bool on = col < h_e && row < B && bf2f(tv) > 0.f;
+            const bool on = col < h_e && row < B && (lane >> 4) * 4 < MR && bf2f(tv) > 0.f;
             o4[r] = on ? acc[r] : 0.f;
             s += o4[r];
         }
         uint2 pk;
         pk.x = (uint32_t)f2bf(o4[0]) | ((uint32_t)f2bf(o4[1]) << 16);
         pk.y = (uint32_t)f2bf(o4[2]) | ((uint32_t)f2bf(o4[3]) << 16);
-        *reinterpret_cast<uint2*>(dtT_out + (size_t)col * Bp + m0 + (lane >> 4) * 4) = pk;
-        if (dt_out != nullptr) {                                 // row-major copy: only the convolutional model continues
+        if ((lane >> 4) * 4 < MR) *reinterpret_cast<uint2*>(dtT_out + (size_t)col * Bp + m0 + (lane >> 4) * 4) = pk;
+        if (dt_out != nullptr && (lane >> 4) * 4 < MR) {                                 // row-major copy: only the convolutional model continues
 #pragma unroll                                                   // the backward pass below the first Linear
             for (int r = 0; r < 4; ++r) dt_out[(size_t)(m0 + (lane >> 4) * 4 + r) * hep + col] = f2bf(o4[r]);
         }
@@ -410,20 +418,24 @@ int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
     const size_t smem = mid_fwd_smem(d.Lp, d.hep, d.hdp);
     HL_REQUIRE(smem <= 150 * 1024, HLVAE_EINVAL, "hidden width too large for the fused middle kernel (%zu B of LDS)", smem);
     HL_PROF("mid_fwd_fused", s);
-#define HL_MF(LPv)                                                                                                     \
+#define HL_MF(LPv, MRv)                                                                                                \
     {                                                                                                                  \
         static size_t attr_max = 48 * 1024;                                                                            \
         if (smem > attr_max) {                                                                                         \
-            HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mid_fwd_fused<LPv>),                          \
+            HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mid_fwd_fused<LPv, MRv>),                     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                      \
             attr_max = smem;                                                                                           \
         }                                                                                                              \
-        k_mid_fwd_fused<LPv><<<Bp / MID_ROWS, MID_THREADS, smem, s>>>(                                                    \
+        k_mid_fwd_fused<LPv, MRv><<<Bp / MRv, MID_THREADS, smem, s>>>(                                                    \
             ws->slab, ws->splitk_enc, Bp, d.hep, d.h_e, ws->P + d.o_b1, ws->t, ws->tT, ws->wmls, ws->P + d.o_bmu,       \
             ws->P + d.o_blv, sample ? eps : nullptr, ws->eps, sample ? ws->rng : nullptr, rng_off, ws->mu, ws->lv,     \
             ws->z, ws->zb, ws->zbT, d.L, ws->klpart, ws->wds, d.hdp, d.h_d, ws->P + d.o_bd, ws->u, ws->uT, B);          \
     }
-    if (d.Lp == 32) HL_MF(32) else if (d.Lp == 64) HL_MF(64) else HL_REQUIRE(false, HLVAE_EINVAL, "latent_dim > 64");
+    // fewer than 128 sixteen-row workgroups (batches below 2048 rows) leave most CUs idle: eight rows per workgroup then
+    const bool small = Bp / MID_ROWS < 128;
+    if (d.Lp == 32) { if (small) HL_MF(32, 8) else HL_MF(32, 16) }
+    else if (d.Lp == 64) { if (small) HL_MF(64, 8) else HL_MF(64, 16) }
+    else HL_REQUIRE(false, HLVAE_EINVAL, "latent_dim > 64");
 #undef HL_MF
     HL_LAUNCH_CHECK();
     return 0;
@@ -436,20 +448,23 @@ int hl_launch_mid_bwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
     const size_t smem = mid_bwd_smem(d.Lp, d.hdp);
     HL_REQUIRE(smem <= 150 * 1024, HLVAE_EINVAL, "hidden width too large for the fused middle kernel (%zu B of LDS)", smem);
     HL_PROF("mid_bwd_fused", s);
-#define HL_MB(LPv)                                                                                                     \
+#define HL_MB(LPv, MRv)                                                                                                \
     {                                                                                                                  \
         static size_t attr_max = 48 * 1024;                                                                            \
         if (smem > attr_max) {                                                                                         \
-            HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mid_bwd_fused<LPv>),                          \
+            HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mid_bwd_fused<LPv, MRv>),                     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                      \
             attr_max = smem;                                                                                           \
         }                                                                                                              \
-        k_mid_bwd_fused<LPv><<<Bp / MID_ROWS, MID_THREADS, smem, s>>>(                                                    \
+        k_mid_bwd_fused<LPv, MRv><<<Bp / MRv, MID_THREADS, smem, s>>>(                                                    \
             ws->slab, ws->splitk_dec, Bp, d.hdp, d.h_d, ws->u, ws->duT, ws->G + d.o_bd, ws->wdTs, ws->eps, ws->lv,     \
             ws->mu, g_mu, g_lv, kl_w, d.L, ws->dmlT, ws->G + d.o_bmu, ws->G + d.o_blv, ws->wmlTs, d.hep, d.h_e, ws->t, \
             ws->dtT, ws->G + d.o_b1, B, d.conv ? ws->dt : nullptr);                                                    \
     }
-    if (d.Lp == 32) HL_MB(32) else if (d.Lp == 64) HL_MB(64) else HL_REQUIRE(false, HLVAE_EINVAL, "latent_dim > 64");
+    const bool small = Bp / MID_ROWS < 128;
+    if (d.Lp == 32) { if (small) HL_MB(32, 8) else HL_MB(32, 16) }
+    else if (d.Lp == 64) { if (small) HL_MB(64, 8) else HL_MB(64, 16) }
+    else HL_REQUIRE(false, HLVAE_EINVAL, "latent_dim > 64");
 #undef HL_MB
     HL_LAUNCH_CHECK();
     return 0;
