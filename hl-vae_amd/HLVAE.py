@@ -377,7 +377,7 @@ class HLVAE(nn.Module):
             t=z(Bp, d.hep), tT=z(d.hep, Bp), mu=z(Bp, d.L, dt=f32), lv=z(Bp, d.L, dt=f32), z=z(Bp, d.L, dt=f32),
             zb=z(Bp, d.Lp), zbT=z(d.Lp, Bp), u=z(Bp, d.hdp), uT=z(d.hdp, Bp), dy=z(Bp, d.NYp), dyT=z(d.NY, Bp),
             log_p_x=z(Bp, d.D, dt=f32), log_p_x_missing=z(Bp, d.D, dt=f32), rowpart=z(NT, Bp, dt=f32),
-            nll=z(Bp, dt=f32), scal=z(8, dt=torch.float64), klpart=z(max(Bp // 8, 1), dt=torch.float64),
+            nll=z(Bp, dt=f32), scal=z(8, dt=torch.float64), klpart=z(max(Bp // 4, 1), dt=torch.float64),
             eps=z(Bp, d.L, dt=f32), rng=z(2, dt=torch.int64), pfull=z(Bp, d.X, dt=f32), xhat=z(Bp, d.D, dt=f32),
             metpart=z(16, 6, d.D, dt=f32),
             du=z(Bp, d.hdp), duT=z(d.hdp, Bp), dz=z(Bp, d.Lp, dt=f32), dml=z(Bp, 2 * d.Lp), dmlT=z(2 * d.Lp, Bp),

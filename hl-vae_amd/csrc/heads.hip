@@ -792,7 +792,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
 int hl_launch_elbo_finalize(const hlvae_plan* p, const hlvae_ws* ws, int B, int Bp, hipStream_t s) {
     const int NT = (p->d.D + 15) / 16;
     HL_PROF("elbo_finalize", s);
-    k_elbo_finalize<<<1, 1024, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal, ws->klpart, Bp / 8, ws->rng);        // one partial per 8 rows (k_mid_fwd_fused)
+    k_elbo_finalize<<<1, 1024, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal, ws->klpart, Bp / 4, ws->rng);        // one partial per 4 rows (k_mid_fwd_fused)
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -112,7 +112,7 @@ typedef struct {
     float* rowpart;      /* [ceil(D/16)][Bp] partial row sums of log_p_x                    */
     float* nll;          /* [Bp]  -sum_d log_p_x                                            */
     double* scal;        /* [8]: 0 = sum_b nll, 1 = KL(q || N(0,I)) of the batch (extension), 2.. reserved */
-    double* klpart;      /* [Bp/8] KL partial sums, one per 8 rows (k_mid_fwd_fused)            */
+    double* klpart;      /* [Bp/4] KL partial sums, one per 4 rows (k_mid_fwd_fused)            */
     float* eps;          /* [Bp][L] reparameterisation noise actually used (kept for backward) */
     uint64_t* rng;       /* [2]: Philox seed, offset (advanced by one per step on device)    */
     float* pfull;        /* [Bp][X]  likelihood parameters concatenated by key (row M), optional */
