@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -97,6 +97,7 @@ _SIGS = {
                                       C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "hlvae_gp_transform": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_bmm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
+    "hlvae_gp_gemv_t": (C.c_int, [_vp, _vp, C.c_long, C.c_long, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "hlvae_gp_rsym": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_bound": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                  C.c_double, C.c_double, C.c_double, _vp, _vp]),

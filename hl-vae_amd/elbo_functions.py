@@ -417,8 +417,9 @@ class GPPriorHIP:
         P1 = self._xchg[LMM:LMM + LM].view(L, M, 1)
         u = self._xchg[LMM + LM:LMM + 2 * LM].view(L, M, 1)
         torch.bmm(KxzT, V, out=W)                                            # sum_s Ks^T iB Ks   [L,M,M]
-        torch.bmm(V.transpose(1, 2), mu64.t().unsqueeze(2), out=P1)          # natural-gradient term (elbo_functions.py:262-266)
-        torch.bmm(KxzT, v.unsqueeze(2), out=u)
+        # P1 = V^T mu (natural-gradient term, elbo_functions.py:262-266) and u = Kxz^T v: one streaming pass per latent each
+        _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(V), _lib.ptr(mu64), mu64.stride(1), mu64.stride(0), _lib.ptr(P1), L, B, M, st), "gp_gemv_t")
+        _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(Kxz), _lib.ptr(v), v.stride(0), v.stride(1), _lib.ptr(u), L, B, M, st), "gp_gemv_t")
         HiK = self.bmm(self.H, iK)
         Qm = self.bmm(iK, HiK)                                               # iK H iK
         world = 1 if self.dp is None else self.dp.world

@@ -40,6 +40,7 @@ def gp_algorithmic_work(gp, B, S, T):
     # fp64 matrix-core products of the M x M algebra: priced against the dense fp64 MFMA peak (MI355X: 78.6 TFLOP/s)
     w["gp_bmm"] = (4 * L * M * M * f, 2 * L * M * M * M, MFMA_FP64_PEAK_TFLOPS)
     w["gp_rsym"] = (4 * L * M * M * f, 0)
+    w["gp_gemv_t"] = (L * B * M * f, 0)
     return w
 
 

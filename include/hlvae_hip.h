@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 19
+#define HLVAE_ABI_VERSION 20
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -302,6 +302,10 @@ int hlvae_gp_bound(const double* part, int S, const double* W, const double* iK,
  * alias C): the M x M algebra of the bound and of the natural gradient (elbo_functions.py:268-283) on the fp64 matrix cores. */
 int hlvae_gp_bmm(const double* A, const double* B, const double* D, double* C, int N, int batch, double alpha, double beta,
                  hlvae_stream s);
+/* out[l][m] = sum_b A[l][b][m] x[l][b]  (A: [L][B][M] dense, x element (l, b) at x[l * x_stride_l + b * x_stride_b], M <= 128):
+ * the matrix^T-vector products Kxz^T v and V^T mu of the bound as one streaming pass per latent */
+int hlvae_gp_gemv_t(const double* A, const double* x, long x_stride_l, long x_stride_b, double* out, int L, int B, int M,
+                    hlvae_stream s);
 /* out[l] = c (u m^T + m u^T - W + X + X^T) + H + m m^T  per latent (u, m: [batch][N]; W, X, H, out: [batch][N][N]): the
  * symmetrised gradient term of K0zz in one pass */
 int hlvae_gp_rsym(const double* u, const double* m, const double* W, const double* X, const double* H, double c, int N, int batch,

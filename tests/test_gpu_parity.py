@@ -625,6 +625,13 @@ def test_gp_bmm_and_rsym_against_torch(N, batch):
     mT = m.transpose(1, 2)
     ref = 1.7 * (u @ mT + m @ u.transpose(1, 2) - A + B + B.transpose(1, 2)) + D + m @ mT
     assert rel_err(out, ref) < 1e-13
+    # matrix^T-vector product with a strided vector operand (k_gp_gemv_t)
+    rows = 203
+    R = torch.randn(batch, rows, N, generator=g, dtype=torch.float64).to(dev)
+    xv = torch.randn(rows, batch, generator=g, dtype=torch.float64).to(dev)             # element (l, b) at xv[b, l]
+    o2 = torch.full((batch, N), float("nan"), dtype=torch.float64, device=dev)
+    _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(R), _lib.ptr(xv), xv.stride(1), xv.stride(0), _lib.ptr(o2), batch, rows, N, st), "gemv_t")
+    assert rel_err(o2, (R.transpose(1, 2) @ xv.t().unsqueeze(2)).squeeze(2)) < 1e-13
 
 
 def test_gp_prior_config5_size_against_autograd_statement():
