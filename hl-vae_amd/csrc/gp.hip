@@ -592,20 +592,22 @@ __global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const 
 // batched N x N fp64 products of the natural-gradient algebra (N = inducing points <= 128):
 //     C[l] = alpha A[l] B[l] + beta D[l]                 (row-major, dense; D may be null or alias C)
 // on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: A/B one double per lane, A[row l&15][k l>>4], B[k l>>4][col l&15];
-// C/D col = lane&15, row = (lane>>4) + 4 reg).  One workgroup = one 64 x 64 tile of one matrix; its 64 x K and K x 64
-// operand panels (K = N <= 128) sit whole in LDS, each wave owns 16 rows x 64 columns.  The library's batched GEMM takes
+// C/D col = lane&15, row = (lane>>4) + 4 reg).  One workgroup = one 32 x 32 tile of one matrix (64 x 64: 15.3 us per
+// product, 32 x 64: 14.6, 32 x 32: 13.7 -- 512 workgroups for 32 latents); its 32 x K and K x 32 operand panels (K = N <= 128)
+// sit whole in LDS, each wave owns one 16 x 16 fragment.  The library's batched GEMM takes
 // 11-32 us for these 120 x 120 x 120 x 32 products (3.5 TFLOP/s); seven of them per step were 18 % of the GP step.
 // ------------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) double f64x4_t;
-#define GP_BMM_T 64
+#define GP_BMM_T 32                                         // tile columns
+#define GP_BMM_R 32                                         // tile rows
 __global__ __launch_bounds__(256) void k_gp_bmm(const double* __restrict__ A, const double* __restrict__ B, const double* D,
                                                 double* C, int N, double alpha, double beta) {
     extern __shared__ __attribute__((aligned(16))) char dsm_bmm[];
     const int Kp = (N + 3) & ~3;                                  // k padded to the MFMA step with zeros
     const int lda = Kp + 1, ldb = GP_BMM_T + 1;
     double* As = reinterpret_cast<double*>(dsm_bmm);              // [64][Kp + 1]
-    double* Bs = As + GP_BMM_T * lda;                             // [Kp][65]
-    const int l = blockIdx.z, m0 = blockIdx.y * GP_BMM_T, n0 = blockIdx.x * GP_BMM_T;
+    double* Bs = As + GP_BMM_R * lda;                             // [Kp][65]
+    const int l = blockIdx.z, m0 = blockIdx.y * GP_BMM_R, n0 = blockIdx.x * GP_BMM_T;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* Al = A + (size_t)l * N * N;
     const double* Bl = B + (size_t)l * N * N;
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(256) void k_gp_bmm(const double* __restrict__ A, co
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int e = tid + 256 * u, r = e / K2, k = 2 * (e - r * K2);
-            t[u] = (e < GP_BMM_T * K2 && m0 + r < N && k < N) ? *reinterpret_cast<const f64x2_t*>(Al + (size_t)(m0 + r) * N + k)
+            t[u] = (e < GP_BMM_R * K2 && m0 + r < N && k < N) ? *reinterpret_cast<const f64x2_t*>(Al + (size_t)(m0 + r) * N + k)
                                                               : f64x2_t{0.0, 0.0};
         }
 #pragma unroll
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(256) void k_gp_bmm(const double* __restrict__ A, co
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int e = tid + 256 * u, r = e / K2, k = 2 * (e - r * K2);
-            if (e < GP_BMM_T * K2) { As[r * lda + k] = t[u][0]; As[r * lda + k + 1] = t[u][1]; }
+            if (e < GP_BMM_R * K2) { As[r * lda + k] = t[u][0]; As[r * lda + k + 1] = t[u][1]; }
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -639,17 +641,17 @@ __global__ __launch_bounds__(256) void k_gp_bmm(const double* __restrict__ A, co
             if (e < Kp * T2) { Bs[k * ldb + c] = tb[u][0]; Bs[k * ldb + c + 1] = tb[u][1]; }
         }
     } else {
-    for (int e0 = tid; e0 < GP_BMM_T * Kp; e0 += 8 * 256) {
+    for (int e0 = tid; e0 < GP_BMM_R * Kp; e0 += 8 * 256) {
         double t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + 256 * u, r = e / Kp, k = e - r * Kp;
-            t[u] = (e < GP_BMM_T * Kp && m0 + r < N && k < N) ? Al[(size_t)(m0 + r) * N + k] : 0.0;
+            t[u] = (e < GP_BMM_R * Kp && m0 + r < N && k < N) ? Al[(size_t)(m0 + r) * N + k] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = e0 + 256 * u, r = e / Kp, k = e - r * Kp;
-            if (e < GP_BMM_T * Kp) As[r * lda + k] = t[u];
+            if (e < GP_BMM_R * Kp) As[r * lda + k] = t[u];
         }
     }
     for (int e0 = tid; e0 < Kp * GP_BMM_T; e0 += 8 * 256) {
@@ -667,24 +669,27 @@ __global__ __launch_bounds__(256) void k_gp_bmm(const double* __restrict__ A, co
     }
     }
     __syncthreads();
-    f64x4_t acc[4];
+    // 4 waves = 2 (16-row halves of the tile) x 2 (32-column halves): two 16 x 16 output fragments per wave
+    const int wr = wave & 1, wc = wave >> 1;
+    constexpr int NJ = GP_BMM_T / 32;
+    f64x4_t acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
-    const double* ap = As + (wave * 16 + (lane & 15)) * lda + (lane >> 4);
-    const double* bp = Bs + (lane >> 4) * ldb + (lane & 15);
-#pragma unroll 2
+    for (int j = 0; j < NJ; ++j) acc[j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const double* ap = As + (wr * 16 + (lane & 15)) * lda + (lane >> 4);
+    const double* bp = Bs + (lane >> 4) * ldb + wc * (GP_BMM_T / 2) + (lane & 15);
+#pragma unroll 4
     for (int k = 0; k < Kp; k += 4) {
         const double a = ap[k];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * ldb + 16 * j], acc[j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * ldb + 16 * j], acc[j], 0, 0, 0);
     }
     const double* Dl = D != nullptr ? D + (size_t)l * N * N : nullptr;
     double* Cl = C + (size_t)l * N * N;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wave * 16 + (lane >> 4) + 4 * r, col = n0 + 16 * j + (lane & 15);
+            const int row = m0 + wr * 16 + (lane >> 4) + 4 * r, col = n0 + wc * (GP_BMM_T / 2) + 16 * j + (lane & 15);
             if (row < N && col < N) {
                 double v = alpha * acc[j][r];
                 if (Dl != nullptr) v += beta * Dl[(size_t)row * N + col];
@@ -909,15 +914,15 @@ int hlvae_gp_bmm(const double* A, const double* B, const double* D, double* C, i
                  hlvae_stream s) {
     HL_REQUIRE(A && B && C && N >= 1 && N <= GP_MMAX && batch >= 1, HLVAE_EINVAL, "gp_bmm: N=%d batch=%d", N, batch);
     const int Kp = (N + 3) & ~3;
-    const size_t smem = ((size_t)GP_BMM_T * (Kp + 1) + (size_t)Kp * (GP_BMM_T + 1)) * sizeof(double);
+    const size_t smem = ((size_t)GP_BMM_R * (Kp + 1) + (size_t)Kp * (GP_BMM_T + 1)) * sizeof(double);
     static size_t attr_max = 0;
     if (smem > attr_max) {
         HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_bmm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_max = smem;
     }
-    const int t = (N + GP_BMM_T - 1) / GP_BMM_T;
+    const int tn = (N + GP_BMM_T - 1) / GP_BMM_T, tm = (N + GP_BMM_R - 1) / GP_BMM_R;
     HL_PROF("gp_bmm", (hipStream_t)s);
-    k_gp_bmm<<<dim3(t, t, batch), 256, smem, (hipStream_t)s>>>(A, B, D, C, N, alpha, beta);
+    k_gp_bmm<<<dim3(tn, tm, batch), 256, smem, (hipStream_t)s>>>(A, B, D, C, N, alpha, beta);
     HL_LAUNCH_CHECK();
     return 0;
 }
