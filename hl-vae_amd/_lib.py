@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -98,6 +98,7 @@ _SIGS = {
     "hlvae_gp_transform": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_bmm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
     "hlvae_gp_gemv_t": (C.c_int, [_vp, _vp, C.c_long, C.c_long, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "hlvae_gp_gkxz": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_rsym": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_bound": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                  C.c_double, C.c_double, C.c_double, _vp, _vp]),

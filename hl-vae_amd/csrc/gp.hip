@@ -745,6 +745,18 @@ __global__ __launch_bounds__(1024) void k_gp_gemv_t(const double* __restrict__ A
     }
 }
 
+// G[l][b][m] = c (v[l][b] w[l][m] - Y[l][b][m]): the gradient w.r.t. K0xz from its two pieces in one pass (as baddbmm: a
+// 15.7 MB copy plus a rank-1 batched GEMM)
+__global__ __launch_bounds__(256) void k_gp_gkxz(const double* __restrict__ Y, const double* __restrict__ v, const double* __restrict__ w,
+                                                 double c, int Bn, int M, long n_total, double* __restrict__ G) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n_total; e += (long)gridDim.x * 256) {
+        const long lb = e / M;
+        const int m = (int)(e - lb * M);
+        const long l = lb / Bn;
+        G[e] = c * (v[lb] * w[l * M + m] - Y[e]);
+    }
+}
+
 // every scalar of the bound in one launch (elbo_functions.py:268-285):
 //   out += c/2 [ sum(part) - sum(W o iK) + sum(Qm o W) - sum(log_var) ]
 //        + rep { 1/2 [ sum(iK o H) + sum(m o iKm) + sum(ldK) - sum(ldH) ] + konst }
@@ -932,6 +944,15 @@ int hlvae_gp_gemv_t(const double* A, const double* x, long x_stride_l, long x_st
     HL_REQUIRE(A && x && out && L >= 1 && B >= 1 && M >= 1 && M <= GP_MMAX, HLVAE_EINVAL, "gp_gemv_t: L=%d B=%d M=%d", L, B, M);
     HL_PROF("gp_gemv_t", (hipStream_t)s);
     k_gp_gemv_t<<<L, 1024, 0, (hipStream_t)s>>>(A, x, x_stride_l, x_stride_b, out, B, M);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_gkxz(const double* Y, const double* v, const double* w, double c, int L, int B, int M, double* G, hlvae_stream s) {
+    HL_REQUIRE(Y && v && w && G && L >= 1 && B >= 1 && M >= 1, HLVAE_EINVAL, "gp_gkxz: null argument");
+    const long n = (long)L * B * M;
+    HL_PROF("gp_gkxz", (hipStream_t)s);
+    k_gp_gkxz<<<(int)((n + 4 * 256 - 1) / (4 * 256)), 256, 0, (hipStream_t)s>>>(Y, v, w, c, B, M, n, G);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -436,7 +436,8 @@ class GPPriorHIP:
         # analytic gradients w.r.t. kernel matrices, chained into hyper-parameters / inducing points by the HIP kernels
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
         Y = V @ (iK - Qm)                                                    # [L,B,M]  (local rows)
-        G_Kxz = torch.baddbmm(Y, v.unsqueeze(2), iKm.transpose(1, 2), beta=-c, alpha=c)   # c [ v (iK m)^T + V (Q - iK) ]
+        G_Kxz = torch.empty_like(Y)                                          # c [ v (iK m)^T + V (Q - iK) ]
+        _lib.check(lib.hlvae_gp_gkxz(_lib.ptr(Y), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), L, B, M, _lib.ptr(G_Kxz), st), "gp_gkxz")
         HiKW = self.bmm(HiK, W)
         # R + R^T with R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T): K0zz's gradient is needed symmetrised.
         # It is built from global sums only, i.e. replicated: each rank contributes 1 / world of it

@@ -41,6 +41,7 @@ def gp_algorithmic_work(gp, B, S, T):
     w["gp_bmm"] = (4 * L * M * M * f, 2 * L * M * M * M, MFMA_FP64_PEAK_TFLOPS)
     w["gp_rsym"] = (4 * L * M * M * f, 0)
     w["gp_gemv_t"] = (L * B * M * f, 0)
+    w["gp_gkxz"] = (2 * L * B * M * f, 0)
     return w
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 20
+#define HLVAE_ABI_VERSION 21
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -306,6 +306,8 @@ int hlvae_gp_bmm(const double* A, const double* B, const double* D, double* C, i
  * the matrix^T-vector products Kxz^T v and V^T mu of the bound as one streaming pass per latent */
 int hlvae_gp_gemv_t(const double* A, const double* x, long x_stride_l, long x_stride_b, double* out, int L, int B, int M,
                     hlvae_stream s);
+/* G[l][b][m] = c (v[l][b] w[l][m] - Y[l][b][m])   (Y, G: [L][B][M]; v: [L][B]; w: [L][M]): gradient w.r.t. K0xz in one pass */
+int hlvae_gp_gkxz(const double* Y, const double* v, const double* w, double c, int L, int B, int M, double* G, hlvae_stream s);
 /* out[l] = c (u m^T + m u^T - W + X + X^T) + H + m m^T  per latent (u, m: [batch][N]; W, X, H, out: [batch][N][N]): the
  * symmetrised gradient term of K0zz in one pass */
 int hlvae_gp_rsym(const double* u, const double* m, const double* W, const double* X, const double* H, double c, int N, int batch,
