@@ -62,6 +62,18 @@ struct GemmGroup {
 enum { HL_PEND_METRICS = 1, HL_PEND_FINALIZE = 2, HL_PEND_RUNNING = 4, HL_PEND_FEED = 8,
        HL_PEND_DEFERRED = HL_PEND_METRICS | HL_PEND_FINALIZE | HL_PEND_FEED };
 
+// a + (the value of the lane 16 / 32 positions away, lane ^ 16 / lane ^ 32): the cross-row steps of a wave reduction on the
+// VALU (gfx950 v_permlane16_swap / v_permlane32_swap: a half exchange between two registers) instead of ds_bpermute through
+// the LDS crossbar.  swap(a, a) leaves {own, partner} in the two results on every lane, so their sum is the all-reduce step.
+__device__ __forceinline__ float xor16_sum(float a) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float a) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 struct hlvae_plan {
     hlvae_dims d;
     hlvae_var* vars_dev;      // [D]

@@ -645,8 +645,7 @@ __global__ __launch_bounds__(256) void k_convT1_bwd(const bf16_t* __restrict__ d
         }
     {   // d b_t1[co = r16]: the four lane groups of a wave by shuffle, the four waves by LDS atomics
         float v = bacc;
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
+        v = xor32_sum(xor16_sum(v));
         if (q == 0) atomicAdd(&bred[r16], v);
     }
     __syncthreads();
@@ -896,8 +895,7 @@ __global__ __launch_bounds__(512) void k_conv_enc_bwd(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float v = b2acc[i];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
+        v = xor32_sum(xor16_sum(v));
         if (q == 0) atomicAdd(&sm.red2[i * 16 + r16], v);          // the four waves own different pooling windows
     }
     // d conv1.{weight, bias}: the 4 lane groups of a wave share co = tid & 15 -> shuffles, then one LDS slot per wave
@@ -906,8 +904,7 @@ __global__ __launch_bounds__(512) void k_conv_enc_bwd(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 10; ++t) {
         float v = w1acc[t];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
+        v = xor32_sum(xor16_sum(v));
         if (q == 0) w1red[wave * 160 + r16 * 10 + t] = v;
     }
     // d conv2.weight in arena order [co][ci][tap] through LDS: the accumulator layout would be 24 scattered 4-byte stores per lane

@@ -547,8 +547,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
 #pragma unroll
     for (int n = 0; n < NACC; ++n) {
         float a = acc[n];
-        a += __shfl_xor(a, 16, 64);
-        a += __shfl_xor(a, 32, 64);
+        a = xor32_sum(xor16_sum(a));
         if ((tid & 63) < 16) red[(wave * 16 + v) * NACC + n] = a;
     }
     __syncthreads();   // also orders the dY tile writes above

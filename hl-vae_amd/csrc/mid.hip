@@ -394,8 +394,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
 #pragma unroll                                                   // the backward pass below the first Linear
             for (int r = 0; r < 4; ++r) dt_out[(size_t)(m0 + (lane >> 4) * 4 + r) * hep + col] = f2bf(o4[r]);
         }
-        s += __shfl_xor(s, 16, 64);                              // the 4 row groups of a column
-        s += __shfl_xor(s, 32, 64);
+        s = xor32_sum(xor16_sum(s));                             // the 4 row groups of a column
         if (lane < 16 && col < h_e) atomicAdd(gb1 + col, s);
     }
 }
