@@ -612,23 +612,35 @@ __global__ __launch_bounds__(1024) void k_elbo_finalize(const float* __restrict_
     double tot = 0.0;
     for (int b = threadIdx.x; b < Bp; b += blockDim.x) {
         float s = 0.f;
-        if (b < B) {
-#pragma unroll 9
-            for (int t = 0; t < NT; ++t) s += rowpart[(size_t)t * Bp + b];
+        if (b < B) {                                    // 27 loads in flight per lane (one workgroup: pure latency; 9 took 8 us)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            int t = 0;
+            for (; t + 27 <= NT; t += 27) {
+                float v[27];
+#pragma unroll
+                for (int k = 0; k < 27; ++k) v[k] = rowpart[(size_t)(t + k) * Bp + b];
+#pragma unroll
+                for (int k = 0; k < 27; k += 3) { s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; }
+            }
+            for (; t < NT; ++t) s0 += rowpart[(size_t)t * Bp + b];
+            s = (s0 + s1) + s2;
         }
         nll[b] = -s;
         tot += (double)(-s);
     }
+    // the KL partials (one per 4 rows) in parallel too: a serial loop of one thread over them is a chain of global loads
+    double kl = 0.0;
+    if (klpart != nullptr)
+        for (int i = threadIdx.x; i < nkl; i += blockDim.x) kl += klpart[i];
     tot = wave_sum_d(tot);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+    kl = wave_sum_d(kl);
+    __shared__ double redk[16];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = tot; redk[threadIdx.x >> 6] = kl; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        double t = 0.0, k = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += red[w]; k += redk[w]; }
         scal[0] = t;
-        double k = 0.0;
-        if (klpart != nullptr)
-            for (int i = 0; i < nkl; ++i) k += klpart[i];
         scal[1] = k;
         if (rng != nullptr) rng[1] += 1;
     }
