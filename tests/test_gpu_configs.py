@@ -1,0 +1,356 @@
+"""GPU parity at the sizes of BASELINE.json configs[2..4] (round-2 additions):
+
+  * D4 at 1024 and 4096 rows -- every D4 batch of >= 896 rows runs the 128-row instance of the head kernel
+    (csrc/heads.hip: hl_launch_y_heads `big`) and the 16-row tiles of the fused middle kernels above 2048 rows:
+    forward, every gradient tensor and one fused ELBOTrainer step from the compact feed against the fp64 oracle;
+  * the full config-5 step: HIP decoder + GPPriorHIP on a 1024-row batch of 51 whole subjects x 20 rows + 4 rows of a
+    52nd, against hlvae_oracle + gp_oracle;
+  * GPPriorHIP loaded from the reference's own output tests/golden/gp_kl.npz (reference elbo_functions.py:196-285,
+    training.py:130-137);
+  * the convolutional model's BACKWARD pass at 512 and 1024 rows against the oracle.
+
+Tolerances: ELBO / loss 1e-4 relative (north star); gradients per tensor 2.5e-2 relative L2 (bf16 operands of both backward
+GEMMs set the floor: 1-2e-2 measured on the first encoder Linear); fp64 GP quantities 1e-7..1e-9; fp32 GP outputs 1e-5."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import hlvae_amd                      # noqa: E402
+from hlvae_amd import synthetic       # noqa: E402
+from tests_common import max_abs_err, rel_err   # noqa: E402
+
+ELBO_RTOL = 1e-4
+GRAD_RTOL = 2.5e-2
+REPORT = {}
+GP_CFG = dict(cat=[2], bin=[], sqexp=[0], cat_int=[{"cont_covariate": 0, "cat_covariate": 2}, {"cont_covariate": 0, "cat_covariate": 3},
+                                                   {"cont_covariate": 1, "cat_covariate": 4}], bin_int=[])
+
+
+def _report(key, **kv):
+    REPORT.setdefault(key, {}).update({k: float(v) for k, v in kv.items()})
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report_configs.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _oracle_state(state, conv=False):
+    st = {k: v.double().clone().requires_grad_(True) for k, v in state.items()
+          if not k.startswith(("hidden.", "Decoder_Conv_layer."))}
+    for k in list(st):
+        if k.startswith("d_layers."):
+            st["hidden." + k[len("d_layers."):]] = st[k]
+        if k.startswith("deconv_layer."):
+            st["Decoder_Conv_layer." + k[len("deconv_layer."):]] = st[k]
+    return st
+
+
+def _adam_reference(st):
+    """names / leaves the reference's torch.optim.Adam would update (training.py:127-128)"""
+    names = [k for k in st if not k.startswith(("hidden.", "Decoder_Conv_layer.")) and k != "_disp_param"]
+    return names, [st[k] for k in names]
+
+
+@pytest.mark.parametrize("B", [1024, 4096])
+def test_d4_large_batch_against_oracle(B):
+    """BASELINE configs[2] (global batch 4096) and configs[4] (batch 1024) on the D4 layout, MLP [5184,[500],32,[500],5]."""
+    import hlvae_oracle as orc
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    from hlvae_amd.datafeed import CompactDataset
+    dev = _dev()
+    n_subj = (B + 19) // 20 + 1
+    src = synthetic.make_d4(n_subjects=n_subj, T=20, seed=100 + B)
+    rows = np.arange(B)
+    P_batch = int(np.unique(src.labels[rows, 2]).size)
+    P_total = 4 * n_subj
+    scale = P_total / P_batch
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    torch.manual_seed(1234 + B)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=B, materialize_samples=False).to(dev)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    eps = torch.randn(B, 32, generator=torch.Generator().manual_seed(5))
+    data = torch.tensor(src.data[rows], device=dev)
+    mask = torch.tensor(src.mask[rows], device=dev)
+    # ---- autograd surface: forward + every gradient
+    out = model(data, mask, None, src.types_info, eps=eps.to(dev))
+    mu, lv, lpx = out[1], out[2], out[3]
+    loss = scale * model.loss_function(lpx).sum() - 0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
+    loss.backward()
+    torch.cuda.synchronize()
+    st = _oracle_state(state)
+    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st)
+    ref = om.forward(torch.tensor(src.data[rows]), torch.tensor(src.mask[rows]), eps.double())
+    nll_ref = om.loss_function(ref["log_p_x"]).sum()
+    kl_ref = orc.standard_normal_kl(ref["mu"], ref["log_var"])
+    ref_loss = scale * nll_ref + kl_ref
+    ref_loss.backward()
+    elbo, elbo_ref = float(lpx.double().sum()), float(ref["log_p_x"].sum())
+    rel = abs(elbo - elbo_ref) / abs(elbo_ref)
+    key = f"d4_b{B}"
+    _report(key, elbo_rel=rel, loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
+            mu=max_abs_err(mu.cpu(), ref["mu"].detach()), lv=max_abs_err(lv.cpu(), ref["log_var"].detach()),
+            lpx_max=max_abs_err(lpx.cpu(), ref["log_p_x"].detach()))
+    assert rel <= ELBO_RTOL, rel
+    assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss))
+    e = np.abs(lpx.detach().double().cpu().numpy() - ref["log_p_x"].detach().numpy())
+    assert np.all(e <= 3e-2 + 2e-2 * np.abs(ref["log_p_x"].detach().numpy()))
+    e = np.abs(out[4].detach().double().cpu().numpy() - ref["log_p_x_missing"].detach().numpy())
+    assert np.all(e <= 3e-2 + 2e-2 * np.abs(ref["log_p_x_missing"].detach().numpy()))
+    sd = dict(model.named_parameters())
+    n_checked = 0
+    for k, p in sd.items():
+        if p.grad is None or st[k].grad is None:
+            assert k == "_disp_param" or p.numel() == 0, k
+            continue
+        err = rel_err(p.grad.double().cpu().numpy(), st[k].grad.numpy())
+        _report(key + "_grads", **{k: err})
+        assert err < GRAD_RTOL, (k, err)
+        n_checked += 1
+    assert n_checked >= 12
+    # ---- the fused training step (no autograd) from the compact feed: same weights, same noise
+    model2 = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=B, materialize_samples=False)
+    model2.load_state_dict(state)
+    model2 = model2.to(dev)
+    tr = ELBOTrainer(model2, P_total=P_total, kl="normal", max_batch=B, metrics=True)
+    ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    rows_dev = torch.tensor(rows.astype(np.int32), device=dev)
+    tr.step_rows(ds, rows_dev, P_batch, eps=eps.to(dev))
+    torch.cuda.synchronize()
+    nll_gpu, kl_gpu = float(tr.scalars()["nll_sum"]), float(tr.scalars()["kl"])
+    _report(key + "_step", nll_rel=abs(nll_gpu - float(nll_ref)) / abs(float(nll_ref)), kl_rel=abs(kl_gpu - float(kl_ref)) / abs(float(kl_ref)))
+    assert abs(nll_gpu - float(nll_ref)) <= ELBO_RTOL * abs(float(nll_ref))
+    assert abs(kl_gpu - float(kl_ref)) <= 2e-3 * abs(float(kl_ref))
+    names, params = _adam_reference(st)
+    live = [i for i, p in enumerate(params) if p.grad is not None]
+    before = {names[i]: params[i].detach().clone() for i in live}
+    orc.adam_step([params[i] for i in live], [params[i].grad for i in live], [torch.zeros_like(params[i]) for i in live],
+                  [torch.zeros_like(params[i]) for i in live], 1)
+    sd2 = dict(model2.named_parameters())
+    for i in live:
+        k = names[i]
+        if params[i].numel() == 0:
+            continue
+        d_ref = (params[i].detach() - before[k]).numpy()
+        d_gpu = (sd2[k].detach().double().cpu() - state[k].double()).numpy()
+        bad = np.abs(d_gpu - d_ref) > 1e-3                    # first Adam step: +-lr wherever the gradient keeps its sign
+        _report(key + "_step", **{"flip__" + k: bad.mean()})
+        assert bad.mean() < 0.02, (k, bad.mean())
+    # per-step metrics (row M) ran beside the backward pass: finite, inside [0, 1] for the discrete variables
+    err = tr.err.cpu().numpy()
+    assert np.isfinite(err).all() and err.min() >= 0.0
+    disc = np.isin(model2.plan.kind, [3, 4])
+    assert err[:, disc].max() <= 1.0
+
+
+def _gp_config5_inputs(dev, seed=1):
+    Ts = [20] * 51 + [4]
+    rows = []
+    for s_, T in enumerate(Ts):
+        for t in range(T):
+            sick = s_ % 2
+            rows.append([float(t), float(t - 9) if sick else 0.0, float(s_), float(s_ % 2), float(sick), float((s_ // 2) % 2)])
+    return torch.tensor(rows, dtype=torch.float64), len(Ts)
+
+
+def _gp_oracle_params(gp):
+    """hyper-parameter rows of a GPPriorHIP -> gp_oracle's parameter dict (leaves requiring grad)"""
+    prm = {}
+    for row, (which, t, f) in enumerate(gp.slot_names):
+        key = f"{which}.{t}.scale" if f is None else f"{which}.{t}.{f}.ls"
+        prm[key] = gp.prm[row].detach().cpu().clone().requires_grad_(True)
+    return prm
+
+
+def test_config5_full_step_against_oracles():
+    """BASELINE configs[4]: GP-prior KL alongside the HIP decoder, batch 1024 = 51 subjects x 20 rows + 4 rows of a 52nd,
+    L = 32, M = 120, the shipped kernel structure (config/hlvae_config_file.txt:41-45).  One fused ELBOTrainer step against
+    hlvae_oracle (VAE half) + gp_oracle (reference elbo_functions.py:196-285, training.py:130-137)."""
+    import gp_oracle as gpo
+    import hlvae_oracle as orc
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.elbo_functions import GPPriorHIP
+    from hlvae_amd.training import ELBOTrainer
+    dev = _dev()
+    src = synthetic.make_d4(n_subjects=52, T=20, seed=77)
+    B = 1024
+    rows = np.arange(B)                                     # 51 whole subjects + 4 rows of the 52nd
+    P_batch, P_total, N_total = 52, 2500, 50000
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    torch.manual_seed(99)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=B, materialize_samples=False).to(dev)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    labels = torch.tensor(src.labels[rows], device=dev)
+    gp = GPPriorHIP(dims[2], torch.tensor(src.labels, device=dev), 120, 2, N_total=N_total, seed=3)
+    with torch.no_grad():
+        gp.prm.add_(0.2 * torch.randn(gp.prm.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(dev))
+    m0, H0, z0 = gp.m.clone().cpu(), gp.H.clone().cpu(), gp.zt_list.detach().clone().cpu()
+    kprm = _gp_oracle_params(gp)
+    tr = ELBOTrainer(model, P_total=P_total, kl="gp", gp=gp, max_batch=B)
+    eps = torch.randn(B, dims[2], generator=torch.Generator().manual_seed(9))
+    data, mask = torch.tensor(src.data[rows], device=dev), torch.tensor(src.mask[rows], device=dev)
+    tr.step(data, mask, P_batch, eps=eps.to(dev), train_x=labels)
+    torch.cuda.synchronize()
+    assert int(gp.fail.item()) == 0
+    nll_gpu, kld_gpu = float(tr.scalars()["nll_sum"]), float(gp.last_kld)
+    mu_dev, lv_dev = model._ws_t["mu"][:B].double().cpu(), model._ws_t["lv"][:B].double().cpu()
+    # ---- GP half, tight: the oracle evaluated at the encoder outputs the device produced (fp64 against fp64)
+    spec = gpo.spec_from_config(GP_CFG["cat"], GP_CFG["bin"], GP_CFG["sqexp"], GP_CFG["cat_int"], GP_CFG["bin_int"], 2)
+    mu_t, lv_t = mu_dev.clone().requires_grad_(True), lv_dev.clone().requires_grad_(True)
+    z_t = z0.clone().requires_grad_(True)
+    noise = torch.ones(dims[2], dtype=torch.float64)
+    kld, gm, gH = gpo.minibatch_kld_upper_bound_iter(spec, kprm, noise, dims[2], m0, H0, torch.tensor(src.labels[rows]), mu_t, lv_t,
+                                                     z_t, P_total, P_batch, N_total, True, 2, 1e-6)
+    kld.sum().backward()
+    _report("config5", kld_rel=abs(kld_gpu - float(kld)) / abs(float(kld)), grad_m=rel_err(gp._grad_m, gm.detach()),
+            grad_H=rel_err(gp._grad_H, gH.detach()))
+    # K0zz of 120 inducing points drawn from 1040 covariate rows with a 1e-6 jitter has a condition number ~1e8: Gauss-Jordan
+    # (device) and Cholesky (oracle) inverses agree to ~1e-7, and so does everything built from iK (measured 5e-8 / 6e-7)
+    assert abs(kld_gpu - float(kld)) <= 5e-7 * abs(float(kld)), (kld_gpu, float(kld))
+    assert rel_err(gp._grad_m, gm.detach()) < 5e-6 and rel_err(gp._grad_H, gH.detach()) < 5e-6
+    m_ref, H_ref = gpo.natural_gradient_update(m0, H0, gm.detach(), gH.detach(), 0.01)
+    _report("config5", m_new=rel_err(gp.m, m_ref), H_new=rel_err(gp.H, H_ref))
+    assert rel_err(gp.m, m_ref) < 5e-6 and rel_err(gp.H, H_ref) < 5e-6
+    # Adam's first update of the GP parameters is -lr * sign(g) wherever g != 0 (HLVAE_main.py:277-278)
+    dz = (gp.zt_list.detach().cpu() - z0)
+    big = z_t.grad.abs() > 1e-3 * z_t.grad.abs().max()
+    assert (torch.sign(dz[big]) == -torch.sign(z_t.grad[big])).double().mean() > 0.999
+    for row, (which, t, f) in enumerate(gp.slot_names):
+        key = f"{which}.{t}.scale" if f is None else f"{which}.{t}.{f}.ls"
+        g_ref = kprm[key].grad
+        d = gp.prm[row].detach().cpu() - kprm[key].detach()
+        nz = g_ref.abs() > 1e-4                              # |step| = lr |g| / (|g| + 1e-8)
+        assert torch.equal(torch.sign(d[nz]), -torch.sign(g_ref[nz])), key
+        if bool(nz.any()):
+            assert float((d[nz].abs() - 1e-3).abs().max()) < 2e-7, key
+    # ---- VAE half + coupling: oracle forward with the same weights and noise
+    st = _oracle_state(state)
+    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st)
+    out = om.forward(torch.tensor(src.data[rows]), torch.tensor(src.mask[rows]), eps.double())
+    nll = om.loss_function(out["log_p_x"]).sum()
+    kld2, _, _ = gpo.minibatch_kld_upper_bound_iter(spec, {k: v.detach() for k, v in kprm.items()}, noise, dims[2], m0, H0,
+                                                    torch.tensor(src.labels[rows]), out["mu"], out["log_var"], z0, P_total, P_batch,
+                                                    N_total, True, 2, 1e-6)
+    (nll * P_total / P_batch + kld2.sum()).backward()
+    _report("config5", nll_rel=abs(nll_gpu - float(nll)) / abs(float(nll)), kld_e2e_rel=abs(kld_gpu - float(kld2)) / abs(float(kld2)))
+    assert abs(nll_gpu - float(nll)) <= ELBO_RTOL * abs(float(nll))
+    assert abs(kld_gpu - float(kld2)) <= 1e-3 * abs(float(kld2))           # bf16 encoder outputs enter the bound
+    # the encoder feels the GP gradient through mu / log_var: direction of the first Adam update of the mean / log-var layers
+    sd = dict(model.named_parameters())
+    for k in ("mean_layer.0.weight", "log_var_layer.0.weight", "VAE_encoder_common_layers.0.weight", "y_layer.0.weight"):
+        delta = sd[k].detach().double().cpu() - state[k].double()
+        gref = st[k].grad
+        big = gref.abs() > 0.05 * gref.abs().max()
+        agree = float((torch.sign(delta[big]) == -torch.sign(gref[big])).double().mean())
+        _report("config5", **{"sign__" + k: agree})
+        assert agree > 0.98, (k, agree)
+
+
+def test_gp_prior_hip_against_reference_fixture(golden_dir):
+    """GPPriorHIP straight against tests/golden/gp_kl.npz -- the output of the reference's own
+    minibatch_KLD_upper_bound_iter (elbo_functions.py:196-285) and natural-gradient step (training.py:130-137): bound,
+    grad_m, grad_H, gradients w.r.t. mu / log-variance / inducing points / every hyper-parameter, m_new, H_new."""
+    from hlvae_amd.elbo_functions import GPPriorHIP
+    g = np.load(os.path.join(golden_dir, "gp_kl.npz"))
+    dev = _dev()
+    P, P_b, N, eps, idc, lr = (float(v) for v in g["scalars"])
+    x = torch.tensor(g["x"], device=dev)
+    L, M = g["mu"].shape[1], g["z"].shape[1]
+    gp = GPPriorHIP(L, x, M, int(idc), N_total=N, eps=eps, natural_gradient_lr=lr)
+    with torch.no_grad():
+        gp.zt_list.copy_(torch.tensor(g["z"], device=dev))
+        for row, (which, t, f) in enumerate(gp.slot_names):
+            key = f"kp__{which}.{t}.scale" if f is None else f"kp__{which}.{t}.{f}.ls"
+            gp.prm[row].copy_(torch.tensor(g[key], device=dev))
+        gp.m.copy_(torch.tensor(g["m"], device=dev))
+        gp.H.copy_(torch.tensor(g["H"], device=dev))
+        gp.noise.copy_(torch.tensor(g["noise"], device=dev))
+    assert len(gp.slot_names) == sum(1 for k in g.files if k.startswith("kp__"))
+    mu = torch.tensor(g["mu"], device=dev).float()
+    lv = torch.tensor(g["log_v"], device=dev).float()
+    # the fixture's mu / log_v are fp64; the product takes the VAE's fp32 outputs: feed the fp32-rounded values to BOTH sides
+    # for the tight comparison of everything but d_mu / d_log_v ... the reference saw the unrounded ones, so compare the bound
+    # at fp32-input accuracy (1e-6) and the derivative outputs (fp32) at 1e-5
+    g_mu, g_lv = gp.kl_and_grads(mu, lv, x, P, P_b)
+    torch.cuda.synchronize()
+    assert int(gp.fail.item()) == 0
+    res = dict(kld=rel_err(gp.last_kld, g["kld"]), grad_m=rel_err(gp._grad_m, g["grad_m"]), grad_H=rel_err(gp._grad_H, g["grad_H"]),
+               d_mu=rel_err(g_mu, g["d_mu"]), d_log_v=rel_err(g_lv, g["d_log_v"]), d_z=rel_err(gp.zt_list.grad, g["d_z"]))
+    for row, (which, t, f) in enumerate(gp.slot_names):
+        key = f"{which}.{t}.scale" if f is None else f"{which}.{t}.{f}.ls"
+        res["kg__" + key] = rel_err(gp.prm.grad[row], g["kg__" + key])
+    _report("gp_kl_fixture", **res)
+    # measured on MI355X: kld 1.4e-9, grad_m 4.5e-9, grad_H 3e-16, d_mu / d_log_v 3e-8 (fp32 outputs of fp32-rounded inputs),
+    # d_z 1.5e-8, hyper-parameter gradients <= 1e-8
+    assert res["kld"] < 1e-8 and res["grad_m"] < 5e-8 and res["grad_H"] < 1e-10
+    assert res["d_mu"] < 3e-7 and res["d_log_v"] < 3e-7 and res["d_z"] < 1e-7
+    for k, v in res.items():
+        if k.startswith("kg__"):
+            assert v < 1e-7, (k, v)
+    gp.optimizer_step()
+    torch.cuda.synchronize()
+    assert int(gp.fail.item()) == 0
+    _report("gp_kl_fixture", m_new=rel_err(gp.m, g["m_new"]), H_new=rel_err(gp.H, g["H_new"]))
+    assert rel_err(gp.m, g["m_new"]) < 1e-9 and rel_err(gp.H, g["H_new"]) < 1e-10      # measured 7e-12 / 5e-16
+
+
+@pytest.mark.parametrize("B", [512, 1024])
+def test_conv_backward_against_oracle(B):
+    """convolutional model (what config/hlvae_config_file.txt:51 selects) at 512 and 1024 rows, hidden 500, latent 32:
+    ELBO, loss and EVERY gradient tensor against the fp64 oracle on the same weights and noise.  1024 rows runs the 128-row
+    instance of the head kernel in its `ysrc` (second transposed convolution) mode."""
+    import hlvae_oracle as orc
+    from hlvae_amd.HLVAE import HLVAE
+    dev = _dev()
+    src = synthetic.make_d4(n_subjects=(B + 19) // 20 + 1, T=20, seed=100)
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    torch.manual_seed(3)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=True, max_batch=B, materialize_samples=False).to(dev)
+    state = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
+    eps = torch.randn(B, 32, generator=torch.Generator().manual_seed(1))
+    data, mask = torch.tensor(src.data[:B]), torch.tensor(src.mask[:B])
+    scale = 7.5
+    out = model(data.to(dev), mask.to(dev), None, src.types_info, eps=eps.to(dev))
+    mu, lv, lpx = out[1], out[2], out[3]
+    loss = scale * model.loss_function(lpx).sum() - 0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
+    loss.backward()
+    torch.cuda.synchronize()
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    for k in list(st):
+        if k.startswith("hidden."):
+            st[k] = st["d_layers." + k[len("hidden."):]]
+        if k.startswith("Decoder_Conv_layer."):
+            st[k] = st["deconv_layer." + k[len("Decoder_Conv_layer."):]]
+    om = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st, conv=True)
+    ref = om.forward(data, mask, eps.double())
+    ref_loss = scale * om.loss_function(ref["log_p_x"]).sum() + orc.standard_normal_kl(ref["mu"], ref["log_var"])
+    ref_loss.backward()
+    elbo, elbo_ref = float(lpx.double().sum()), float(ref["log_p_x"].sum())
+    key = f"conv_b{B}"
+    _report(key, elbo_rel=abs(elbo - elbo_ref) / abs(elbo_ref), loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
+    assert abs(elbo - elbo_ref) <= ELBO_RTOL * abs(elbo_ref), (elbo, elbo_ref)
+    assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss))
+    sd = dict(model.named_parameters())
+    errs = {}
+    for k, p in sd.items():
+        if k.startswith(("hidden.", "Decoder_Conv_layer.")) or p.grad is None or st[k].grad is None or p.numel() == 0:
+            continue
+        errs[k] = rel_err(p.grad.double().cpu().numpy(), st[k].grad.numpy())
+    _report(key + "_grads", **errs)
+    assert len(errs) >= 20, sorted(errs)
+    for k, e in errs.items():
+        # d_layers.0.weight = dU^T z sums B signed terms per element with heavy cancellation, and dU has passed two transposed
+        # convolutions in bf16 with ReLU gates: 3.4e-2 at 512 rows, 2.6e-2 at 1024 (falls as 1 / sqrt(B): rounding noise, not
+        # logic; the MLP path shows 1.4e-2 / 0.7e-2 at 1024 / 4096 rows).  Everything else sits inside the MLP path's bound.
+        tol = 5e-2 if k == "d_layers.0.weight" else GRAD_RTOL
+        assert e < tol, (k, e)
