@@ -8,13 +8,20 @@ batches at 1/2/4/8 MI355X).
 
 A "step" = one full pass of the hot path over one batch: normalise/pack -> encoder -> reparameterise ->
 decoder + heads + log-likelihoods (+ backward) + imputed values -> per-variable reconstruction metrics -> KL ->
-dense backward -> [RCCL gradient all-reduce] -> Adam  (the training.py:70-137 sequence).  Workload at N=1 = BASELINE.json configs[1]: the 1k-sample synthetic D4 set (50 subjects x 20 rows,
-324 real + 972 five-class categorical variables, 25 % missing), MLP [5184,[500],32,[500],5], batch 512 rows
-(25 whole subjects + 12 rows of a 26th; whole-subject batching is the reference's sampler semantics),
-bf16 MFMA encoder/decoder with fp32 ELBO accumulation.  Inputs are the reference's fp64 [B,X]/[B,D] batch
-tensors, already resident in HBM.  Weak scaling: every rank processes its own 512-row batch.
+dense backward -> [RCCL reduce-scatter / sharded Adam / all-gather] -> Adam  (the training.py:70-137 sequence).
 
-Prints ONE JSON line on rank 0.
+Default workload = BASELINE.json configs[1]: the 1k-sample synthetic D4 set (50 subjects x 20 rows, 324 real + 972
+five-class categorical variables, 25 % missing), MLP [5184,[500],32,[500],5], batch 512 rows per GPU (25 whole subjects
++ 12 rows of a 26th), bf16 MFMA encoder/decoder with fp32 ELBO accumulation, inputs resident in HBM.  Weak scaling:
+every rank holds its own data shard and processes its own 512-row batch; the global batch at N = 8 is 4096 rows
+(configs[2]'s shape).  The other BASELINE configs at N = 1 (their lines are kept under profiles/):
+
+    configs[2]  --workload d4 --rows 100000 --batch 4096            100k-sample D4, the whole global batch on one GPU
+    configs[3]  --workload tabular --rows 1000000 --batch 4096      64 mixed-type features (16 real / 16 pos / 8 count / 16 cat5 /
+                                                                    8 ordinal5, interleaved), 1 M rows
+    configs[4]  --workload d4 --rows 50000 --batch 1024 --kl gp     GP-prior KL (L = 32, M = 120) alongside the HIP decoder
+
+--rows and --batch are PER GPU.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -31,8 +38,7 @@ sys.path.insert(0, ROOT)
 import hlvae_amd                                  # noqa: E402
 from hlvae_amd import synthetic                   # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-MFMA_BF16_PEAK_TFLOPS = 2500.0
+T_SUBJECT = {"d4": 20, "tabular": 16}
 
 
 def parse():
@@ -40,15 +46,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--workload", default="d4", choices=["d4", "tabular"])
+    ap.add_argument("--rows", type=int, default=None, help="rows of the synthetic data set PER GPU (default 1000)")
+    ap.add_argument("--batch", type=int, default=512, help="rows per step PER GPU")
     ap.add_argument("--kl", default="normal", choices=["normal", "gp", "none"])
-    ap.add_argument("--prefetch", action="store_true",
-                    help="run the NEXT batch's input stage on a side stream inside each step (measured slower on MI355X: a forked "
-                         "branch in the HIP graph costs more than the 31 us it hides; DESIGN.md section 5)")
     ap.add_argument("--feed", default="compact", choices=["fp64", "compact"],
                     help="compact (default): the whole dataset resident in HBM at 5 B/entry, a batch = a vector of row indices, "
                          "the input stage gathers on the device (SURVEY 8(f).3; bit-identical packed inputs, tested); fp64: "
                          "the reference's expanded fp64 batch tensors resident in HBM (the drop-in HLVAE.forward call surface)")
+    ap.add_argument("--prefetch", action="store_true", help="fp64 feed only: the next batch's input stage on a torch side stream")
     ap.add_argument("--conv", action="store_true",
                     help="convolutional encoder/decoder (conv_hivae = True, what config/hlvae_config_file.txt:51 selects) "
                          "instead of the MLP the north star names")
@@ -58,35 +64,63 @@ def parse():
                          "step's backward pass")
     ap.add_argument("--no-graph-chain", dest="graph_chain", action="store_false",
                     help="one HIP graph per step (default: the 4-batch ring is also captured as one graph of 4 steps)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="N = 1: run the data-parallel optimiser path (flat sharded Adam -> bf16 copy -> shadows) instead of the "
+                         "fused tile Adam, to price the code path the multi-GPU step uses")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--tag", default=None, help="label copied into config.tag (profiles/ bookkeeping)")
     return ap.parse_args()
 
 
-def build_batches(src, batch, n_ring, dev):
-    """resident ring of batches: consecutive row windows (rows are sorted by subject)"""
+def make_source(a, rank):
+    """the synthetic data set of this rank (its shard of the subjects): compact form above 2000 rows"""
+    rows = a.rows if a.rows is not None else 1000
+    T = T_SUBJECT[a.workload]
+    n_subj = (rows + T - 1) // T
+    expanded = rows <= 2000 or a.feed == "fp64"
+    if expanded and rows > 20000:
+        raise SystemExit(f"--feed fp64 needs the expanded fp64 matrices on the host: {rows} rows is too many, use --feed compact")
+    if a.workload == "d4":
+        return synthetic.make_d4(n_subjects=n_subj, T=T, seed=100 + rank, expanded=expanded), n_subj
+    if a.conv:
+        raise SystemExit("--conv views the variables as a 36 x 36 image: D4 workload only")
+    return synthetic.make_tabular(n_rows=n_subj * T, T=T, seed=100 + rank, expanded=expanded), n_subj
+
+
+def build_ring(src, batch, n_ring):
+    """resident ring of batches: row windows spread over the data set (rows are sorted by subject, so a window is whole
+    subjects plus the head of one more -- the reference's sampler semantics, utils.py:77-97)"""
+    from hlvae_amd.datafeed import subject_index
     N = len(src)
+    if batch > N:
+        raise SystemExit(f"--batch {batch} exceeds the {N} rows of the data set (--rows)")
     out = []
     for i in range(n_ring):
         lo = (i * (N - batch) // max(n_ring - 1, 1)) if N > batch else 0
-        rows = np.arange(lo, min(lo + batch, N))
-        P_b = int(np.unique(src.labels[rows, src.id_covariate]).size)
-        out.append(dict(data=torch.tensor(src.data[rows], dtype=torch.float64, device=dev),
-                        mask=torch.tensor(src.mask[rows], dtype=torch.float64, device=dev),
-                        labels=torch.tensor(src.labels[rows], dtype=torch.float64, device=dev), P_batch=P_b, rows=rows))
+        rows = np.arange(lo, lo + batch)
+        ids = src.labels[rows, src.id_covariate]
+        out.append(dict(rows=rows, P_batch=int(np.unique(ids).size), groups=subject_index(ids)))
     return out
 
 
-def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps, conv=False):
-    """The oracle (CPU fp64 restatement, kind "port") executing the training.py:70-137 sequence:
-    forward, NLL, per-step metrics, KL, backward, Adam -- on the host cores of this box."""
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps, conv=False, gp_state=None, budget_s=45.0):
+    """The oracle (CPU fp64 restatement, kind "port") executing the training.py:70-137 sequence -- forward, NLL, per-step
+    metrics, KL (N(0, I) closed form or the GP prior + natural gradient), backward, Adam -- on ALL host cores of this box
+    (3 warm-ups, >= 10 timed steps, median; fewer timed steps only if they would exceed the budget)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hlvae_oracle as orc
     import metrics_oracle as mo
-    # a one-GPU box shares its host: 16 threads is this process's CPU share (more threads only thrash on
-    # the many small fp64 ops of the step)
-    cores = min(os.cpu_count() or 1, 16)
+    cores = host_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: {cores} host cores (torch threads)", file=sys.stderr, flush=True)
     st = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in state.items()
           if not k.startswith(("hidden.", "Decoder_Conv_layer."))}
     for k in list(st):
@@ -99,10 +133,25 @@ def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps, conv=False
     params = [st[k] for k in names]
     m1 = [torch.zeros_like(p) for p in params]
     m2 = [torch.zeros_like(p) for p in params]
-    data, mask = torch.tensor(src.data[rows]), torch.tensor(src.mask[rows])
+    if hasattr(src, "expand_rows"):
+        d_np, m_np = src.expand_rows(rows)
+    else:
+        d_np, m_np = src.data[rows], src.mask[rows]
+    data, mask = torch.tensor(d_np), torch.tensor(m_np)
+    labels = torch.tensor(src.labels[rows])
     g = torch.Generator().manual_seed(0)
-    times = []
-    for it in range(steps + 1):
+    gpo = None
+    if kl == "gp":
+        import gp_oracle as gpo
+        spec, kprm, gm_, gH_, z_, noise, N_total, id_cov = gp_state
+        kprm = {k: v.clone().requires_grad_(True) for k, v in kprm.items()}
+        z_ = z_.clone().requires_grad_(True)
+        gp_leaves = list(kprm.values()) + [z_]
+        gp_m1, gp_m2 = [torch.zeros_like(p) for p in gp_leaves], [torch.zeros_like(p) for p in gp_leaves]
+    times, warm = [], 3
+
+    def one(it):
+        nonlocal gm_, gH_
         t0 = time.perf_counter()
         for p in params:
             p.grad = None
@@ -113,14 +162,33 @@ def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps, conv=False
         loss = nll * P_total / P_batch
         if kl == "normal":
             loss = loss + orc.standard_normal_kl(out["mu"], out["log_var"])
+        elif kl == "gp":
+            for p in gp_leaves:
+                p.grad = None
+            kld, grad_m, grad_H = gpo.minibatch_kld_upper_bound_iter(spec, kprm, noise, dims[2], gm_, gH_, labels, out["mu"],
+                                                                     out["log_var"], z_, P_total, P_batch, N_total, True, id_cov, 1e-6)
+            loss = loss + kld.sum()
         loss.backward()
         live = [i for i, p in enumerate(params) if p.grad is not None]       # torch.optim.Adam skips grad-less params
         orc.adam_step([params[i] for i in live], [params[i].grad for i in live], [m1[i] for i in live],
                       [m2[i] for i in live], it + 1)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times[1:]))
+        if kl == "gp":
+            orc.adam_step(gp_leaves, [p.grad for p in gp_leaves], gp_m1, gp_m2, it + 1)
+            gm_, gH_ = gpo.natural_gradient_update(gm_, gH_, grad_m.detach(), grad_H.detach(), 0.01)
+        return time.perf_counter() - t0
+
+    t_first = one(0)
+    n_timed = steps
+    if t_first * (warm + steps) > budget_s:
+        n_timed = max(3, int(budget_s / t_first) - warm)
+    for it in range(1, warm):
+        one(it)
+    for it in range(n_timed):
+        times.append(one(warm + it))
+    med = float(np.median(times))
     return dict(value=len(rows) / med, unit="samples/s", cores=cores, kind="port",
-                sample=f"{steps} steps (after 1 warm-up) of the same {len(rows)}-row batch, median {med:.3f} s/step, torch CPU fp64")
+                sample=f"{n_timed} timed steps after {warm} warm-ups of the same {len(rows)}-row batch, median {med:.3f} s/step, "
+                       f"torch CPU fp64, {cores} threads")
 
 
 def main():
@@ -134,65 +202,98 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    from hlvae_amd.parallel import DataParallel
     dp = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-        from hlvae_amd.parallel import DataParallel
         dp = DataParallel(dist.group.WORLD)
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    elif a.sharded:
+        dp = DataParallel.single()
 
     from hlvae_amd.HLVAE import HLVAE
     from hlvae_amd.training import ELBOTrainer
+    from hlvae_amd.datafeed import CompactDataset
 
-    src = synthetic.make_d4(n_subjects=50, T=20, seed=100 + rank)          # BASELINE configs[1]: 1k-sample set
+    src, n_subj = make_source(a, rank)
     dims = [src.cov_dim_ext, [500], 32, [500], 5]
     torch.manual_seed(0)                                                   # identical initial weights on all ranks
     model = HLVAE(dims, src.types_info, src.n_variables, conv=a.conv, max_batch=a.batch, materialize_samples=False).to(dev)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    P_total = 50 * world
+    P_total = n_subj * world
     kl = None if a.kl == "none" else a.kl
-    gp = None
+    gp = gp_state = None
     if kl == "gp":
         from hlvae_amd.elbo_functions import GPPriorHIP
-        gp = GPPriorHIP.from_reference_config(model, src, P_total, dev, dp=dp)       # shipped kernels, M = 120 inducing points
+        gp = GPPriorHIP.from_reference_config(model, src, P_total, dev, dp=dp if world > 1 else None)   # shipped kernels, M = 120
     trainer = ELBOTrainer(model, P_total=P_total, kl=kl, gp=gp, max_batch=a.batch, dp=dp, metrics=True)
-    ring = build_batches(src, a.batch, 4, dev)
-    use_graph = not a.no_graph and world == 1
-    # software pipeline of the input stage: while batch i trains, batch i+1 is normalised and packed on a side stream
-    # (row A depends on the data only).  Every step still runs exactly one input stage inside the timed region.
-    nxt = lambda i: (ring[(i + 1) % len(ring)]["data"], ring[(i + 1) % len(ring)]["mask"])
-    pipelined = a.prefetch
+    ring = build_ring(src, a.batch, 4)
+    compact = a.feed == "compact"
+    can_capture = world == 1 or backend == "nccl"                          # gloo's host-side collectives cannot be captured
+    use_graph = not a.no_graph and can_capture
     feed_pf = False
-    compact = a.feed == "compact" and kl != "gp"       # the GP variant takes the batch's covariates as a tensor (fp64 feed)
+    pipelined = a.prefetch and not compact
+    if gp is not None and rank == 0 and not a.no_cpu_baseline:            # GP state at step 0 for the CPU baseline
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import gp_oracle as gpo
+        spec = gpo.spec_from_config([2], [], [0], [{"cont_covariate": 0, "cat_covariate": 2}, {"cont_covariate": 0, "cat_covariate": 3},
+                                                   {"cont_covariate": 1, "cat_covariate": 4}], [], 2)
+        kprm = {}
+        for row, (which, t, f) in enumerate(gp.slot_names):
+            kprm[f"{which}.{t}.scale" if f is None else f"{which}.{t}.{f}.ls"] = gp.prm[row].detach().cpu().clone()
+        gp_state = (spec, kprm, gp.m.detach().cpu().clone(), gp.H.detach().cpu().clone(), gp.zt_list.detach().cpu().clone(),
+                    torch.ones(dims[2], dtype=torch.float64), float(gp.N_total), 2)
+
+    for b in ring:
+        b["rows_dev"] = torch.tensor(b["rows"].astype(np.int32), device=dev)
+        b["groups_dev"] = torch.tensor(b["groups"], device=dev) if kl == "gp" else None
+    PB = [b["P_batch"] * world for b in ring]
+    graph_note = None
     if compact:
-        from hlvae_amd.datafeed import CompactDataset
-        dsd = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
-        for b in ring:
-            b["rows_dev"] = torch.tensor(b["rows"].astype(np.int32), device=dev)
-        # pipelined input stage (MLP, single process): every step runs the statistics + pack kernels of the NEXT batch on
-        # the side stream of its backward pass (they depend on the data only) -- still exactly one input stage per step
-        # inside the timed region, but off the critical path
+        if hasattr(src, "raw"):
+            dsd = CompactDataset.from_raw(src.raw, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+        else:
+            dsd = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+        # pipelined input stage (MLP): every step runs the statistics + pack kernels of the NEXT batch beside its backward pass
+        # (they depend on the data only; with several ranks the statistics all-reduce rides on the same side stream) -- still
+        # exactly one input stage per step inside the timed region, but off the critical path
         feed_pf = use_graph and a.feed_prefetch and not a.conv
         if use_graph:
             R = [b["rows_dev"] for b in ring]
-            PB = [b["P_batch"] * world for b in ring]
+            Gr = [b["groups_dev"] for b in ring]
             nx = [R[(i + 1) % len(ring)] for i in range(len(ring))]
-            for i in range(len(ring)):
-                trainer.capture_rows(i, dsd, R[i], PB[i], next_rows=nx[i] if feed_pf else None)
-            if a.graph_chain:      # the whole ring (4 consecutive steps, one per batch) as ONE graph; a replay = 4 steps
-                trainer.capture_rows("ring", dsd, R, PB, next_rows=nx if feed_pf else None)
-            if feed_pf:
+            try:
+                for i in range(len(ring)):
+                    trainer.capture_rows(i, dsd, R[i], PB[i], next_rows=nx[i] if feed_pf else None, groups=Gr[i])
+                if a.graph_chain:      # the whole ring (4 consecutive steps, one per batch) as ONE graph; a replay = 4 steps
+                    trainer.capture_rows("ring", dsd, R, PB, next_rows=nx if feed_pf else None, groups=Gr)
+                ok = 1
+            except Exception as e:     # noqa: BLE001 -- a failed capture must not cost the whole measurement
+                ok, graph_note = 0, f"capture failed: {type(e).__name__}: {e}"
+            if world > 1:              # every rank replays graphs, or none does
+                t = torch.tensor([ok], device=dev, dtype=torch.int32)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+                ok = int(t.item())
+            if not ok:
+                use_graph = feed_pf = False
+                graph_note = graph_note or "capture failed on another rank"
+                print(f"[bench] rank {rank}: HIP-graph capture unavailable ({graph_note}); launching eagerly", file=sys.stderr, flush=True)
+            elif feed_pf:
                 trainer.prime_rows(dsd, R[0])
-    elif use_graph:
-        for i, b in enumerate(ring):
-            trainer.capture(i, b["data"], b["mask"], b["P_batch"] * world, train_x=b["labels"],
-                            prefetch=nxt(i) if pipelined else None)
-        if pipelined:
-            trainer.prime(ring[0]["data"], ring[0]["mask"])
+    else:
+        for b in ring:
+            b["data"] = torch.tensor(src.data[b["rows"]], dtype=torch.float64, device=dev)
+            b["mask"] = torch.tensor(src.mask[b["rows"]], dtype=torch.float64, device=dev)
+            b["labels"] = torch.tensor(src.labels[b["rows"]], dtype=torch.float64, device=dev)
+        nxt = lambda i: (ring[(i + 1) % len(ring)]["data"], ring[(i + 1) % len(ring)]["mask"])
+        if use_graph:
+            for i, b in enumerate(ring):
+                trainer.capture(i, b["data"], b["mask"], PB[i], train_x=b["labels"], prefetch=nxt(i) if pipelined else None)
+            if pipelined:
+                trainer.prime(ring[0]["data"], ring[0]["mask"])
 
     it = [0]                                   # the batch chain continues across warm-up and the timed region
-
     chain = use_graph and compact and a.graph_chain
 
     def run(n):
@@ -210,10 +311,9 @@ def main():
             if use_graph:
                 trainer.replay(i % len(ring))
             elif compact:
-                trainer.step_rows(dsd, b["rows_dev"], b["P_batch"] * world)
+                trainer.step_rows(dsd, b["rows_dev"], PB[i % len(ring)], groups=b["groups_dev"])
             else:
-                trainer.step(b["data"], b["mask"], b["P_batch"] * world, train_x=b["labels"],
-                             prefetch=nxt(i) if pipelined else None)
+                trainer.step(b["data"], b["mask"], PB[i % len(ring)], train_x=b["labels"], prefetch=nxt(i) if pipelined else None)
 
     run(a.warmup)
     torch.cuda.synchronize()
@@ -231,45 +331,57 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    rows_per_step = sum(len(ring[i % len(ring)]["rows"]) for i in range(a.steps)) / a.steps
-    value = world * rows_per_step * a.steps / dt
+    value = world * a.batch * a.steps / dt
     nll_last = float(trainer.scalars()["nll_sum"])
     assert np.isfinite(nll_last), "non-finite NLL after the timed steps"
+    if gp is not None:
+        assert int(gp.fail.item()) == 0, "GP prior: a non-positive pivot in an SPD inversion during the timed steps"
 
     if rank == 0:
         print(f"[bench] {world} GPU(s): {value:.0f} samples/s, {1e3 * dt / a.steps:.4f} ms/step", file=sys.stderr, flush=True)
     from hlvae_amd import roofline
     # every rank runs the eager per-kernel pass (the data-parallel step contains collectives); rank 0 reports
-    roof = roofline.measure_dominant_kernel(trainer, ring[0], a.steps, ds=dsd if compact else None)
+    roof = roofline.measure_dominant_kernel(trainer, ring[0], a.steps, ds=dsd if compact else None, P_batch=PB[0])
     if rank != 0:
         roof = None
-    if roof is not None:      # HBM traffic from PMC counters is collected offline (separate rocprofv3 --pmc passes)
+    workload_key = f"{a.workload}_b{a.batch}" + ("_conv" if a.conv else "") + (f"_{a.kl}" if a.kl != "normal" else "")
+    if roof is not None:      # HBM traffic from PMC counters is collected offline (separate rocprofv3 --pmc passes, tools/pmc_traffic.py)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
-            if roof["kernel"] in pm and not a.conv and kl != "gp":
-                roof["traffic"] = pm[roof["kernel"]]["traffic_bytes_per_launch"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+            k = pm.get(workload_key, {}).get("kernels", {})
+            if roof["kernel"] in k:
+                roof["traffic"] = k[roof["kernel"]]["traffic_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r2_pmc_traffic.json:" + workload_key
         except Exception:
             pass
-
     if rank == 0:
         print(f"[bench] roofline: {json.dumps(roof)}", file=sys.stderr, flush=True)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(src, dims, state0, ring[0]["rows"], P_total, ring[0]["P_batch"], kl, a.cpu_steps, conv=a.conv)
+        cpu = cpu_baseline(src, dims, state0, ring[0]["rows"], P_total, ring[0]["P_batch"], kl, a.cpu_steps, conv=a.conv, gp_state=gp_state)
 
     if rank == 0:
+        T = T_SUBJECT[a.workload]
+        if a.workload == "d4":
+            what = (f"synthetic D4 Het-HealthMNIST set, {n_subj * T} rows/GPU ({n_subj} subjects x {T}; 324 real + 972 cat5, 25 pct missing), "
+                    + ("convolutional encoder/decoder (conv 1-16-32 + 2592-500-32 | 32-500-2592 + deconv 32-16-5), " if a.conv
+                       else "MLP [5184,[500],32,[500],5], "))
+        else:
+            what = (f"synthetic mixed-type tabular longitudinal set, {n_subj * T} rows/GPU, 64 features (16 real / 16 pos / 8 count / "
+                    "16 cat5 / 8 ordinal5, interleaved, 25 pct missing), MLP [160,[500],32,[500],5], ")
+        cfg_name = {("d4", 512, "normal"): "configs[1]", ("d4", 4096, "normal"): "configs[2] at N=1", ("tabular", 4096, "normal"): "configs[3] at N=1",
+                    ("d4", 1024, "gp"): "configs[4]"}.get((a.workload, a.batch, a.kl), "custom")
         line = {
             "metric": "ELBO-steps/sec (samples/sec) on Het-HealthMNIST", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic 1k-sample D4 Het-HealthMNIST set (324 real + 972 cat5, 25 pct missing), "
-                                   + ("convolutional encoder/decoder (conv 1-16-32 + 2592-500-32 | 32-500-2592 + deconv 32-16-5), "
-                                      if a.conv else "MLP [5184,[500],32,[500],5], ")
-                                   + f"batch {a.batch} rows/GPU, "
+            "config": {"workload": f"{cfg_name}: " + what + f"batch {a.batch} rows/GPU, "
                                    + ("compact dataset (5 B/entry) resident in HBM, batches = row-index vectors" if compact
                                       else "fp64 inputs resident in HBM"),
-                       "kl": a.kl, "hip_graph": use_graph, "steps_per_graph_launch": (len(ring) if chain else 1), "input_stage_prefetch": bool(pipelined or (compact and feed_pf)), "rows_per_step_per_gpu": rows_per_step,
-                       "final_nll_sum": nll_last},
+                       "kl": a.kl, "hip_graph": use_graph, "steps_per_graph_launch": (len(ring) if chain else 1),
+                       "input_stage_prefetch": bool(pipelined or (compact and feed_pf)), "rows_per_step_per_gpu": a.batch,
+                       "optimizer": "fused tile Adam" if dp is None else f"reduce-scatter + sharded Adam + bf16 all-gather (world {world})",
+                       "final_nll_sum": nll_last, **({"graph_note": graph_note} if graph_note else {}), **({"tag": a.tag} if a.tag else {})},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

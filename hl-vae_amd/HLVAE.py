@@ -28,6 +28,7 @@ from .layout import (KIND_CAT, KIND_COUNT, KIND_ORDINAL, KIND_POS, KIND_REAL, Co
 
 
 _INPUT_STAGE = ("sums", "norm", "xn", "xnT", "xt", "m8")
+GRAD_SLACK = 4096        # floats behind the gradient arena (hlvae_amd.parallel.ShardPlan.pad <= world * 32)
 
 
 def _ru(v, m):
@@ -218,6 +219,7 @@ class HLVAE(nn.Module):
         self._fwd_token = 0
         self._block_cols = None
         self._grad_region_clean = True
+        self._master_sync = None
 
     # ------------------------------------------------------------------ arena / parameters
     def _bind_arena(self, arena: torch.Tensor):
@@ -254,6 +256,13 @@ class HLVAE(nn.Module):
                 p.requires_grad_(r)
             self._anchor = torch.zeros((), requires_grad=True, device=probe.device)
         return self
+
+    def state_dict(self, *a, **k):
+        """under the sharded data-parallel optimiser a rank's fp32 masters are current for its own slices only: gather
+        the others first (hlvae_amd.parallel.ShardedState.sync_masters, a collective: call on every rank)"""
+        if getattr(self, "_master_sync", None) is not None:
+            self._master_sync()
+        return super().state_dict(*a, **k)
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         sd = {k: v.to(torch.float32) for k, v in state_dict.items()}
@@ -305,6 +314,10 @@ class HLVAE(nn.Module):
         d.o_wd, d.o_bd = ao(self.d_layers[0].weight), ao(self.d_layers[0].bias)
         d.o_wy, d.o_by = ao(self.y_layer[0].weight), ao(self.y_layer[0].bias)
         d.arena_size, d.atomic_region = self._arena_size, self._atomic_region
+        d.frozen_lo = d.frozen_hi = 0
+        if not self._log_vy_real.requires_grad and not self._log_vy_pos.requires_grad:      # vy_fixed (HLVAE.py:209-216)
+            d.frozen_lo = ao(self._log_vy_real)                   # the two tensors are neighbours at the start of the arena
+            d.frozen_hi = _ru(ao(self._log_vy_pos) + self._log_vy_pos.numel(), 4)
         _lib.load().hlvae_dims_fill(C.byref(d))
         return d
 
@@ -368,7 +381,7 @@ class HLVAE(nn.Module):
         S_d = pick(ksteps_d, (Bp // 64) * (d.hdp // 64))
         NT = (d.D + 15) // 16
         t = dict(
-            G=z(self._arena_size, dt=f32),
+            G=z(self._arena_size + GRAD_SLACK, dt=f32),      # tail slack: the padded extent of the last reduce-scatter slice
             w1s=z(d.hep, d.Xep), wmls=z(2 * d.Lp, d.hep), wmlTs=z(d.hep, 2 * d.Lp), wds=z(d.hdp, d.Lp),
             wdTs=z(d.Lp, d.hdp), wys=z(d.NYlp if d.conv else d.NYl, d.hdp), wyTs=z(d.hdp, d.NYlp),
             sums=z(_lib.STAT_CHUNKS, 3, max(d.n_stat, 1), dt=torch.float64), norm=z(2, max(d.n_stat, 1), dt=f32),

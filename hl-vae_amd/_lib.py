@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 STAT_CHUNKS = 16
 
 _vp = C.c_void_p
@@ -25,7 +25,7 @@ class HlvaeDims(C.Structure):
                                             "Xp", "hep", "hdp", "Lp", "NY", "NYp", "n_stat", "Xe", "Xep", "NYl", "NYlp")]
                 + [(n, C.c_int64) for n in ("o_w1", "o_b1", "o_wmu", "o_bmu", "o_wlv", "o_blv", "o_wd", "o_bd",
                                             "o_wy", "o_by", "o_c1w", "o_c1b", "o_c2w", "o_c2b", "o_t1w", "o_t1b", "o_t2w", "o_t2b",
-                                            "o_cv_lo", "cv_n", "arena_size", "atomic_region")])
+                                            "o_cv_lo", "cv_n", "arena_size", "atomic_region", "frozen_lo", "frozen_hi")])
 
 
 WS_POINTERS = ("P", "G", "w1s", "wmls", "wmlTs", "wds", "wdTs", "wys", "wyTs", "sums", "norm", "xn", "xnT", "xt", "m8",
@@ -84,6 +84,11 @@ _SIGS = {
                                   C.c_float, _vp]),
     "hlvae_backward_adam": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_float, C.c_int, _vp, _vp, _vp, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.c_float, _vp]),
+    "hlvae_adam_shard": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, C.c_float, _vp]),
+    "hlvae_adam_small": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   _vp]),
+    "hlvae_shadows_from_bf16": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int64, C.c_uint, _vp]),
     "hlvae_gp_kernel_matrix": (C.c_int, [C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp,
                                          C.c_int, C.c_int, C.c_double, _vp, _vp]),
     "hlvae_gp_chol_inv": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

@@ -33,6 +33,9 @@ int hl_launch_transpose_bf16(const bf16_t*, int, bf16_t*, int, int, int, const c
 int hl_adam_grid(const hlvae_plan*, const hlvae_ws*, unsigned, int);
 int hl_adam_part(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, unsigned, int,
                  unsigned, const char*, hipStream_t);
+int hl_adam_flat(const hlvae_plan*, const hlvae_ws*, const float*, float*, float*, uint16_t*, const int64_t*, long, long, float, float,
+                 float, float, float, hipStream_t);
+int hl_shadows_from_bf16(const hlvae_plan*, const hlvae_ws*, const uint16_t*, unsigned, const char*, hipStream_t);
 
 static thread_local char g_err[512] = "";
 void hl_set_error(const char* fmt, ...) {
@@ -520,6 +523,30 @@ int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m
     if (int rc = hl_adam_part(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, 0x01, 0, 0u, "adam_wy_early", (hipStream_t)s))
         return rc;
     return hl_adam(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, (hipStream_t)s, 1);
+}
+
+int hlvae_adam_shard(const hlvae_plan* p, const hlvae_ws* ws, const float* grad_shard, float* m1, float* m2, uint16_t* pb16_shard,
+                     const int64_t* step_count, int64_t lo, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float grad_scale, hlvae_stream s) {
+    HL_REQUIRE(p && ws && grad_shard && m1 && m2 && pb16_shard && step_count, HLVAE_EINVAL, "adam_shard: null argument");
+    // the kernel indexes master / m / v by arena element and the two compact buffers from 0
+    return hl_adam_flat(p, ws, grad_shard, m1, m2, pb16_shard - lo, step_count, (long)lo, (long)n, lr, beta1, beta2, eps, grad_scale,
+                        (hipStream_t)s);
+}
+
+int hlvae_adam_small(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float beta1,
+                     float beta2, float eps, float grad_scale, hlvae_stream s) {
+    HL_REQUIRE(p && ws && m1 && m2 && step_count, HLVAE_EINVAL, "adam_small: null argument");
+    return hl_adam_part(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, 0u, 1, (unsigned)hl_adam_grid(p, ws, 0u, 1),
+                        "adam_small", (hipStream_t)s);
+}
+
+int hlvae_shadows_from_bf16(const hlvae_plan* p, const hlvae_ws* ws, const uint16_t* pb16, int64_t base, unsigned which,
+                            hlvae_stream s) {
+    HL_REQUIRE(p && ws && pb16, HLVAE_EINVAL, "shadows_from_bf16: null argument");
+    HL_REQUIRE(which != 0 && (which & ~0x1fu) == 0 && base % 4 == 0, HLVAE_EINVAL, "shadows_from_bf16: which=0x%x base=%ld", which,
+               (long)base);
+    return hl_shadows_from_bf16(p, ws, pb16 - base, which, which == 0x01 ? "shadows_wy" : "shadows_rest", (hipStream_t)s);
 }
 
 int hlvae_gemm_nt_f32(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int ldc, int M, int N, int K,

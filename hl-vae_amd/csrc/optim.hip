@@ -35,10 +35,14 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
                                                            float* __restrict__ M1, float* __restrict__ M2,
                                                            int64_t* __restrict__ step_count, float lr, float b1,
                                                            float b2, float eps, float gscale, int update, long n4_flat,
-                                                           unsigned ticket_total) {
+                                                           unsigned ticket_total, const bf16_t* __restrict__ Pb16,
+                                                           long frozen_lo4, long frozen_hi4) {
     // update: 0 = shadows only; 1 = Adam with step number step_count[0] + 1.  Workgroups past the tiles (if the launch
     // has any) update the small flat region [0, 4 n4_flat) and zero its gradients.  ticket_total = workgroups of ALL the
     // launches of this optimiser step (0: this launch takes no tickets).
+    // Pb16 != nullptr (update == 0 only): the shadows are built from the flat bf16 copy of the arena that the sharded
+    // optimiser all-gathers (data parallel) instead of from the fp32 masters.  [frozen_lo4, frozen_hi4): float4 range of the
+    // flat region whose parameters do not train (vy_fixed, reference HLVAE.py:209-211): gradients cleared, nothing updated.
     constexpr int T = 64, CLD = T + 1;
     __shared__ float tile[T * CLD];
     if ((int)blockIdx.x >= set.total_tiles) {                       // flat region (update == 1 only)
@@ -49,6 +53,10 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
         float4* M24 = reinterpret_cast<float4*>(M2);
         const long nfb = (long)gridDim.x - set.total_tiles;
         for (long i = ((long)blockIdx.x - set.total_tiles) * HL_THREADS + threadIdx.x; i < n4_flat; i += nfb * HL_THREADS) {
+            if (i >= frozen_lo4 && i < frozen_hi4) {              // torch.optim.Adam skips parameters without a gradient
+                G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                continue;
+            }
             float4 p = P4[i], g = G4[i], m = M14[i], v = M24[i];
             p.x = adam_one(p.x, g.x, m.x, v.x, a);
             p.y = adam_one(p.y, g.y, m.y, v.y, a);
@@ -93,6 +101,20 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
     const bool vec = (mt.C & 3) == 0;
     const int nv = min(4, mt.C - (c0 + c4));
     auto ld4 = [&](const float* b, long off) -> float4 {
+        if (Pb16 != nullptr) {                                  // (block-uniform) bf16 source, same indexing
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vec) {
+                const uint2 q = *reinterpret_cast<const uint2*>(Pb16 + off);
+                r.x = bf2f((bf16_t)(q.x & 0xffff)); r.y = bf2f((bf16_t)(q.x >> 16));
+                r.z = bf2f((bf16_t)(q.y & 0xffff)); r.w = bf2f((bf16_t)(q.y >> 16));
+                return r;
+            }
+            if (nv > 0) r.x = bf2f(Pb16[off]);
+            if (nv > 1) r.y = bf2f(Pb16[off + 1]);
+            if (nv > 2) r.z = bf2f(Pb16[off + 2]);
+            if (nv > 3) r.w = bf2f(Pb16[off + 3]);
+            return r;
+        }
         if (vec) return *reinterpret_cast<const float4*>(b + off);
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (nv > 0) r.x = b[off];
@@ -222,7 +244,8 @@ int hl_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s) {
     if (int rc = check_set(set)) return rc;
     {
         HL_PROF("shadow_cast", s);
-        k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 0u);
+        k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 0u,
+                                                            nullptr, 0, 0);
         HL_LAUNCH_CHECK();
     }
     if (p->d.conv) return hl_conv_pack_weights(p, ws, s);
@@ -254,7 +277,8 @@ int hl_adam_part(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, 
     {
         HL_PROF(label, s);
         k_adam_tiled<<<grid, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 1,
-                                                 with_flat ? d.atomic_region / 4 : 0, ticket_total);
+                                                 with_flat ? d.atomic_region / 4 : 0, ticket_total, nullptr, d.frozen_lo / 4,
+                                                 (d.frozen_hi + 3) / 4);
         HL_LAUNCH_CHECK();
     }
     if (with_flat && d.conv) return hl_conv_pack_weights(p, ws, s);   // the convolution weights live in the flat region
@@ -267,4 +291,77 @@ int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64
     const unsigned which = skip_wy ? 0x1e : 0x1f;
     return hl_adam_part(p, ws, m1, m2, step_count, lr, b1, b2, eps, gscale, which, 1, (unsigned)hl_adam_grid(p, ws, which, 1),
                         skip_wy ? "adam_weights_shadows" : "adam_all_in_one", s);
+}
+
+
+// ---- sharded optimiser (data parallel; hl-vae_amd/parallel.py) ------------------------------------------------------------
+// Every rank owns one contiguous slice of the DENSE part of the arena [atomic_region, arena_size).  Its gradients arrive
+// from the reduce-scatter as a compact fp32 buffer; the rank updates master / m / v of the slice only (1 / world of the
+// optimiser's HBM traffic) and leaves a bf16 copy of the updated values in the flat bf16 arena that the all-gather then
+// completes on every rank; hl_shadows_from_bf16 turns that arena into the padded shadows the MFMA kernels read.
+__global__ __launch_bounds__(HL_THREADS) void k_adam_flat(float* __restrict__ P, const float* __restrict__ gsh,
+                                                          float* __restrict__ M1, float* __restrict__ M2,
+                                                          bf16_t* __restrict__ Pb, long lo4, long n4,
+                                                          const int64_t* __restrict__ step_count, float lr, float b1, float b2,
+                                                          float eps, float gscale) {
+    const AdamScalars a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
+    float4* P4 = reinterpret_cast<float4*>(P) + lo4;
+    const float4* G4 = reinterpret_cast<const float4*>(gsh);
+    float4* M14 = reinterpret_cast<float4*>(M1) + lo4;
+    float4* M24 = reinterpret_cast<float4*>(M2) + lo4;
+    uint2* B4 = reinterpret_cast<uint2*>(Pb) + lo4;
+    // two float4 per lane and pass: 8 loads in flight before the first store
+    const long stride = (long)gridDim.x * HL_THREADS;
+    for (long i = (long)blockIdx.x * HL_THREADS + threadIdx.x; i < n4; i += 2 * stride) {
+        const long j = i + stride;
+        const bool two = j < n4;
+        float4 p0 = P4[i], g0 = G4[i], m0 = M14[i], v0 = M24[i];
+        float4 p1 = p0, g1 = g0, m1 = m0, v1 = v0;
+        if (two) { p1 = P4[j]; g1 = G4[j]; m1 = M14[j]; v1 = M24[j]; }
+        auto upd = [&](float4& p, const float4& g, float4& m, float4& v) {
+            p.x = adam_one(p.x, g.x, m.x, v.x, a);
+            p.y = adam_one(p.y, g.y, m.y, v.y, a);
+            p.z = adam_one(p.z, g.z, m.z, v.z, a);
+            p.w = adam_one(p.w, g.w, m.w, v.w, a);
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(p.x) | ((uint32_t)f2bf(p.y) << 16);
+            pk.y = (uint32_t)f2bf(p.z) | ((uint32_t)f2bf(p.w) << 16);
+            return pk;
+        };
+        const uint2 k0 = upd(p0, g0, m0, v0);
+        P4[i] = p0; M14[i] = m0; M24[i] = v0; B4[i] = k0;
+        if (two) {
+            const uint2 k1 = upd(p1, g1, m1, v1);
+            P4[j] = p1; M14[j] = m1; M24[j] = v1; B4[j] = k1;
+        }
+    }
+}
+
+int hl_adam_flat(const hlvae_plan* p, const hlvae_ws* ws, const float* gsh, float* m1, float* m2, uint16_t* pb16,
+                 const int64_t* step_count, long lo, long n, float lr, float b1, float b2, float eps, float gscale, hipStream_t s) {
+    const hlvae_dims& d = p->d;
+    HL_REQUIRE(lo % 4 == 0 && n % 4 == 0 && lo >= d.atomic_region && lo + n <= d.arena_size, HLVAE_ESHAPE,
+               "adam_flat: slice [%ld, +%ld) must be 4-aligned and inside the dense region [%ld, %ld)", lo, n,
+               (long)d.atomic_region, (long)d.arena_size);
+    if (n == 0) return 0;
+    const long n4 = n / 4;
+    long blocks = (n4 + 2 * HL_THREADS - 1) / (2 * HL_THREADS);
+    if (blocks > 2048) blocks = 2048;
+    HL_PROF("adam_flat_shard", s);
+    k_adam_flat<<<(int)blocks, HL_THREADS, 0, s>>>(ws->P, gsh, m1, m2, pb16, lo / 4, n4, step_count, lr, b1, b2, eps, gscale);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+// padded bf16 shadows (row-major + transposed) of the matrices `which` from the flat bf16 arena
+int hl_shadows_from_bf16(const hlvae_plan* p, const hlvae_ws* ws, const uint16_t* pb16, unsigned which, const char* label,
+                         hipStream_t s) {
+    const ShadowSet set = make_set(p, ws, which);
+    if (int rc = check_set(set)) return rc;
+    if (set.total_tiles == 0) return 0;
+    HL_PROF(label, s);
+    k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 0u,
+                                                        pb16, 0, 0);
+    HL_LAUNCH_CHECK();
+    return 0;
 }

@@ -54,6 +54,14 @@ class CompactDataset:
         return cls(vals, np.ascontiguousarray(mask != 0).astype(np.uint8), np.asarray(labels, dtype=np.float64), types_info,
                    id_covariate)
 
+    @classmethod
+    def from_raw(cls, raw: np.ndarray, mask: np.ndarray, labels: np.ndarray, types_info: dict, id_covariate: int = 2) -> "CompactDataset":
+        """raw [N, D]: one number per variable -- the value (real / pos / count), the class index (cat, -1 = none) or
+        level - 1 (ordinal): what ``from_expanded`` folds the one-hot / thermometer columns into.  For data sets that are
+        never materialised in the expanded fp64 form (100 k rows of D4 = 4.1 GB of mostly zeros)."""
+        return cls(np.ascontiguousarray(raw, dtype=np.float32), np.ascontiguousarray(np.asarray(mask) != 0).astype(np.uint8),
+                   np.asarray(labels, dtype=np.float64), types_info, id_covariate)
+
     def __len__(self):
         return self.values.shape[0]
 
@@ -116,34 +124,80 @@ class DeviceDataset:
     host: CompactDataset
 
 
+def subject_index(ids: np.ndarray) -> np.ndarray:
+    """Subject structure of a batch for the GP prior (reference elbo_functions.py:242-252 walks ``torch.unique`` of the id
+    covariate): int32 [S, Tmax], row s = positions INSIDE THE BATCH of the rows of the s-th subject (sorted by id, as
+    torch.unique returns them), -1 = padding.  Host arithmetic on the sampler's side: no device round trip per step."""
+    ids = np.asarray(ids)
+    order = np.argsort(ids, kind="stable")
+    uniq, start, count = np.unique(ids[order], return_index=True, return_counts=True)
+    idx = -np.ones((len(uniq), int(count.max())), dtype=np.int32)
+    for s, (a, c) in enumerate(zip(start, count)):
+        idx[s, :c] = order[a:a + c]
+    return idx
+
+
+@dataclass
+class Batch:
+    """one training batch as the sampler hands it over: dataset rows, subjects of the GLOBAL batch, subject structure"""
+    rows: np.ndarray             # int32 [B] dataset rows of THIS rank
+    P_batch: int                 # subjects in the global batch (loss scale P / P_batch, training.py:121-122)
+    groups: np.ndarray           # int32 [S, Tmax] (subject_index of this rank's rows)
+
+    def to(self, device):
+        return (torch.as_tensor(self.rows, device=device), self.P_batch, torch.as_tensor(self.groups, device=device))
+
+
 class SubjectBatchSampler:
     """Batches of WHOLE subjects (the GP prior needs each subject's T x T block, elbo_functions.py:243-252).
 
     Every epoch: subjects in random order, the rows of a subject consecutive and in dataset order, ``subjects_per_batch``
     subjects per batch, last batch smaller (utils.py:53-97).  Data parallel: rank r of ``world`` takes subjects
     r, r + world, ... of every global batch; ``P_batch`` is the number of subjects of the GLOBAL batch (the loss scale
-    P / P_batch, training.py:121-122)."""
+    P / P_batch, training.py:121-122).  Every rank must take part in every global batch (the step contains collectives): a
+    last batch with fewer subjects than ranks is folded into the batch before it, identically on every rank."""
 
     def __init__(self, subject_ids: np.ndarray, subjects_per_batch: int, shuffle: bool = True, seed: int = 0, rank: int = 0,
-                 world: int = 1):
+                 world: int = 1, min_last: Optional[int] = None):
         ids = np.asarray(subject_ids)
-        uniq, first = np.unique(ids, return_index=True)
-        order = np.argsort(first, kind="stable")               # subjects in order of first appearance (utils.py:62-64)
-        self.subjects = uniq[order]
-        self.rows_of = [np.nonzero(ids == s)[0] for s in self.subjects]
+        self.min_last = world if min_last is None else min_last      # smallest last batch that stays a batch of its own
+        if subjects_per_batch < world:
+            raise ValueError(f"subjects_per_batch={subjects_per_batch} < world={world}: a rank would get no subject")
+        order = np.argsort(ids, kind="stable")                  # one sort instead of one scan per subject
+        uniq, start = np.unique(ids[order], return_index=True)
+        rows_sorted = np.split(order, start[1:])
+        first = np.array([r[0] for r in rows_sorted])           # subjects in order of first appearance (utils.py:62-64)
+        by_first = np.argsort(first, kind="stable")
+        self.subjects = uniq[by_first]
+        self.rows_of = [rows_sorted[i] for i in by_first]
+        self.subject_ids = ids
         self.P = len(self.subjects)
+        if self.P < world:
+            raise ValueError(f"{self.P} subjects for {world} ranks")
         self.subjects_per_batch, self.shuffle, self.rank, self.world = subjects_per_batch, shuffle, rank, world
-        self.rng = np.random.default_rng(seed)
+        self.rng = np.random.default_rng(seed)                  # same seed on every rank: identical global batches
+
+    def _bounds(self):
+        lo = list(range(0, self.P, self.subjects_per_batch))
+        hi = lo[1:] + [self.P]
+        if len(lo) > 1 and hi[-1] - lo[-1] < self.min_last:     # short tail: one larger last batch instead
+            lo.pop()
+            hi.pop(-2)
+        return list(zip(lo, hi))
 
     def __len__(self):
-        return (self.P + self.subjects_per_batch - 1) // self.subjects_per_batch
+        return len(self._bounds())
 
-    def __iter__(self) -> Iterator[Tuple[np.ndarray, int]]:
+    def batches(self) -> Iterator[Batch]:
         r = np.arange(self.P)
         if self.shuffle:
             self.rng.shuffle(r)
-        for lo in range(0, self.P, self.subjects_per_batch):
-            batch = r[lo:lo + self.subjects_per_batch]
+        for lo, hi in self._bounds():
+            batch = r[lo:hi]
             mine = batch[self.rank::self.world]
-            rows = np.concatenate([self.rows_of[s] for s in mine]) if len(mine) else np.zeros(0, dtype=np.int64)
-            yield rows.astype(np.int32), len(batch)
+            rows = np.concatenate([self.rows_of[s] for s in mine]).astype(np.int32)
+            yield Batch(rows, len(batch), subject_index(self.subject_ids[rows]))
+
+    def __iter__(self) -> Iterator[Tuple[np.ndarray, int]]:
+        for b in self.batches():
+            yield b.rows, b.P_batch

@@ -386,7 +386,11 @@ class GPPriorHIP:
         dev = mu.device
         c = float(P_total) / float(P_batch)
         x = train_x.contiguous()
-        idx = self._group(x)
+        # subject structure of the batch: [S, T] batch rows of each subject, -1 = padding.  The sampler knows it when it builds
+        # the batch (datafeed.subject_index, no device work); from a bare covariate tensor it costs a host round trip, cached
+        idx = groups if groups is not None else self._group(x)
+        if idx.dtype != torch.int32 or not idx.is_contiguous() or idx.dim() != 2:
+            raise ValueError("groups: contiguous int32 [S, T] tensor of batch-row indices, -1 = padding")
         S, T = idx.shape
         k0, k1, z = self.k0, self.k1, self.zt_list
         hyp = self._transform()

@@ -45,7 +45,7 @@ def gp_algorithmic_work(gp, B, S, T):
     return w
 
 
-def algorithmic_work(model, B):
+def algorithmic_work(model, B, trainer_world=1):
     """label -> (bytes, flops) per launch (algorithmic: every operand read once, every result written once)."""
     d = model._dims
     Bp = _ru(B, 128)
@@ -60,7 +60,8 @@ def algorithmic_work(model, B):
     w["mid_fwd_fused"] = (S_e * B * hep * 4 + 2 * B * hep * 2 + 2 * Lp * hep * 2 + B * L * 16 + hdp * Lp * 2 + 2 * B * hdp * 2,
                           2 * B * he * 2 * L + 2 * B * L * hd)
     w["dec1_relu"] = ((B * Lp + hdp * Lp) * 2 + 2 * B * hdp * 2, 2 * B * L * hd)
-    w["y_heads_loglik"] = ((B * hdp + NY * hdp) * 2 + B * D * 5 + 2 * B * NY * 2 + 2 * B * D * 4, 2 * B * NY * hd + 150 * B * D)
+    # U + Wy panels in, targets + mask in (5 B / entry), dY out in both layouts, log_p_x + log_p_x_missing + x_hat out
+    w["y_heads_loglik"] = ((B * hdp + NY * hdp) * 2 + B * D * 5 + 2 * B * NY * 2 + 3 * B * D * 4, 2 * B * NY * hd + 150 * B * D)
     w["metrics_partial"] = (B * D * 9, 0)
     w["metrics_finish"] = (16 * 6 * D * 4, 0)
     w["elbo_finalize"] = (((D + 15) // 16) * B * 4, 0)
@@ -81,6 +82,13 @@ def algorithmic_work(model, B):
     w["adam_weights_shadows"] = (n_rest * 28 + sh_rest + model._atomic_region * 32, 0)
     w["adam_all_in_one"] = ((n_wy + n_rest) * 28 + sh_wy + sh_rest + model._atomic_region * 32, 0)     # data-parallel path
     w["shadow_cast"] = ((n_wy + n_rest) * 4 + sh_wy + sh_rest, 0)
+    # sharded optimiser (data parallel; world 1 here unless the trainer says otherwise): 28 B + 2 B (bf16 copy) per owned
+    # parameter, then the shadows from the flat bf16 copy
+    world = trainer_world
+    w["adam_flat_shard"] = ((n_wy + n_rest) * 30 // (2 * world), 0)          # two launches per step (one per slice): the mean
+    w["adam_small"] = (model._atomic_region * 32, 0)
+    w["shadows_wy"] = (n_wy * 2 + sh_wy, 0)
+    w["shadows_rest"] = (n_rest * 2 + sh_rest, 0)
     if d.conv:      # csrc/conv.hip, per launch over the whole batch: activations in / out once; MACs x 2
         px = 36 * 36
         w["conv_enc_fwd"] = (B * (X + D) * 8 + B * px * 4 + 2 * B * Xe * 2 + B * D * 5, 2 * B * (px * 16 * 9 + 324 * 32 * 144))
@@ -101,7 +109,7 @@ def algorithmic_work(model, B):
     return w
 
 
-def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None):
+def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None, P_batch=None):
     """Run `steps` eager steps with the library's per-kernel HIP events on, find the kernel with the
     largest total time and price it against its roofline.  Returns the bench.py 'roofline' object
     (plus the per-kernel table for DESIGN.md / profiles)."""
@@ -109,13 +117,14 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None):
     m = trainer.model
     n = steps if eager_steps is None else eager_steps
     n = max(5, min(n, 100))
-    B = batch["data"].shape[0]
+    B = len(batch["rows"])
+    P_batch = batch["P_batch"] if P_batch is None else P_batch
     import torch
     def one():
         if ds is not None:
-            trainer.step_rows(ds, batch["rows_dev"], batch["P_batch"])
+            trainer.step_rows(ds, batch["rows_dev"], P_batch, groups=batch.get("groups_dev"))
         else:
-            trainer.step(batch["data"], batch["mask"], batch["P_batch"], train_x=batch.get("labels"))
+            trainer.step(batch["data"], batch["mask"], P_batch, train_x=batch.get("labels"))
 
     for _ in range(3):
         one()
@@ -126,13 +135,13 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None):
     lib.hlvae_prof_enable(0)
     buf = C.create_string_buffer(1 << 16)
     _lib.check(lib.hlvae_prof_report(buf, len(buf)), "hlvae_prof_report")
-    work = algorithmic_work(m, B)
+    work = algorithmic_work(m, B, trainer.dp.world if trainer.dp is not None else 1)
     if ds is not None:      # compact feed: 5 B per entry in instead of the expanded fp64 matrices
         d_ = m._dims
         work["normalize_pack"] = (B * d_.D * 5 + 2 * B * d_.Xp * 2 + B * d_.D * 5, 0)
         work["colstats"] = (B * d_.n_stat * 5, 0)
-    if getattr(trainer, "gp", None) is not None and batch.get("labels") is not None and hasattr(trainer.gp, "_group"):
-        S, T = trainer.gp._group(batch["labels"].contiguous()).shape
+    if getattr(trainer, "gp", None) is not None:
+        S, T = batch["groups"].shape
         work.update(gp_algorithmic_work(trainer.gp, B, S, T))
     table = {}
     for line in buf.value.decode().splitlines():

@@ -89,19 +89,27 @@ def _render_subjects(P: int, T: int, rng: np.random.Generator):
     yy, xx = np.meshgrid(np.arange(IMG, dtype=np.float64), np.arange(IMG, dtype=np.float64), indexing="ij")
     c = (IMG - 1) / 2.0
     shift = (t_age / 10.0)[None, :, None, None]
-    X0 = xx[None, None] - c - shift
-    Y0 = yy[None, None] - c - shift
-    ca, sa = np.cos(ang)[:, :, None, None], np.sin(ang)[:, :, None, None]
-    XR = ca * X0 + sa * Y0
-    YR = -sa * X0 + ca * Y0
-    img = np.zeros((P, T, IMG, IMG))
+    # every random draw happens here, for all subjects at once (the rendering below is chunked over subjects to bound the
+    # memory of the 100 k-row sets: 8 arrays of [chunk, T, 36, 36] instead of [P, T, 36, 36])
+    strokes = []
     for b in range(2):                                       # two strokes per subject
         cx = rng.uniform(-7, 7, (P, 1, 1, 1)) + (gender[:, None, None, None] * 2 - 1) * (3 - 6 * b)
         cy = rng.uniform(-7, 7, (P, 1, 1, 1))
         sx = rng.uniform(2.5, 9.0, (P, 1, 1, 1))
         sy = rng.uniform(2.0, 5.0, (P, 1, 1, 1))
-        img += np.exp(-0.5 * (((XR - cx) / sx) ** 2 + ((YR - cy) / sy) ** 2))
-    img = np.clip(np.rint(255.0 * img / img.max(axis=(2, 3), keepdims=True)), 0, 255)
+        strokes.append((cx, cy, sx, sy))
+    img = np.zeros((P, T, IMG, IMG))
+    for lo in range(0, P, 256):
+        hi = min(P, lo + 256)
+        X0 = xx[None, None] - c - shift
+        Y0 = yy[None, None] - c - shift
+        ca, sa = np.cos(ang[lo:hi])[:, :, None, None], np.sin(ang[lo:hi])[:, :, None, None]
+        XR = ca * X0 + sa * Y0
+        YR = -sa * X0 + ca * Y0
+        part = np.zeros((hi - lo, T, IMG, IMG))
+        for cx, cy, sx, sy in strokes:
+            part += np.exp(-0.5 * (((XR - cx[lo:hi]) / sx[lo:hi]) ** 2 + ((YR - cy[lo:hi]) / sy[lo:hi]) ** 2))
+        img[lo:hi] = np.clip(np.rint(255.0 * part / part.max(axis=(2, 3), keepdims=True)), 0, 255)
     pixels = img.reshape(P * T, IMG * IMG)
     subj = np.repeat(np.arange(P), T).astype(np.float64)
     labels = np.stack([
@@ -139,8 +147,9 @@ def expand(raw: np.ndarray, spec: List[Tuple[str, int]]) -> np.ndarray:
     return out
 
 
-def make_d4(n_subjects: int = 50, T: int = 20, missing: float = 0.25, seed: int = 100) -> HetBatchSource:
-    """D4 Het-HealthMNIST-shaped set: n_subjects*T rows x 1296 variables (324 real + 972 cat5)."""
+def make_d4(n_subjects: int = 50, T: int = 20, missing: float = 0.25, seed: int = 100, expanded: bool = True):
+    """D4 Het-HealthMNIST-shaped set: n_subjects*T rows x 1296 variables (324 real + 972 cat5).
+    expanded = False: a ``CompactSource`` (one number per variable, no one-hot matrix) for the 50 k / 100 k-row sets."""
     rng = np.random.default_rng(seed)
     px, labels = _render_subjects(n_subjects, T, rng)
     spec = d4_type_spec()
@@ -149,11 +158,11 @@ def make_d4(n_subjects: int = 50, T: int = 20, missing: float = 0.25, seed: int 
     for r in (r2, r3, r4):
         raw[:, r] = quantise5(px[:, r].astype(np.int64))
     mask = (rng.random(raw.shape) >= missing).astype(np.float64)
-    return _finish(raw, mask, labels, spec)
+    return _finish(raw, mask, labels, spec) if expanded else _finish_compact(raw, mask, labels, spec)
 
 
 def make_tabular(n_rows: int = 4096, T: int = 16, missing: float = 0.25, seed: int = 100,
-                 spec: List[Tuple[str, int]] | None = None) -> HetBatchSource:
+                 spec: List[Tuple[str, int]] | None = None, expanded: bool = True):
     """BASELINE.json config 4 mix: real~N(mu_d, s_d), pos~LogNormal, count~Poisson(+1 shift,
     read_functions.py:103-105), cat/ordinal~Uniform{0..K-1}.  Rows grouped in subjects of T."""
     rng = np.random.default_rng(seed)
@@ -178,7 +187,42 @@ def make_tabular(n_rows: int = 4096, T: int = 16, missing: float = 0.25, seed: i
                        np.repeat(rng.binomial(1, 0.5, P), T)[:n_rows].astype(np.float64),
                        np.repeat(sick, T)[:n_rows].astype(np.float64),
                        np.repeat(rng.binomial(1, 0.5, P), T)[:n_rows].astype(np.float64)], axis=1)
-    return _finish(raw, mask, labels, spec)
+    return _finish(raw, mask, labels, spec) if expanded else _finish_compact(raw, mask, labels, spec)
+
+
+@dataclass
+class CompactSource:
+    """a synthetic data set in the compact form of datafeed.CompactDataset (raw value | class index | level - 1 per variable)"""
+    raw: np.ndarray           # [N, D] float32
+    mask: np.ndarray          # [N, D] uint8, 1 = observed
+    labels: np.ndarray        # [N, Q] float64
+    types_info: dict
+    n_variables: int
+    cov_dim_ext: int
+    id_covariate: int = 2
+
+    def __len__(self):
+        return self.raw.shape[0]
+
+    @property
+    def n_subjects(self):
+        return int(np.unique(self.labels[:, self.id_covariate]).size)
+
+    def expand_rows(self, rows, spec=None):
+        """(data fp64 [B, X], mask fp64 [B, D]) of a few rows in the reference's expanded form (CPU baseline, parity checks)"""
+        td = self.types_info["types_dict"]
+        spec = [(t["type"], int(t["nclass"])) for t in td]
+        return expand(self.raw[rows].astype(np.float64), spec), self.mask[rows].astype(np.float64)
+
+
+def _finish_compact(raw, mask, labels, spec) -> CompactSource:
+    info = build_types_info(make_types_dict(spec), miss_mask=None)
+    for t in info["types_dict"]:
+        t["dim"] = int(t["dim"])
+        t["nclass"] = int(t["nclass"])
+    X = int(sum(k if t in ("cat", "ordinal") else 1 for t, k in spec))
+    return CompactSource(raw=raw.astype(np.float32), mask=(mask != 0).astype(np.uint8), labels=labels, types_info=info,
+                         n_variables=len(spec), cov_dim_ext=X)
 
 
 def _finish(raw, mask, labels, spec) -> HetBatchSource:
@@ -204,11 +248,13 @@ def subject_batches(labels: np.ndarray, subjects_per_batch: int, id_covariate: i
     order = np.arange(len(uniq))
     if rng is not None:
         rng.shuffle(order)
-    rows_of = {s: np.nonzero(ids == s)[0] for s in uniq}
+    srt = np.argsort(ids, kind="stable")
+    su, st = np.unique(ids[srt], return_index=True)
+    rows_of = dict(zip(su, np.split(srt, st[1:])))
     gsz = subjects_per_batch * world
     for g in range(0, len(order), gsz):
         grp = order[g:g + gsz]
-        mine = grp[rank * subjects_per_batch:(rank + 1) * subjects_per_batch]
-        if len(mine) == 0:
-            continue
+        if len(grp) < world:             # every rank takes part in every global batch (the step contains collectives)
+            break
+        mine = grp[rank::world]          # round-robin: a short last batch still gives every rank a subject
         yield np.concatenate([rows_of[uniq[s]] for s in mine])

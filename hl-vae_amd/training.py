@@ -45,6 +45,76 @@ class FusedAdam:
         m.mark_shadows_fresh()
 
 
+class ShardedAdam:
+    """The same optimiser for data-parallel runs (hlvae_amd.parallel): the dense part of the arena is cut into one slice per
+    rank; after the reduce-scatter of the gradients each rank runs Adam on its slices only (csrc/optim.hip k_adam_flat),
+    all-gathers a bf16 copy of the updated weights and rebuilds its padded shadows from it.  The small region (head
+    parameters, biases, convolution weights) is all-reduced and updated on every rank.  World size 1 runs the same kernels
+    with the collectives skipped."""
+
+    def __init__(self, model: HLVAE, dp, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        from .HLVAE import GRAD_SLACK
+        from .parallel import ShardPlan, ShardedState
+        self.model, self.dp, self.lr, self.betas, self.eps = model, dp, lr, betas, eps
+        dev, d = model.device, model._dims
+        self.m1 = torch.zeros(model._arena_size, dtype=torch.float32, device=dev)
+        self.m2 = torch.zeros(model._arena_size, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(2, dtype=torch.int64, device=dev)
+        a0, end, o_wy = int(d.atomic_region), int(d.arena_size), int(d.o_wy)
+        # slices in the order their gradients become final.  MLP: y_layer's weight (the last tensor of the arena) first --
+        # its reduce-scatter overlaps the rest of the backward pass; the convolutional model's y_layer gradient is final only
+        # after the transposed convolutions' backward, so its (smaller) dense region is one slice
+        ranges = [(a0, end, 0x1f)] if model.conv else [(o_wy, end, 0x01), (a0, o_wy, 0x1e)]
+        self.plan = ShardPlan(ranges, dp.world, dp.rank)
+        if self.plan.pad > GRAD_SLACK:
+            raise ValueError(f"world size {dp.world}: slice padding {self.plan.pad} exceeds the gradient arena's slack")
+        self.state = ShardedState(dp, self.plan, dev)
+        model._master_sync = self.sync_masters
+        self._masters_stale = False
+
+    def _args(self):
+        return (C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), C.c_float(1.0))
+
+    def reduce_scatter(self, k: int, async_op: bool = False):
+        if self.plan.world == 1:          # the gradient arena itself is the "summed slice": no copy
+            from .parallel import _Done
+            return _Done()
+        return self.state.reduce_scatter_slice(k, self.model._grad_arena, async_op=async_op)
+
+    def step_slice(self, k: int):
+        """Adam on this rank's part of slice k (its summed gradients are in the reduce-scatter's output buffer)"""
+        m, lib = self.model, _lib.load()
+        lo, hi = self.plan.slices[k].own(self.plan.rank)
+        if hi > lo:
+            g = self.state.gsh[k] if self.plan.world > 1 else m._grad_arena[lo:hi]
+            _lib.check(lib.hlvae_adam_shard(m._plan_handle, C.byref(m._ws), _lib.ptr(g), _lib.ptr(self.m1),
+                                            _lib.ptr(self.m2), _lib.ptr(self.state.own_copy_view(k)), _lib.ptr(self.step_count),
+                                            lo, hi - lo, *self._args(), m._stream()), "hlvae_adam_shard")
+
+    def step_small(self):
+        """replicated Adam on the (all-reduced) small region; commits the step number: after every step_slice"""
+        m = self.model
+        _lib.check(_lib.load().hlvae_adam_small(m._plan_handle, C.byref(m._ws), _lib.ptr(self.m1), _lib.ptr(self.m2),
+                                                _lib.ptr(self.step_count), *self._args(), m._stream()), "hlvae_adam_small")
+
+    def gather(self, k: int, async_op: bool = False):
+        return self.state.all_gather_slice(k, async_op=async_op)
+
+    def rebuild_shadows(self, k: int):
+        m, s = self.model, self.plan.slices[k]
+        _lib.check(_lib.load().hlvae_shadows_from_bf16(m._plan_handle, C.byref(m._ws), _lib.ptr(self.state.pb[k]), s.lo, s.which,
+                                                       m._stream()), "hlvae_shadows_from_bf16")
+        self._masters_stale = self.plan.world > 1
+        m.mark_shadows_fresh()
+
+    def sync_masters(self):
+        """collective: brings the fp32 masters of the other ranks' slices up to date (state_dict, checkpoints)"""
+        if self._masters_stale:
+            self.state.sync_masters(self.model._arena)
+            self._masters_stale = False
+            self.model.mark_shadows_fresh()
+
+
 class ELBOTrainer:
     """One object per model: owns the optimiser state and (optionally) captured HIP graphs.
 
@@ -61,9 +131,17 @@ class ELBOTrainer:
         self.model, self.P_total, self.kl, self.gp, self.dp, self.metrics = model, P_total, kl, gp, dp, metrics
         model._max_batch = max(model._max_batch, max_batch)
         model._ensure_device_state(max_batch)
-        self.opt = FusedAdam(model, lr=lr)
+        frozen = [p for p in model._order if not p.requires_grad and p is not model._log_vy_real and p is not model._log_vy_pos]
+        if frozen or (model._log_vy_real.requires_grad != model._log_vy_pos.requires_grad):
+            raise ValueError("the fused optimiser step freezes _log_vy_real / _log_vy_pos together (vy_fixed) and trains every other "
+                             "parameter, as the reference does (HLVAE.py:209-216)")
+        self.opt = FusedAdam(model, lr=lr) if dp is None else ShardedAdam(model, dp, lr=lr)
         dev, L = model.device, model.z_dim
         self._graphs = {}
+        if dp is not None and dp.world > 1:
+            # every rank draws its own reparameterisation noise: the in-kernel Philox stream is indexed by the LOCAL row, so
+            # the seed carries the rank (the reference's single process draws one randn_like for the whole batch, HLVAE.py:361)
+            model._ws_t["rng"][0] = (int(model._ws_t["rng"][0].item()) + (dp.rank + 1) * 0x9E3779B97F4A7C15) % (2 ** 62)
         self._pf_stream = torch.cuda.Stream(device=dev)      # input stage of the NEXT batch (prefetch)
         self.err = torch.zeros(3, model.plan.D, dtype=torch.float32, device=dev)     # error_observed / missing / all
 
@@ -107,8 +185,7 @@ class ELBOTrainer:
         m = self.model
         B = rows.shape[0]
         m._ensure_device_state(B)
-        _lib.check(_lib.load().hlvae_feed_fused(m._plan_handle, C.byref(m._ws), _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows),
-                                                B, m._stream()), "feed_fused")
+        self._feed_stage(ds, rows, B)
 
     def step_rows(self, ds, rows: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None, groups=None,
                   prefetch_rows: Optional[torch.Tensor] = None, prepacked: bool = False):
@@ -126,21 +203,27 @@ class ELBOTrainer:
         m._ensure_device_state(B)
         m._packed_key = None
         ws, s = C.byref(m._ws), m._stream()
-        if prefetch_rows is not None and (self.dp is not None or m.conv):
-            raise ValueError("step_rows(prefetch_rows=...): single-process MLP training only")
-        if prepacked:
-            pass
-        elif self.dp is None:
+        if prefetch_rows is not None and m.conv:
+            raise ValueError("step_rows(prefetch_rows=...): the convolutional input stage reads the weights, it cannot run ahead")
+        if not prepacked:
+            self._feed_stage(ds, rows, B)
+        train_x = ds.labels.index_select(0, rows.long()) if self.kl == "gp" else None
+        self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None,
+                        feed_next=None if prefetch_rows is None else (ds, prefetch_rows), groups=groups)
+
+    def _feed_stage(self, ds, rows, B):
+        """statistics -> [all-reduce over ranks] -> normalise + pack of the rows ``rows`` on the current stream, into the
+        front buffer set"""
+        m, lib = self.model, _lib.load()
+        ws, s = C.byref(m._ws), m._stream()
+        if self.dp is None or self.dp.world == 1:
             _lib.check(lib.hlvae_feed_fused(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_fused")
         else:
             _lib.check(lib.hlvae_feed_stats(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_stats")
             self.dp.allreduce_stats(m._ws_t["sums"])
             _lib.check(lib.hlvae_feed_pack(m._plan_handle, ws, _lib.ptr(ds.values), _lib.ptr(ds.mask), _lib.ptr(rows), B, s), "feed_pack")
-        train_x = ds.labels.index_select(0, rows.long()) if self.kl == "gp" else None
-        self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None,
-                        feed_next=None if prefetch_rows is None else (ds, prefetch_rows))
 
-    def _step_core(self, B, scale, eps, train_x, P_batch, prefetch, hook, feed_next=None):
+    def _step_core(self, B, scale, eps, train_x, P_batch, prefetch, hook, feed_next=None, groups=None):
         m = self.model
         lib = _lib.load()
         ws, s = C.byref(m._ws), m._stream()
@@ -162,16 +245,30 @@ class ELBOTrainer:
         _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 2, 2 if self.metrics else 0, 0, B, s), "decoder_fwd")     # want_grad = 2: ELBO scalars deferred to the backward's side stream
         if self.metrics:     # row M: imputed values + per-variable errors (training.py:84-101), device resident
             _lib.check(lib.hlvae_step_metrics(m._plan_handle, ws, B, _lib.ptr(self.err), s), "step_metrics")
-        if feed_next is not None:       # deferred: the backward pass queues it on its side stream (hlvae_feed_prefetch)
+        multi = self.dp is not None and self.dp.world > 1
+        if feed_next is not None and not multi:   # deferred: the backward pass queues it on its side stream (hlvae_feed_prefetch)
             nds, nrows = feed_next
             m._ensure_device_state(nrows.shape[0])
             _lib.check(lib.hlvae_feed_prefetch(m._plan_handle, C.byref(m._ws_alt), _lib.ptr(nds.values), _lib.ptr(nds.mask),
                                                _lib.ptr(nrows), nrows.shape[0], s), "feed_prefetch")
             self._pf_ref = feed_next
+        elif feed_next is not None:
+            # several ranks: the next batch's statistics cross the ranks between its two kernels.  Forked from here on a stream
+            # of ours, so that this small all-reduce is the FIRST collective of the step on RCCL's queue and the next step starts
+            # at its first GEMM instead of behind a blocking exchange
+            nds, nrows = feed_next
+            m._ensure_device_state(nrows.shape[0])
+            main = torch.cuda.current_stream(m.device)
+            self._pf_stream.wait_stream(main)
+            m._swap_input_buffers()
+            with torch.cuda.stream(self._pf_stream):
+                self._feed_stage(nds, nrows, nrows.shape[0])
+            m._swap_input_buffers()
+            self._pf_ref = feed_next
         g_mu = g_lv = None
         kl_w = 1.0 if self.kl == "normal" else 0.0
         if self.kl == "gp":
-            g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch)
+            g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch, groups=groups)
         fused_opt = self.dp is None
         if fused_opt:
             # backward and optimiser in one call: y_layer's Adam update runs under the rest of the backward pass
@@ -180,25 +277,33 @@ class ELBOTrainer:
                                                _lib.ptr(o.m2), _lib.ptr(o.step_count), C.c_float(o.lr), C.c_float(o.betas[0]),
                                                C.c_float(o.betas[1]), C.c_float(o.eps), C.c_float(1.0), s), "backward_adam")
             m.mark_shadows_fresh()
-        elif m.conv:
-            # convolutional model: y_layer's gradient is final only after the transposed convolutions' backward and the arena
-            # is 2.7 M parameters (10.8 MB): one all-reduce after the backward pass
-            _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 0, B, s), "backward")
-            self.dp.allreduce_(m._grad_arena)
         else:
-            # data parallel: the y_layer gradient (the largest slice of the arena) is final first; its all-reduce runs on
-            # RCCL's stream while the rest of the backward pass is still computing
-            d = m._dims
-            _lib.check(lib.hlvae_backward_wy(m._plan_handle, ws, B, s), "backward_wy")
-            G = m._grad_arena
-            lo = int(d.o_wy)                                 # y_layer's weight is the last tensor of the arena
-            pending = self.dp.allreduce_async(G[lo:])
-            _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 1, B, s), "backward")
-            self.dp.allreduce_(G[:lo])
-            pending.wait()
+            # data parallel (hlvae_amd.parallel): reduce-scatter of the dense gradient slices -> Adam on this rank's slices ->
+            # all-gather of the bf16 copies -> shadows; the small region is all-reduced and updated on every rank
+            o = self.opt
+            G, d = m._grad_arena, m._dims
+            if m.conv:
+                _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 0, B, s), "backward")
+                pend = [o.reduce_scatter(0, async_op=True)]
+            else:
+                # y_layer's gradient (the largest slice) is final first: its reduce-scatter runs on RCCL's stream while the
+                # rest of the backward pass is still computing
+                _lib.check(lib.hlvae_backward_wy(m._plan_handle, ws, B, s), "backward_wy")
+                pend = [o.reduce_scatter(0, async_op=True)]
+                _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 1, B, s), "backward")
+                pend.append(o.reduce_scatter(1, async_op=True))
+            small = self.dp.allreduce_async(G[:int(d.atomic_region)])
+            gath = []
+            for k, h in enumerate(pend):        # slice k: wait for its sums, update, start the all-gather of the bf16 copy
+                h.wait()
+                o.step_slice(k)
+                gath.append(o.gather(k, async_op=True))
+            small.wait()
+            o.step_small()
+            for k, h in enumerate(gath):
+                h.wait()
+                o.rebuild_shadows(k)
         m._fwd_token += 1
-        if not fused_opt:
-            self.opt.step()
         m._grad_region_clean = True
         if self.kl == "gp":
             self.gp.optimizer_step()
@@ -207,7 +312,9 @@ class ELBOTrainer:
             m._swap_input_buffers()
             m._packed_key = self._batch_key(prefetch[0], prefetch[1])
             self._pf_ref = prefetch          # keep the tensors alive: their addresses identify the packed batch
-        elif feed_next is not None:              # joined by the backward call; its buffers become the front set
+        elif feed_next is not None:              # joined by the backward call (or here); its buffers become the front set
+            if multi:
+                torch.cuda.current_stream(m.device).wait_stream(self._pf_stream)
             m._swap_input_buffers()
             m._packed_key = None
         else:
@@ -237,9 +344,11 @@ class ELBOTrainer:
         self._graphs[key] = g
         return g
 
-    def capture_rows(self, key, ds, rows, P_batch, next_rows=None):
+    def capture_rows(self, key, ds, rows, P_batch, next_rows=None, groups=None):
         """Capture ``step_rows`` reading the STATIC index tensor ``rows``: refill it in place (``rows.copy_(...)``) and
         replay -- one graph serves every batch of that size and subject count.
+
+        groups: the batch's subject structure for the GP prior (datafeed.subject_index; a list for a chain), static like ``rows``.
 
         ``rows`` / ``P_batch`` may be LISTS: that many consecutive steps (one per index tensor) go into ONE graph.  Inside a
         graph the last kernel of a step and the first of the next are neighbours on one hardware queue (no gap); between
@@ -252,19 +361,20 @@ class ELBOTrainer:
         many = isinstance(rows, (list, tuple))
         chain = list(zip(rows, P_batch)) if many else [(rows, P_batch)]
         nxt = [None] * len(chain) if next_rows is None else (list(next_rows) if many else [next_rows])
+        grp = [None] * len(chain) if groups is None else (list(groups) if many else [groups])
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):                       # warm-up (an even number of steps: the buffer sets end where they began)
-                self.step_rows(ds, chain[0][0], chain[0][1])
+                self.step_rows(ds, chain[0][0], chain[0][1], groups=grp[0])
             if next_rows is not None:
                 self.prime_rows(ds, chain[0][0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.cuda.graph(g):
-            for (r, pb), nr in zip(chain, nxt):
-                self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None)
+            for (r, pb), nr, gr in zip(chain, nxt, grp):
+                self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None, groups=gr)
         self._graphs[key] = g
         return g
 

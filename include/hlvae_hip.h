@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 21
+#define HLVAE_ABI_VERSION 22
 #define HLVAE_STAT_CHUNKS 16
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -73,6 +73,9 @@ typedef struct {
     int64_t arena_size;          /* floats */
     int64_t atomic_region;       /* grads in [0, atomic_region) are accumulated with atomics and
                                     must be zero when a backward pass starts (hlvae_backward zeroes them) */
+    int64_t frozen_lo, frozen_hi; /* arena range inside [0, atomic_region) that the optimiser leaves alone (vy_fixed = True:
+                                    _log_vy_real / _log_vy_pos without requires_grad, HLVAE.py:209-216; torch.optim.Adam skips
+                                    parameters without a gradient); frozen_lo == frozen_hi: none */
 } hlvae_dims;
 
 void hlvae_dims_fill(hlvae_dims* d);   /* fills the derived fields from D,X,y_dim,h_e,h_d,L,n_real,n_pos */
@@ -241,6 +244,25 @@ int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m
 int hlvae_backward_adam(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
                         int B, float* m1, float* m2, int64_t* step_count, float lr, float beta1, float beta2, float eps,
                         float grad_scale, hlvae_stream s);
+
+/* ---- sharded optimiser step (data parallel: hl-vae_amd/parallel.py; the reference has no distributed code, the semantics
+ * to keep are ONE optimiser step on the sum of the ranks' gradients, training.py:121-128) ------------------------------------
+ * The dense part of the arena [atomic_region, arena_size) is cut into equal contiguous slices, one per rank.  After the
+ * reduce-scatter of the gradient arena a rank holds the SUMMED gradients of its slice in a compact buffer grad_shard[n]
+ * (element i of the arena at grad_shard[i - lo]); hlvae_adam_shard updates master / m / v of [lo, lo + n) only (m1, m2 are
+ * indexed like the arena) and writes the bf16 copy of the updated values to pb16_shard[i - lo].  The caller all-gathers the
+ * bf16 slices; hlvae_shadows_from_bf16 then rebuilds the padded row-major + transposed shadows of the matrices `which`
+ * (bit 0 y_layer, 1 encoder Linear, 2 d_layers, 3 mean_layer, 4 log_var_layer) from that flat bf16 copy, where arena
+ * element i lives at pb16[i - base].  hlvae_adam_small is the replicated part: Adam on [0, atomic_region) (head parameters,
+ * biases, convolution weights: all-reduce their gradients first), zeroes the consumed gradients and commits the step number
+ * -- call it AFTER every hlvae_adam_shard of the step, on the same stream. */
+int hlvae_adam_shard(const hlvae_plan* p, const hlvae_ws* ws, const float* grad_shard, float* m1, float* m2, uint16_t* pb16_shard,
+                     const int64_t* step_count, int64_t lo, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float grad_scale, hlvae_stream s);
+int hlvae_adam_small(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float beta1,
+                     float beta2, float eps, float grad_scale, hlvae_stream s);
+int hlvae_shadows_from_bf16(const hlvae_plan* p, const hlvae_ws* ws, const uint16_t* pb16, int64_t base, unsigned which,
+                            hlvae_stream s);
 
 /* ---- GP-prior KL (row K): reference elbo_functions.py:196-285 with the kernels of GP_model.py:27-116, fp64 ----------
  * An additive kernel = sum over terms of  scale_t[l] * prod_f factor_f(x[dim], x'[dim]);  factors: categorical equality,

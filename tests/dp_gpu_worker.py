@@ -63,25 +63,37 @@ def main():
     # data parallel, this rank's subjects, fed from the device-resident compact dataset (what bench.py --gpus N runs)
     from hlvae_amd.datafeed import CompactDataset
     dsd = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    from hlvae_amd.datafeed import subject_index
     rows_dev = torch.tensor(rows.astype(np.int32), device=dev)
+    groups_dev = torch.tensor(subject_index(subj[rows]), device=dev)          # the sampler's subject structure (GP prior)
     dp = DataParallel(dist.group.WORLD)
     model_d, gp_d, tr_d = build(dp)
     nll_d, kld_d = [], []
+    tr_d.prime_rows(dsd, rows_dev)          # pipelined input stage: every step packs the NEXT batch (statistics all-reduce included)
     for i in range(steps):
-        tr_d.step_rows(dsd, rows_dev, P_batch, eps=eps[i][rows].to(dev))
+        tr_d.step_rows(dsd, rows_dev, P_batch, eps=eps[i][rows].to(dev), prefetch_rows=rows_dev, prepacked=True, groups=groups_dev)
         part = torch.stack([tr_d.scalars()["nll_sum"].double().reshape(()), tr_d.scalars()["kl"].double().reshape(())])
         dist.all_reduce(part)
         nll_d.append(float(part[0]))
         kld_d.append(float(gp_d.last_kld) if gp_d is not None else float(part[1]))
     torch.cuda.synchronize()
+    model_d.state_dict()                    # collective: gathers the fp32 masters of the other rank's slices
     out = dict(kl=kl, world=world, rows=[int(len(rows))], nll_single=nll_s, nll_dp=nll_d, kld_single=kld_s, kld_dp=kld_d,
                params=rel(model_d._arena, model_s._arena))
     if gp_s is not None:
         out.update(gp_theta=rel(gp_d._theta, gp_s._theta), gp_m=rel(gp_d.m, gp_s.m), gp_H=rel(gp_d.H, gp_s.H))
-    # replicas must agree exactly
-    chk = model_d._arena.clone()
-    dist.broadcast(chk, 0)
-    out["replica_drift"] = float((chk - model_d._arena).abs().max())
+    # replicas must agree exactly: the masters after the gather, and the bf16 shadows every rank computes with
+    drift = 0.0
+    for t in (model_d._arena, model_d._ws_t["wys"].float(), model_d._ws_t["w1s"].float(), model_d._ws_t["wyTs"].float(),
+              model_d._ws_t["wmls"].float(), model_d._ws_t["wds"].float()):
+        chk = t.clone()
+        dist.broadcast(chk, 0)
+        drift = max(drift, float((chk - t).abs().max()))
+    out["replica_drift"] = drift
+    # the shadows ARE the bf16 rounding of the gathered masters
+    d = model_d._dims
+    wy = model_d.y_layer[0].weight.detach()
+    out["shadow_vs_master"] = float((model_d._ws_t["wys"][:wy.shape[0], :wy.shape[1]].float() - wy.to(torch.bfloat16).float()).abs().max())
     if rank == 0:
         print("DPRESULT " + json.dumps(out), flush=True)
     dist.destroy_process_group()

@@ -1,5 +1,6 @@
 """world_size = 2 data-parallel run of the HIP path on one GPU (gloo transports the collectives): the N > 1 code path of
-hl-vae_amd/training.py and the GP-prior exchange of elbo_functions.GPPriorHIP, checked against a single-process run of
+hl-vae_amd/training.py (pipelined input stage with its statistics all-reduce, reduce-scatter of the two dense gradient slices,
+sharded Adam, all-gather of the bf16 copies, shadows rebuilt from them) and the GP-prior exchange of elbo_functions.GPPriorHIP, checked against a single-process run of
 the same global batch.  Tolerances: NLL 1e-5 rel (fp32 sums in a different order), GP bound 1e-7, parameters after two
 Adam steps 2e-3 rel (Adam's first steps amplify rounding of tiny gradients), GP state 1e-6."""
 import json
@@ -36,6 +37,6 @@ def test_two_rank_step_matches_single_process(kl):
     for a, b in zip(out["kld_dp"], out["kld_single"]):
         assert abs(a - b) <= tol * abs(b) + 1e-9, out
     assert out["params"] < 2e-3, out
-    assert out["replica_drift"] == 0.0, out
+    assert out["replica_drift"] == 0.0 and out["shadow_vs_master"] == 0.0, out
     if kl == "gp":
         assert out["gp_theta"] < 1e-6 and out["gp_m"] < 1e-6 and out["gp_H"] < 1e-6, out

@@ -354,3 +354,63 @@ def test_conv_backward_against_oracle(B):
         # logic; the MLP path shows 1.4e-2 / 0.7e-2 at 1024 / 4096 rows).  Everything else sits inside the MLP path's bound.
         tol = 5e-2 if k == "d_layers.0.weight" else GRAD_RTOL
         assert e < tol, (k, e)
+
+
+def test_sharded_optimizer_path_matches_fused_path():
+    """The data-parallel optimiser path at world size 1 (flat Adam on the whole dense region -> bf16 copy -> shadows rebuilt
+    from it; hl-vae_amd/parallel.py with the collectives skipped) against the fused tile Adam of the single-process step: D4,
+    512 rows, three steps with the same noise -- same arithmetic, so the parameters agree to fp32 atomics' reordering and the
+    shadows bit for bit."""
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    from hlvae_amd.parallel import DataParallel
+    from hlvae_amd.datafeed import CompactDataset
+    dev = _dev()
+    src = synthetic.make_d4(n_subjects=30, T=20, seed=11)
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    rows = [torch.tensor(np.arange(i * 40, i * 40 + 512).astype(np.int32), device=dev) for i in range(2)]
+    eps = [torch.randn(512, 32, generator=torch.Generator().manual_seed(40 + i)).to(dev) for i in range(3)]
+    res = []
+    for dp in (None, DataParallel.single()):
+        torch.manual_seed(5)
+        model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=512, materialize_samples=False).to(dev)
+        tr = ELBOTrainer(model, P_total=30, kl="normal", max_batch=512, dp=dp, metrics=True)
+        nll = []
+        tr.prime_rows(ds, rows[0])
+        for i in range(3):
+            tr.step_rows(ds, rows[i % 2], 26, eps=eps[i], prefetch_rows=rows[(i + 1) % 2], prepacked=True)
+            nll.append(float(tr.scalars()["nll_sum"]))
+        torch.cuda.synchronize()
+        assert int(tr.opt.step_count[0]) == 3
+        res.append((nll, model._arena.clone(), {k: model._ws_t[k].clone() for k in ("wys", "wyTs", "w1s", "wds", "wdTs", "wmls", "wmlTs")}))
+    (nll_a, P_a, sh_a), (nll_b, P_b, sh_b) = res
+    assert rel_err(np.array(nll_b), np.array(nll_a)) < 1e-6, (nll_a, nll_b)
+    assert rel_err(P_b, P_a) < 1e-6
+    for k in sh_a:
+        assert float((sh_a[k].float() - sh_b[k].float()).abs().max()) <= 2.0 ** -8 * float(sh_a[k].float().abs().max()), k
+        assert float((sh_a[k] != sh_b[k]).float().mean()) < 1e-4, k          # a last-bit difference of a master may flip a rounding
+
+
+def test_vy_fixed_parameters_stay_put_under_the_fused_optimiser():
+    """vy_fixed = True (reference HLVAE.py:209-216: _log_vy_real / _log_vy_pos without requires_grad): torch.optim.Adam skips
+    them; the fused optimiser step must too, while every other parameter trains."""
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    dev = _dev()
+    src = synthetic.make_tabular(n_rows=96, T=8, seed=3)
+    dims = [src.cov_dim_ext, [32], 8, [32], 5]
+    model = HLVAE(dims, src.types_info, src.n_variables, vy_fixed=True, conv=False, max_batch=128, materialize_samples=False).to(dev)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    tr = ELBOTrainer(model, P_total=12, kl="normal", max_batch=128)
+    data, mask = torch.tensor(src.data, device=dev), torch.tensor(src.mask, device=dev)
+    for _ in range(3):
+        tr.step(data, mask, 12)
+    torch.cuda.synchronize()
+    after = dict(model.named_parameters())
+    assert torch.equal(after["_log_vy_real"], before["_log_vy_real"]) and torch.equal(after["_log_vy_pos"], before["_log_vy_pos"])
+    for k in ("obs_layer.0.weight", "y_layer.0.bias", "d_layers.0.bias", "y_layer.0.weight"):
+        assert not torch.equal(after[k], before[k]), k
+    d = model._dims
+    assert float(tr.opt.m1[int(d.frozen_lo):int(d.frozen_hi)].abs().max()) == 0.0
+    assert float(model._grad_arena[int(d.frozen_lo):int(d.frozen_hi)].abs().max()) == 0.0      # cleared for the next step's atomics
