@@ -105,10 +105,26 @@ def build_ring(src, batch, n_ring):
 
 
 def host_cores():
+    """host cores this process may actually use: the affinity mask capped by the cgroup CPU quota.  On the one-GPU boxes of
+    this pool 256 hardware threads are visible but cpu.max is 16 cores' worth; 256 torch threads against that quota were
+    measured at 31.6 s per oracle step against 0.07 s with 16 (gpurun_out/r2_b_default.json, round 2)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps, conv=False, gp_state=None, budget_s=45.0):
@@ -120,7 +136,8 @@ def cpu_baseline(src, dims, state, rows, P_total, P_batch, kl, steps, conv=False
     import metrics_oracle as mo
     cores = host_cores()
     torch.set_num_threads(cores)
-    print(f"[bench] cpu_baseline: {cores} host cores (torch threads)", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline: {cores} host cores usable by this process (affinity capped by the cgroup quota) = torch threads",
+          file=sys.stderr, flush=True)
     st = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in state.items()
           if not k.startswith(("hidden.", "Decoder_Conv_layer."))}
     for k in list(st):
