@@ -364,6 +364,12 @@ class HLVAE(nn.Module):
             self._alloc_workspace(max(Bp, _ru(self._max_batch, 128)))
         self._sync_shadows()
 
+    def _head_acc(self) -> int:
+        """accumulators per variable of the head-kernel instance this plan selects (csrc/heads.hip: HeadAcc + y_dim)"""
+        y, kmax = self.y_dim, max([2] + [int(k) for k, kd in zip(self.plan.ncls, self.plan.kind) if kd in (KIND_CAT, KIND_ORDINAL)])
+        km = 8 if y != 5 else (3 if kmax <= 3 else 5 if kmax <= 5 else 8 if kmax <= 8 else 16)
+        return max((y + 1) * (km - 1), y + km) + y
+
     def _alloc_workspace(self, Bp: int):
         d, dev = self._dims, self.device
         bf, f32 = torch.bfloat16, torch.float32
@@ -389,7 +395,7 @@ class HLVAE(nn.Module):
             slab=z(max(S_e, S_d), Bp, max(d.hep, d.hdp), dt=f32),
             t=z(Bp, d.hep), tT=z(d.hep, Bp), mu=z(Bp, d.L, dt=f32), lv=z(Bp, d.L, dt=f32), z=z(Bp, d.L, dt=f32),
             zb=z(Bp, d.Lp), zbT=z(d.Lp, Bp), u=z(Bp, d.hdp), uT=z(d.hdp, Bp), dy=z(Bp, d.NYp), dyT=z(d.NY, Bp),
-            log_p_x=z(Bp, d.D, dt=f32), log_p_x_missing=z(Bp, d.D, dt=f32), rowpart=z(NT, Bp, dt=f32),
+            log_p_x=z(Bp, d.D, dt=f32), log_p_x_missing=z(Bp, d.D, dt=f32), rowpart=z(NT, Bp, dt=f32), hgpart=z(Bp // 64, NT * 16, self._head_acc(), dt=f32),
             nll=z(Bp, dt=f32), scal=z(8, dt=torch.float64), klpart=z(max(Bp // 4, 1), dt=torch.float64),
             eps=z(Bp, d.L, dt=f32), rng=z(2, dt=torch.int64), pfull=z(Bp, d.X, dt=f32), xhat=z(Bp, d.D, dt=f32),
             metpart=z(16, 6, d.D, dt=f32),

@@ -10,8 +10,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 STAT_CHUNKS = 16
+HEAD_ACC = 95
 
 _vp = C.c_void_p
 
@@ -30,7 +31,7 @@ class HlvaeDims(C.Structure):
 
 WS_POINTERS = ("P", "G", "w1s", "wmls", "wmlTs", "wds", "wdTs", "wys", "wyTs", "sums", "norm", "xn", "xnT", "xt", "m8",
                "slab", "t", "tT", "mu", "lv", "z", "zb", "zbT", "u", "uT", "dy", "dyT", "log_p_x", "log_p_x_missing",
-               "rowpart", "nll", "scal", "klpart", "eps", "rng", "pfull", "xhat", "metpart", "du", "duT", "dz", "dml", "dmlT", "dt", "dtT",
+               "rowpart", "hgpart", "nll", "scal", "klpart", "eps", "rng", "pfull", "xhat", "metpart", "du", "duT", "dz", "dml", "dmlT", "dt", "dtT",
                "w1Ts", "cpack", "img", "yc", "a2", "yv", "da2", "dyc", "dycT", "dfeat", "dimg", "cvpart")
 CONV_PART_ROWS = 512
 CONV_PACK_ELEMS = 32 * 160 + 16 * 288 + 4 * 16 * 128 + 32 * 256 + 4 * 16 * 64 + 16 * 128      # csrc/conv.hip CP_TOTAL

@@ -13,6 +13,7 @@ int hl_launch_gemm_act(int, const bf16_t*, int, const bf16_t*, int, int, int, in
                        bf16_t*, int, bf16_t*, int, int, float*, const char*, hipStream_t);
 int hl_launch_y_heads(const hlvae_plan*, const hlvae_ws*, const float*, float, int, int, int, int, hipStream_t);
 int hl_launch_elbo_finalize(const hlvae_plan*, const hlvae_ws*, int, int, hipStream_t);
+int hl_launch_head_grad_reduce(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
 int hl_launch_scale_dy(const hlvae_plan*, const hlvae_ws*, const float*, int, int, hipStream_t);
 int hl_launch_step_metrics(const hlvae_plan*, const hlvae_ws*, int, float*, hipStream_t);
 int hl_launch_stats(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, hipStream_t);
@@ -445,6 +446,8 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     hipStream_t s0 = g_prof_on ? st : p->side[0], s1 = g_prof_on ? st : p->side[1];
     if (d.conv)     // d y_grouped -> d a2 -> d (y_layer output), weight gradients of the transposed convolutions
         if ((rc = hl_launch_conv_dec_bwd(p, ws, B, Bp, st))) return rc;
+    if (skip_wy)    // data-parallel host: the small region is all-reduced right after this call
+        if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, st))) return rc;
     const bf16_t* dyl = d.conv ? ws->dyc : ws->dy;          // gradient of y_layer's output, both layouts
     const bf16_t* dylT = d.conv ? ws->dycT : ws->dyT;
     HL_CHECK(hipEventRecord(p->ev[0], st));        // dY is final
@@ -482,6 +485,10 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
                                        0, 0u, "adam_dense_early", s0))) return rc;
             }
         }
+        // head-parameter / y_layer-bias gradients: the head kernel left per-row-block partial sums; they are folded into the arena
+        // at the END of side 0 (only the final Adam launch, which joins side 0, consumes them).  At the head of this chain the
+        // 4 us kernel started 40 us late in the replayed graph and took dWy and y_layer's Adam launch with it (rocprofv3 trace).
+        if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s0))) return rc;
         HL_CHECK(hipEventRecord(p->ev[3], s0));
     }
     if (p->pend_flags & HL_PEND_DEFERRED) {

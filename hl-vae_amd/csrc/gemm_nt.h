@@ -16,7 +16,7 @@
 #include <type_traits>
 #include "common.h"
 
-template <int BM, int BN, int BK, int WM, int WN, int NS = 3>
+template <int BM, int BN, int BK, int WM, int WN, int NS = 3, int CLDV = 0>
 struct GemmNT {
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(BK == 32 || BK == 64, "BK");
@@ -35,7 +35,7 @@ struct GemmNT {
     static constexpr int BM_ALLOC = A_IT * HL_THREADS / CPR, BN_ALLOC = B_IT * HL_THREADS / CPR;
     static constexpr int STAGE_ELEMS = (BM_ALLOC + BN_ALLOC) * LDS;   // one LDS buffer (A tile then B tile), two buffers
     static constexpr int AB_BYTES = 2 * STAGE_ELEMS * 2;
-    static constexpr int CLD = BN + 1;                 // fp32 C tile row stride in LDS
+    static constexpr int CLD = CLDV ? CLDV : BN + 1;   // fp32 C tile row stride in LDS (CLDV: an epilogue's own choice)
     static constexpr int C_BYTES = BM * CLD * 4;
     static constexpr int SMEM_BYTES = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
 
@@ -99,9 +99,21 @@ struct GemmNT {
         }
     }
 
+    struct NoHook { __device__ __forceinline__ void operator()() const {} };
     __device__ static __forceinline__ void run(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                int ldb, int m0, int n0, int M, int N, int k_begin, int k_end,
                                                char* smem, Acc& acc) {
+        run(A, lda, B, ldb, m0, n0, M, N, k_begin, k_end, smem, acc, NoHook(), NoHook());
+    }
+    // after_prologue: called once between the issue of the first three k-tiles' global loads and the first LDS write.  An
+    // epilogue can consume loads IT issued before run() there (vmcnt retires in order: they cost no extra wait, their latency
+    // overlaps the prologue's) without keeping their registers alive through the main loop.
+    // after_group: called once behind the first three k-steps (or behind the loop when it is shorter): whatever after_prologue
+    // requested has arrived by then, so the epilogue's registers need not stay alive through the whole main loop.
+    template <class Hook, class Hook2>
+    __device__ static __forceinline__ void run(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
+                                               int ldb, int m0, int n0, int M, int N, int k_begin, int k_end,
+                                               char* smem, Acc& acc, Hook after_prologue, Hook2 after_group) {
         static_assert(NS == 3, "the pipeline is written out for three register stages");
         bf16_t* const sbase = reinterpret_cast<bf16_t*>(smem);
         const int tid = threadIdx.x;
@@ -123,7 +135,7 @@ struct GemmNT {
             pb[i] = B + (size_t)r * ldb + (c % CPR) * 8 + k_begin;
         }
         const int nk = (k_end - k_begin) / BK;
-        if (nk <= 0) return;
+        if (nk <= 0) { after_prologue(); after_group(); return; }
         // three NAMED register stages (a runtime- or loop-indexed array of stages ends up in scratch memory)
         Stage s0, s1, s2;
         // (loads past the last tile are clamped to it: an unconditional, redundant load keeps the stages in VGPRs)
@@ -131,6 +143,7 @@ struct GemmNT {
         gload(s0, pa, pb, 0);
         gload(s1, pa, pb, min(BK, klast));
         gload(s2, pa, pb, min(2 * BK, klast));
+        after_prologue();
         lstore(s0, sbase, tid);
         __syncthreads();
         // step t: refill the stage consumed one step ago with tile t+3, write tile t+1 to the other LDS buffer,
@@ -144,6 +157,13 @@ struct GemmNT {
             __syncthreads();                                                                  \
         }
         int kt = 0;
+        if (nk >= 3) {
+            HL_STEP(s0, s1, 0)
+            HL_STEP(s1, s2, 1)
+            HL_STEP(s2, s0, 2)
+            kt = 3;
+        }
+        after_group();
         for (; kt + 3 <= nk; kt += 3) {      // full groups: no conditionals around the stage registers
             HL_STEP(s0, s1, kt)
             HL_STEP(s1, s2, kt + 1)

@@ -3,17 +3,34 @@
 //
 // Tile = BM batch rows x 16 variables (= 16*YD columns of Y = U * Wy^T + by, column d*YD + k is
 // feature k of variable d: the reshape of HLVAE.py:343).  The fp32 accumulator tile is staged in
-// LDS; thread (v = tid & 15, rg = tid >> 4) then owns variable v of the tile for rows rg, rg+16, ...
-// so the type of a variable is a per-thread constant, its head weights live in registers, and
+// LDS; thread (v = tid & 15, rg = tid >> 4) then owns variable v of the tile for the rows HL_ROW(rg, i)
+// = 4 rg + (i & 3) + 64 (i >> 2): groups of FOUR CONSECUTIVE rows, so that the transposed copy of dY leaves
+// straight from the thread's own values as 8-byte stores (4 bf16 of one column), and with the tile's row
+// stride CLD = 16 YD + 4 every LDS access of the epilogue is conflict-free (the two row groups of a
+// 32-lane half sit 4 CLD = 16 (mod 32) banks apart, exactly the gap the 16 variables' YD-strided
+// columns leave; PMC before: 38 % of the LDS cycles were bank conflicts).
+// The type of a variable is a per-thread constant, its head weights live in registers, and
 // mixed-type columns cost no gather/scatter (the reference walks boolean masks per type block,
 // HLVAE.py:387-412, 422-452).  Y itself is never written to HBM: the tile is overwritten in LDS by
 // g * d log_p_x / d Y and leaves as bf16 in both layouts for the two backward GEMMs.
 //
 // Stop-gradient through missing entries (HLVAE.py:435-452): theta = head(y) everywhere, gradient
 // only where the mask is 1 -> dY and all head-parameter gradients are gated by the mask.
+#include <stdlib.h>
 #include "gemm_nt.h"
 
 #define HL_LOG2PI 1.8378770664093453f
+#define HL_ROW(rg, i) (4 * (rg) + ((i) & 3) + 64 * ((i) >> 2))
+
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane: four VALU adds with DPP operands
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) instead of four ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float s) {
+    s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, true));
+    s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, true));
+    s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xF, 0xF, true));
+    s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xF, 0xF, true));
+    return s;
+}
 
 template <int YD, int KM>
 struct HeadAcc {
@@ -57,7 +74,7 @@ __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int 
     const float pos_var = is_pos ? __expf(p) : 0.f;              // read_functions.py:285
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) {
-        const int r = rg + 16 * i, gr = m0 + r;
+        const int r = HL_ROW(rg, i), gr = m0 + r;
         float* yrow = Cs + r * CLD + v * YD;
         float th = b;
         float y[YD];
@@ -69,8 +86,8 @@ __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int 
         float lp_obs = 0.f, dth = 0.f;
         if (gr < B) {
             const size_t o = (size_t)gr * D + d;
-            const float x = xt[o] * xscale;                      // raw x (real) or log1p x (pos)
-            const bool ob = m8[o] != 0;
+            const float x = xt[i * HL_THREADS] * xscale;         // raw x (real) or log1p x (pos): this thread's slot of the prefetched tile
+            const bool ob = m8[i * HL_THREADS] != 0;
             float thv = th, dsig = 1.f;
             if (conv_real) {
                 thv = sigmoid_f(th);
@@ -115,7 +132,7 @@ __device__ __forceinline__ void proc_count(float* Cs, int v, int rg, int m0, int
     const float b = P[var.b_off];
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) {
-        const int r = rg + 16 * i, gr = m0 + r;
+        const int r = HL_ROW(rg, i), gr = m0 + r;
         float* yrow = Cs + r * CLD + v * YD;
         float th = b;
         float y[YD];
@@ -127,8 +144,8 @@ __device__ __forceinline__ void proc_count(float* Cs, int v, int rg, int m0, int
         float lp_obs = 0.f, dth = 0.f;
         if (gr < B) {
             const size_t o = (size_t)gr * D + d;
-            const float x = xt[o];
-            const bool ob = m8[o] != 0;
+            const float x = xt[i * HL_THREADS];
+            const bool ob = m8[i * HL_THREADS] != 0;
             const float sp = softplus_f(th);
             const float lam = fminf(fmaxf(sp, 1e-6f), 1e20f);    // :203
             const float lp = x * __logf(lam) - lam - lgammaf(x + 1.f);   // Poisson.log_prob
@@ -171,7 +188,7 @@ __device__ __forceinline__ void proc_cat(float* Cs, int v, int rg, int m0, int B
     }
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) {
-        const int r = rg + 16 * i, gr = m0 + r;
+        const int r = HL_ROW(rg, i), gr = m0 + r;
         float* yrow = Cs + r * CLD + v * YD;
         float y[YD], th[KM - 1];
 #pragma unroll
@@ -185,19 +202,22 @@ __device__ __forceinline__ void proc_cat(float* Cs, int v, int rg, int m0, int B
             th[j] = t;
             if (j < K - 1) mx = fmaxf(mx, t);
         }
-        float se = __expf(-mx);
+        float se = __expf(-mx), ex[KM - 1];
 #pragma unroll
-        for (int j = 0; j < KM - 1; ++j)
-            if (j < K - 1) se += __expf(th[j] - mx);
+        for (int j = 0; j < KM - 1; ++j) {
+            ex[j] = j < K - 1 ? __expf(th[j] - mx) : 0.f;
+            se += ex[j];
+        }
         const float lse = mx + __logf(se);                       // loglik.py:134
+        const float inv_se = __frcp_rn(se);                      // softmax_j = ex[j] / se: the gradient reuses the exponentials
         float dth[KM - 1];
 #pragma unroll
         for (int j = 0; j < KM - 1; ++j) dth[j] = 0.f;
         float lp_obs = 0.f;
         if (gr < B) {
             const size_t o = (size_t)gr * D + d;
-            const int cls = (int)xt[o];                          // -1: all-zero one-hot row
-            const bool ob = m8[o] != 0;
+            const int cls = (int)xt[i * HL_THREADS];             // -1: all-zero one-hot row
+            const bool ob = m8[i * HL_THREADS] != 0;
             float lp = 0.f;
             if (cls == 0) lp = -lse;
 #pragma unroll
@@ -210,7 +230,7 @@ __device__ __forceinline__ void proc_cat(float* Cs, int v, int rg, int m0, int B
                 lp_obs = lp;
 #pragma unroll
                 for (int j = 0; j < KM - 1; ++j)
-                    if (j < K - 1) dth[j] = g * ((cls == j + 1 ? 1.f : 0.f) - __expf(th[j] - lse));
+                    if (j < K - 1) dth[j] = g * ((cls == j + 1 ? 1.f : 0.f) - ex[j] * inv_se);
             } else if (ob) {
                 lp_obs = lp;
             }
@@ -281,7 +301,7 @@ __device__ __forceinline__ void proc_ord(float* Cs, int v, int rg, int m0, int B
     }
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) {
-        const int r = rg + 16 * i, gr = m0 + r;
+        const int r = HL_ROW(rg, i), gr = m0 + r;
         float* yrow = Cs + r * CLD + v * YD;
         float y[YD];
         float reg = b;
@@ -316,8 +336,8 @@ __device__ __forceinline__ void proc_ord(float* Cs, int v, int rg, int m0, int B
         for (int j = 0; j < KM - 1; ++j) du[j] = 0.f;
         if (gr < B) {
             const size_t o = (size_t)gr * D + d;
-            const bool ob = m8[o] != 0;
-            int cls = ob ? (int)xt[o] : 0;                       // :172-174 (masked rows -> class 0)
+            const bool ob = m8[i * HL_THREADS] != 0;
+            int cls = ob ? (int)xt[i * HL_THREADS] : 0;          // :172-174 (masked rows -> class 0)
             cls = cls < 0 ? 0 : (cls > K - 1 ? K - 1 : cls);
             float pcc = pc[0];
 #pragma unroll
@@ -403,21 +423,32 @@ __device__ __forceinline__ int acc_dest(const hlvae_var& var, int n) {
 }
 
 template <int YD, int BM, int KMAX>
-__global__ __launch_bounds__(HL_THREADS) void k_y_heads(
+__global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) void k_y_heads(
     const bf16_t* __restrict__ U, int ldu, const bf16_t* __restrict__ Wy, int K, const hlvae_var* __restrict__ vars,
-    const float* __restrict__ P, float* __restrict__ G, long o_by, const float* __restrict__ norm, int n_stat,
+    const float* __restrict__ P, float* __restrict__ hgpart, long o_by, const float* __restrict__ norm, int n_stat,
     const float* __restrict__ xt, const uint8_t* __restrict__ m8, int D, const float* __restrict__ g_elem, float g_scale,
     bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dyT, int Bp, float* __restrict__ logpx,
     float* __restrict__ logpx_miss, float* __restrict__ rowpart, float* __restrict__ pfull, int X,
-    float* __restrict__ xhat, int B, int want_grad, const float* __restrict__ ysrc, int ldys) {
+    float* __restrict__ xhat, int B, int want_grad, const float* __restrict__ ysrc, int ldys, long long* __restrict__ clk) {
+#define HL_CLK(i) do { if (clk != nullptr && (threadIdx.x & 63) == 0) clk[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12 + (i)] = clock64(); } while (0)
+    HL_CLK(0);
     // ysrc != nullptr: convolutional decoder -- the tile of y_grouped comes from the second ConvTranspose (csrc/conv.hip,
     // bias included) instead of the y_layer GEMM; d Y leaves in row-major layout only and d by is not ours
     constexpr int BN = 16 * YD;
-    using Gm = GemmNT<BM, BN, 64, 4, 1>;
+    using Gm = GemmNT<BM, BN, 64, 4, 1, 3, BN + 4>;
     constexpr int CLD = Gm::CLD;
-    constexpr int NACC = HeadAcc<YD, KMAX>::N;
-    constexpr int RED_BYTES = 4 * 16 * NACC * 4;
-    __shared__ __attribute__((aligned(16))) char smem[Gm::SMEM_BYTES + RED_BYTES];
+    constexpr int RPT = BM / 16;                                  // rows per thread
+    constexpr int NHEAD = HeadAcc<YD, KMAX>::N;                   // head-parameter gradient accumulators of a variable
+    constexpr int NACC = NHEAD + YD;                              // + d by of its YD columns
+    constexpr int RST = 272;                                      // row stride of the reduction image: 16 banks between rows
+    // scratch behind the GEMM buffers, used strictly BEFORE the gradient reduction image that overlays them:
+    //   [head parameters, statistics and y_layer bias of the 16 variables | likelihood targets | masks] of the tile
+    constexpr int PW = YD * (KMAX - 1), PB = KMAX - 1, PS = PW + 2 * PB + 2 + YD;      // [w | b | e | mean, var | by]
+    constexpr int SCR_BYTES = 16 * PS * 4 + RPT * HL_THREADS * 5;
+    // after the epilogue: [C tile with dY | acc[n][thread] image]
+    constexpr int POST_BYTES = BM * CLD * 4 + NACC * RST * 4;
+    constexpr int SMEM_TOTAL = Gm::SMEM_BYTES + SCR_BYTES > POST_BYTES ? Gm::SMEM_BYTES + SCR_BYTES : POST_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_TOTAL];
     // 1-D grid, XCD-aware: the tiles_m row-blocks that share one 16-variable panel of Wy get consecutive
     // logical ids and therefore one XCD's L2
     const int tiles_m = Bp / BM;
@@ -426,177 +457,255 @@ __global__ __launch_bounds__(HL_THREADS) void k_y_heads(
     const int NY = D * YD;
     float* Cs = reinterpret_cast<float*>(smem);
     const bool conv = ysrc != nullptr;
-    // Parameter prefetch: the heads' weights hang off a dependent chain (vars[d] -> arena offsets -> P[...]) that used to sit,
-    // exposed, between the GEMM and the log-likelihoods.  16 lanes (one per variable of the tile) walk that chain NOW, keep
-    // the values in registers under the GEMM main loop and park them in LDS afterwards; the epilogue then reads LDS only.
-    constexpr int PW = YD * (KMAX - 1), PB = KMAX - 1, PS = PW + 2 * PB + 2;           // [w | b | e | mean, var]
-    static_assert(16 * PS * 4 <= RED_BYTES, "parameter scratch shares the LDS of the gradient reduction");
-    float* pscr = reinterpret_cast<float*>(smem + Gm::SMEM_BYTES);                     // = red, used strictly before it
+    float* pscr = reinterpret_cast<float*>(smem + Gm::SMEM_BYTES);
+    float* xs = pscr + 16 * PS;                                   // [RPT][256] this thread's targets at xs[i * 256 + tid]
+    uint8_t* ms = reinterpret_cast<uint8_t*>(xs + RPT * HL_THREADS);
     const int tid = threadIdx.x, v = tid & 15, rg = tid >> 4;
     const int d = tn * 16 + v;
-    hlvae_var var;
-    var.kind = -1;
-    if (d < D) var = vars[d];
-    float pre[PS];
-    if (tid < 16 && d < D) {
-        const int K1 = var.ncls - 1;
-        const bool cont = var.kind == HLVAE_REAL || var.kind == HLVAE_POS;
-        const int nw = var.kind == HLVAE_CAT ? YD * K1 : YD, nb = var.kind == HLVAE_CAT ? K1 : 1;
-        const int ne = cont ? 1 : (var.kind == HLVAE_ORDINAL ? K1 : 0);
+    hlvae_var var = vars[d < D ? d : D - 1];                     // unconditional (a conditional copy makes hipcc wait for it at once);
+    // Everything the epilogue reads from global memory is REQUESTED here, ahead of the GEMM, and parked in LDS by the hook
+    // below while the GEMM's own first tiles are still in flight: the likelihood targets and masks of this thread's rows
+    // (HBM-cold: they used to cost every wave a full memory latency at the top of the epilogue) and, by 16 lanes (one per
+    // variable of the tile), the dependent chain vars[d] -> arena offsets -> P[...] of the heads' parameters.
+    float xv[RPT];
+    uint8_t mv[RPT];
 #pragma unroll
-        for (int i = 0; i < PW; ++i) pre[i] = i < nw ? P[var.w_off + i] : 0.f;
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            pre[PW + i] = i < nb ? P[var.b_off + i] : 0.f;
-            pre[PW + PB + i] = i < ne ? P[var.e_off + i] : 0.f;
-        }
-        pre[PW + 2 * PB] = cont ? norm[var.sidx] : 0.f;
-        pre[PW + 2 * PB + 1] = cont ? norm[n_stat + var.sidx] : 1.f;
+    for (int i = 0; i < RPT; ++i) {
+        const int gr = min(m0 + HL_ROW(rg, i), B - 1);               // clamped, unconditional loads; rows >= B are masked when parked
+        const size_t o = (size_t)gr * D + (d < D ? d : D - 1);
+        xv[i] = xt[o];
+        mv[i] = m8[o];
     }
+    // hook, run between the issue of the GEMM's first three k-tiles and its first LDS write: park the targets / masks (their
+    // loads are older than the tiles': no extra wait) and ISSUE the heads' parameter loads, which hang off vars[d] (one memory
+    // latency, now overlapped with the tiles' instead of exposed ahead of the GEMM: 3.4 k of 43 k clocks per wave).  The values
+    // stay in registers for the first three k-steps only and are parked then (keeping them through the loop spilled 29 VGPRs).
+    float pre[PS];
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            xs[i * HL_THREADS + tid] = xv[i];
+            ms[i * HL_THREADS + tid] = (m0 + HL_ROW(rg, i) < B && d < D) ? mv[i] : (uint8_t)0;
+        }
+        if (tid < 16 && d < D) {
+            const int K1 = var.ncls - 1;
+            const bool cont = var.kind == HLVAE_REAL || var.kind == HLVAE_POS;
+            const int nw = var.kind == HLVAE_CAT ? YD * K1 : YD, nb = var.kind == HLVAE_CAT ? K1 : 1;
+            const int ne = cont ? 1 : (var.kind == HLVAE_ORDINAL ? K1 : 0);
+#pragma unroll
+            for (int i = 0; i < PW; ++i) pre[i] = i < nw ? P[var.w_off + i] : 0.f;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                pre[PW + i] = i < nb ? P[var.b_off + i] : 0.f;
+                pre[PW + PB + i] = i < ne ? P[var.e_off + i] : 0.f;
+            }
+            pre[PW + 2 * PB] = cont ? norm[var.sidx] : 0.f;
+            pre[PW + 2 * PB + 1] = cont ? norm[n_stat + var.sidx] : 1.f;
+#pragma unroll
+            for (int k = 0; k < YD; ++k) pre[PW + 2 * PB + 2 + k] = conv ? 0.f : P[o_by + (long)d * YD + k];
+        }
+    };
+    auto park_params = [&]() {
+        if (tid < 16 && d < D) {
+#pragma unroll
+            for (int i = 0; i < PS; ++i) pscr[v * PS + i] = pre[i];
+        }
+    };
+    HL_CLK(1);
     if (!conv) {
         typename Gm::Acc accm;
         Gm::zero(accm);
-        Gm::run(U, ldu, Wy, ldu, m0, n0, Bp, NY, 0, K, smem, accm);
+        Gm::run(U, ldu, Wy, ldu, m0, n0, Bp, NY, 0, K, smem, accm, park, park_params);
+        HL_CLK(2);
         Gm::to_lds(accm, smem);
+        HL_CLK(3);
     } else {
+        park();
+        park_params();
         for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
             const int r = idx / BN, c = idx % BN;
             Cs[r * CLD + c] = (m0 + r < B && n0 + c < NY) ? ysrc[(size_t)(m0 + r) * ldys + n0 + c] : 0.f;
         }
         __syncthreads();
     }
-    float* red = reinterpret_cast<float*>(smem + Gm::SMEM_BYTES);
-
-    if (tid < 16 && d < D) {
-#pragma unroll
-        for (int i = 0; i < PS; ++i) pscr[v * PS + i] = pre[i];
-    }
-    __syncthreads();
     float acc[NACC];
 #pragma unroll
     for (int n = 0; n < NACC; ++n) acc[n] = 0.f;
-    float lpo[BM / 16];
+    float lpo[RPT];
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) lpo[i] = 0.f;
+    for (int i = 0; i < RPT; ++i) lpo[i] = 0.f;
     if (d < D) {
-        float byv[YD];                        // y_layer's bias: independent loads, in flight together with the targets
+        float byv[YD];
 #pragma unroll
-        for (int k = 0; k < YD; ++k) byv[k] = conv ? 0.f : P[o_by + (long)d * YD + k];
-        // from here on the "arena" and the statistics are this variable's slice of the LDS scratch
+        for (int k = 0; k < YD; ++k) byv[k] = pscr[v * PS + PW + 2 * PB + 2 + k];
+        // from here on the "arena", the statistics, the targets and the masks are this thread's slices of the LDS scratch
         const float* P = pscr;
         const float* norm = pscr;
+        const float* xt = xs + tid;
+        const uint8_t* m8 = ms + tid;
         const int n_stat = 1;
         var.w_off = v * PS;
         var.b_off = v * PS + PW;
         var.e_off = v * PS + PW + PB;
         var.sidx = v * PS + PW + 2 * PB;
+        float (&hacc)[NHEAD] = *reinterpret_cast<float (*)[NHEAD]>(&acc[0]);
         switch (var.kind) {
             case HLVAE_REAL:
-                proc_realpos<YD, BM, CLD, NACC>(false, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
-                                                g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo, conv);
+                proc_realpos<YD, BM, CLD, NHEAD>(false, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
+                                                 g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, conv);
                 break;
             case HLVAE_POS:
-                proc_realpos<YD, BM, CLD, NACC>(true, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
-                                                g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo, false);
+                proc_realpos<YD, BM, CLD, NHEAD>(true, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
+                                                 g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, false);
                 break;
             case HLVAE_COUNT:
-                proc_count<YD, BM, CLD, NACC>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
-                                              logpx_miss, pfull, X, xhat, acc, lpo);
+                proc_count<YD, BM, CLD, NHEAD>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                               logpx_miss, pfull, X, xhat, hacc, lpo);
                 break;
             case HLVAE_CAT:
                 if (KMAX <= 3 || var.ncls <= 3)
-                    proc_cat<YD, BM, CLD, NACC, 3>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
-                                                   logpx_miss, pfull, X, xhat, acc, lpo);
+                    proc_cat<YD, BM, CLD, NHEAD, 3>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                    logpx_miss, pfull, X, xhat, hacc, lpo);
                 else if (KMAX <= 5 || var.ncls <= 5)
-                    proc_cat<YD, BM, CLD, NACC, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem,
-                                                                      g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo);
+                    proc_cat<YD, BM, CLD, NHEAD, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem,
+                                                                       g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo);
                 else
-                    proc_cat<YD, BM, CLD, NACC, KMAX>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
-                                                      logpx_miss, pfull, X, xhat, acc, lpo);
+                    proc_cat<YD, BM, CLD, NHEAD, KMAX>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                       logpx_miss, pfull, X, xhat, hacc, lpo);
                 break;
             case HLVAE_ORDINAL:
                 if (KMAX <= 5 || var.ncls <= 5)
-                    proc_ord<YD, BM, CLD, NACC, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem,
-                                                                      g_scale, logpx, logpx_miss, pfull, X, xhat, acc, lpo);
+                    proc_ord<YD, BM, CLD, NHEAD, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem,
+                                                                       g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo);
                 else
-                    proc_ord<YD, BM, CLD, NACC, KMAX>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
-                                                      logpx_miss, pfull, X, xhat, acc, lpo);
+                    proc_ord<YD, BM, CLD, NHEAD, KMAX>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                                                       logpx_miss, pfull, X, xhat, hacc, lpo);
                 break;
         }
     } else {   // columns past the last variable: keep the tile clean
 #pragma unroll
-        for (int i = 0; i < BM / 16; ++i)
+        for (int i = 0; i < RPT; ++i)
 #pragma unroll
-            for (int k = 0; k < YD; ++k) Cs[(rg + 16 * i) * CLD + v * YD + k] = 0.f;
+            for (int k = 0; k < YD; ++k) Cs[HL_ROW(rg, i) * CLD + v * YD + k] = 0.f;
     }
+    HL_CLK(4);
     // ELBO row sums over the 16 variables of the tile (wavefront shuffles inside the 16-lane group)
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) {
-        float s = lpo[i];
-        s += __shfl_xor(s, 8, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 1, 64);
-        const int gr = m0 + rg + 16 * i;
+    for (int i = 0; i < RPT; ++i) {
+        const float s = row16_sum(lpo[i]);
+        const int gr = m0 + HL_ROW(rg, i);
         if (v == 0 && gr < Bp) rowpart[(size_t)tn * Bp + gr] = gr < B ? s : 0.f;
     }
+    HL_CLK(5);
     if (!want_grad) return;
-    __syncthreads();                       // every wave is done with the parameter scratch that `red` overlays
-    // head-parameter gradients: 4 lane groups of a wave share v -> shuffle, then 4 waves through LDS
-    const int wave = tid >> 6;
+    // d Y^T [NY][Bp] straight from this thread's own cells of the tile (written by the head functions above: no barrier):
+    // four consecutive rows of one column = one 8-byte store, and the column sums d by on the way
+    if (!conv && d < D) {
 #pragma unroll
-    for (int n = 0; n < NACC; ++n) {
-        float a = acc[n];
-        a = xor32_sum(xor16_sum(a));
-        if ((tid & 63) < 16) red[(wave * 16 + v) * NACC + n] = a;
+        for (int k = 0; k < YD; ++k) {
+            float cs = 0.f;
+#pragma unroll
+            for (int q = 0; q < RPT / 4; ++q) {
+                const float* src = Cs + HL_ROW(rg, 4 * q) * CLD + v * YD + k;
+                const float a0 = src[0], a1 = src[CLD], a2 = src[2 * CLD], a3 = src[3 * CLD];
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(a0) | ((uint32_t)f2bf(a1) << 16);
+                pk.y = (uint32_t)f2bf(a2) | ((uint32_t)f2bf(a3) << 16);
+                *reinterpret_cast<uint2*>(dyT + (size_t)(n0 + v * YD + k) * Bp + m0 + HL_ROW(rg, 4 * q)) = pk;
+                cs += (a0 + a1) + (a2 + a3);
+            }
+            acc[NHEAD + k] = cs;
+        }
     }
-    __syncthreads();   // also orders the dY tile writes above
-    for (int idx = tid; idx < 16 * NACC; idx += HL_THREADS) {
-        const int vv = idx / NACC, n = idx % NACC;
-        const int dd = tn * 16 + vv;
-        if (dd >= D) continue;
-        const hlvae_var vr = vars[dd];
-        const int dst = acc_dest<YD, KMAX>(vr, n);
-        if (dst < 0) continue;
-        const float sum = red[(0 * 16 + vv) * NACC + n] + red[(1 * 16 + vv) * NACC + n] +
-                          red[(2 * 16 + vv) * NACC + n] + red[(3 * 16 + vv) * NACC + n];
-        atomicAdd(G + dst, sum);
-    }
-    // dY tile -> HBM (bf16, both layouts) and d by = column sums.  One 16-byte store (8 bf16) per task; the kernel is bound
-    // by instruction issue (PMC: 29 % active + 20 % issue stalls at 3 waves / SIMD), and the element-pair version of these
-    // loops was ~40 % of its VALU instructions.
-    auto pack8 = [](const float* p, int stride) {
-        uint4 o;
-        o.x = (uint32_t)f2bf(p[0]) | ((uint32_t)f2bf(p[stride]) << 16);
-        o.y = (uint32_t)f2bf(p[2 * stride]) | ((uint32_t)f2bf(p[3 * stride]) << 16);
-        o.z = (uint32_t)f2bf(p[4 * stride]) | ((uint32_t)f2bf(p[5 * stride]) << 16);
-        o.w = (uint32_t)f2bf(p[6 * stride]) | ((uint32_t)f2bf(p[7 * stride]) << 16);
-        return o;
-    };
+    HL_CLK(6);
+    __syncthreads();                       // every wave is done with the scratch and the operand buffers; the dY tile is complete
+    HL_CLK(7);
+    // head-parameter gradients and d by: every thread's accumulators go to LDS as image[n][thread] (conflict-free), a second
+    // pass sums the 16 row groups of each (variable, n) and leaves the tile's partial sums in ws->hgpart [row block][n][variable]
+    // for k_head_grad_reduce.  (Before: two permlane swaps per accumulator + 464 global float atomics per workgroup through an
+    // arena-offset switch: 2.4 k + 5.0 k of a wave's 43 k clocks.)
+    float* img = reinterpret_cast<float*>(smem) + BM * CLD;
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) img[n * RST + tid] = acc[n];
+    HL_CLK(8);
+    // dY tile -> HBM, row-major bf16 [Bp][NYp]: one 16-byte store (8 bf16) per task from two 16-byte LDS reads
     constexpr int CCH = BN / 8;                                   // 8-column chunks per tile row
     for (int idx = tid; idx < BM * CCH; idx += HL_THREADS) {
         const int r = idx / CCH, c = (idx % CCH) * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(Cs + r * CLD + c);
+        const float4 hi = *reinterpret_cast<const float4*>(Cs + r * CLD + c + 4);
         if (n0 + c + 8 <= lddy) {
-            *reinterpret_cast<uint4*>(dy + (size_t)(m0 + r) * lddy + n0 + c) = pack8(Cs + r * CLD + c, 1);
+            uint4 o;
+            o.x = (uint32_t)f2bf(lo.x) | ((uint32_t)f2bf(lo.y) << 16);
+            o.y = (uint32_t)f2bf(lo.z) | ((uint32_t)f2bf(lo.w) << 16);
+            o.z = (uint32_t)f2bf(hi.x) | ((uint32_t)f2bf(hi.y) << 16);
+            o.w = (uint32_t)f2bf(hi.z) | ((uint32_t)f2bf(hi.w) << 16);
+            *reinterpret_cast<uint4*>(dy + (size_t)(m0 + r) * lddy + n0 + c) = o;
         } else {
+            const float e8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             for (int e = 0; e < 8; ++e)
-                if (n0 + c + e < lddy) dy[(size_t)(m0 + r) * lddy + n0 + c + e] = f2bf(Cs[r * CLD + c + e]);
+                if (n0 + c + e < lddy) dy[(size_t)(m0 + r) * lddy + n0 + c + e] = f2bf(e8[e]);
         }
     }
-    if (conv) return;
-    constexpr int RCH = BM / 8;                                   // 8-row chunks per tile column: 8 consecutive lanes = 1 column
-    for (int idx = tid; idx < BN * RCH; idx += HL_THREADS) {
-        const int c = idx / RCH, r = (idx % RCH) * 8;
-        const float* src = Cs + r * CLD + c;
-        float s = 0.f;
+    HL_CLK(9);
+    __syncthreads();
+    HL_CLK(10);
+    const int NTV = (int)(gridDim.x / tiles_m) * 16;               // variables, padded to whole tiles
+    float* out = hgpart + (size_t)(m0 / BM) * NACC * NTV + tn * 16;
+    for (int idx = tid; idx < 16 * NACC; idx += HL_THREADS) {
+        const int vv = idx & 15, n = idx >> 4;
+        const float* src = img + n * RST + vv;
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += src[e * CLD];
-        if (n0 + c < NY) *reinterpret_cast<uint4*>(dyT + (size_t)(n0 + c) * Bp + m0 + r) = pack8(src, CLD);
-        // d by[c] = column sum: the RCH lanes of a column are consecutive
-#pragma unroll
-        for (int o = 1; o < RCH; o <<= 1) s += __shfl_xor(s, o, 64);
-        if ((idx % RCH) == 0 && n0 + c < NY) atomicAdd(G + o_by + n0 + c, s);
+        for (int q = 0; q < 16; q += 2) { s0 += src[q * 16]; s1 += src[q * 16 + 16]; }
+        out[(size_t)n * NTV + vv] = s0 + s1;
     }
+    HL_CLK(11);
+#undef HL_CLK
+}
+
+// folds the per-row-block partial sums of k_y_heads into the gradient arena: one thread per (accumulator n, variable)
+template <int YD, int KMAX>
+__global__ __launch_bounds__(256) void k_head_grad_reduce(const float* __restrict__ hgpart, int tiles_m, int NTV, int D,
+                                                          const hlvae_var* __restrict__ vars, float* __restrict__ G, long o_by,
+                                                          int conv) {
+    constexpr int NHEAD = HeadAcc<YD, KMAX>::N, NACC = NHEAD + YD;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int dd = idx % NTV, n = idx / NTV;
+    if (n >= NACC || dd >= D) return;
+    int dst;
+    if (n >= NHEAD) {
+        if (conv) return;                                        // y_layer's bias gradient belongs to the convolution kernels there
+        dst = (int)o_by + dd * YD + (n - NHEAD);
+    } else {
+        dst = acc_dest<YD, KMAX>(vars[dd], n);
+    }
+    if (dst < 0) return;
+    const float* src = hgpart + (size_t)n * NTV + dd;
+    const size_t st = (size_t)NACC * NTV;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = 0;
+    for (; t + 4 <= tiles_m; t += 4) { s0 += src[t * st]; s1 += src[(t + 1) * st]; s2 += src[(t + 2) * st]; s3 += src[(t + 3) * st]; }
+    for (; t < tiles_m; ++t) s0 += src[t * st];
+    atomicAdd(G + dst, (s0 + s1) + (s2 + s3));                   // the region is zero at the start of a step: other kernels add to
+}                                                                // their own parts of it concurrently
+
+int hl_launch_head_grad_reduce(const hlvae_plan* p, const hlvae_ws* ws, int Bp, hipStream_t s) {
+    const hlvae_dims& d = p->d;
+    const int NT = (d.D + 15) / 16, NTV = NT * 16, tiles_m = Bp / 64;
+    HL_PROF("head_grad_reduce", s);
+#define HL_RED(YDv, KMv)                                                                                               \
+    k_head_grad_reduce<YDv, KMv><<<(NTV * (HeadAcc<YDv, KMv>::N + YDv) + 255) / 256, 256, 0, s>>>(ws->hgpart, tiles_m, NTV, d.D,    \
+                                                                                                p->vars_dev, ws->G, d.o_by, d.conv)
+    if (d.y_dim == 3) HL_RED(3, 8);
+    else if (d.y_dim == 8) HL_RED(8, 8);
+    else if (p->kmax <= 3) HL_RED(5, 3);
+    else if (p->kmax <= 5) HL_RED(5, 5);
+    else if (p->kmax <= 8) HL_RED(5, 8);
+    else HL_RED(5, 16);
+#undef HL_RED
+    HL_LAUNCH_CHECK();
+    return 0;
 }
 
 // ELBO bookkeeping in ONE block (no atomics, no memset, deterministic):
@@ -771,6 +880,27 @@ __global__ void k_scale_dy(bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict
     }
 }
 
+// phase stamps of every wave (tools/heads_phases.py): HL_HEADS_CLK=1 makes the launcher hand the kernel a buffer
+// [workgroup][wave][12] of clock64() values; nullptr (no stamps) otherwise
+static long long* g_heads_clk = nullptr;
+static int g_heads_clk_n = 0;
+static long long* hl_heads_clk_buffer(int grid) {
+    static const bool on = getenv("HL_HEADS_CLK") != nullptr;
+    if (!on) return nullptr;
+    if (grid > g_heads_clk_n) {
+        if (g_heads_clk) (void)hipFree(g_heads_clk);
+        if (hipMalloc(&g_heads_clk, sizeof(long long) * 48 * grid) != hipSuccess) { g_heads_clk = nullptr; g_heads_clk_n = 0; return nullptr; }
+        g_heads_clk_n = grid;
+    }
+    return g_heads_clk;
+}
+extern "C" int hlvae_debug_heads_clk(long long* host, int max_wg) {
+    if (!g_heads_clk) return 0;
+    const int n = max_wg < g_heads_clk_n ? max_wg : g_heads_clk_n;
+    if (hipMemcpy(host, g_heads_clk, sizeof(long long) * 48 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+
 int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_elem, float g_scale, int want_grad,
                       int want_params, int B, int Bp, hipStream_t s) {
     const hlvae_dims& d = p->d;
@@ -780,30 +910,27 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
     float* pf = want_params == 1 ? ws->pfull : nullptr;      // 1: p_params + x_hat, 2: x_hat only (training metrics)
     float* xh = want_params ? ws->xhat : nullptr;
     HL_REQUIRE(!want_params || (ws->xhat && (want_params != 1 || ws->pfull)), HLVAE_EINVAL, "want_params without pfull/xhat buffers");
+    HL_REQUIRE(!want_grad || ws->hgpart, HLVAE_EINVAL, "want_grad without the ws->hgpart buffer");
     {
         HL_PROF("y_heads_loglik", s);
-        const bool big = (long)(Bp / 128) * NT >= 512;
-        const int grid = NT * (big ? Bp / 128 : Bp / 64);
-#define HL_LAUNCH_HEADS(BMv, KMv)                                                                                      \
-        HL_LAUNCH_HEADS_Y(5, BMv, KMv)
+        // 64-row tiles at every batch size.  A 128-row instance (half the Wy panel re-reads, 2 workgroups per CU) was kept for
+        // >= 512 workgroups in round 1; measured on MI355X at 4096 rows it is no faster (173.3 vs 171.7 us; 33.7 vs 29.6 us at
+        // 512 rows).  Stand-alone the GEMM part takes 12 us and the epilogue 15 us of the kernel's 23 (512 rows): they barely
+        // overlap, because the co-resident workgroups of a CU run in phase; PMC: VALU busy 42 %, 49 % of the wave-cycles waiting
+        const int grid = NT * (Bp / 64);
+        long long* clk = hl_heads_clk_buffer(grid);
+#define HL_LAUNCH_HEADS(KMv) HL_LAUNCH_HEADS_Y(5, 64, KMv)
 #define HL_LAUNCH_HEADS_Y(YDv, BMv, KMv)                                                                               \
-        k_y_heads<YDv, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G, d.o_by,  \
+        k_y_heads<YDv, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->hgpart, d.o_by,  \
                                                           ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, \
                                                           d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing,       \
-                                                          ws->rowpart, pf, d.X, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY)
-        if (d.y_dim != 5) {      // other y_dim (config/hlvae_config_file.txt: y_dim): 64-row tiles, all class counts up to 8
-            const int g64 = NT * (Bp / 64);
-            if (d.y_dim == 3) k_y_heads<3, 64, 8><<<g64, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G,
-                d.o_by, ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, d.NYp, ws->dyT, Bp, ws->log_p_x,
-                ws->log_p_x_missing, ws->rowpart, pf, d.X, xh, B, want_grad, nullptr, d.NY);
-            else k_y_heads<8, 64, 8><<<g64, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->G,
-                d.o_by, ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, d.NYp, ws->dyT, Bp, ws->log_p_x,
-                ws->log_p_x_missing, ws->rowpart, pf, d.X, xh, B, want_grad, nullptr, d.NY);
-        } else
-        if (p->kmax <= 3) { if (big) HL_LAUNCH_HEADS(128, 3); else HL_LAUNCH_HEADS(64, 3); }
-        else if (p->kmax <= 5) { if (big) HL_LAUNCH_HEADS(128, 5); else HL_LAUNCH_HEADS(64, 5); }
-        else if (p->kmax <= 8) { if (big) HL_LAUNCH_HEADS(128, 8); else HL_LAUNCH_HEADS(64, 8); }
-        else { const int g64 = NT * (Bp / 64); const int grid = g64; HL_LAUNCH_HEADS(64, 16); }      // 9..16 classes: one instance
+                                                          ws->rowpart, pf, d.X, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY, clk)
+        if (d.y_dim == 3) HL_LAUNCH_HEADS_Y(3, 64, 8);          // other y_dim (config/hlvae_config_file.txt: y_dim): all class counts up to 8
+        else if (d.y_dim == 8) HL_LAUNCH_HEADS_Y(8, 64, 8);
+        else if (p->kmax <= 3) HL_LAUNCH_HEADS(3);
+        else if (p->kmax <= 5) HL_LAUNCH_HEADS(5);
+        else if (p->kmax <= 8) HL_LAUNCH_HEADS(8);
+        else HL_LAUNCH_HEADS(16);                                // 9..16 classes: one instance
 #undef HL_LAUNCH_HEADS
 #undef HL_LAUNCH_HEADS_Y
     }

@@ -26,8 +26,10 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 22
+#define HLVAE_ABI_VERSION 23
 #define HLVAE_STAT_CHUNKS 16
+/* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
+#define HLVAE_HEAD_ACC 95
 
 #define HLVAE_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define HLVAE_ESHAPE (-2)   /* operand shapes do not match what the kernel grid assumes */
@@ -113,6 +115,8 @@ typedef struct {
     uint16_t* dy; uint16_t* dyT;     /* d loss / d Y   [Bp][NYp], [NY][Bp]                  */
     float* log_p_x; float* log_p_x_missing;   /* [Bp][D]                                    */
     float* rowpart;      /* [ceil(D/16)][Bp] partial row sums of log_p_x                    */
+    float* hgpart;       /* [Bp/64][ceil(D/16)*16][HLVAE_HEAD_ACC] per-row-block partial sums of the head-parameter and y_layer-bias
+                            gradients (k_y_heads); folded into ws->G by the backward pass                             */
     float* nll;          /* [Bp]  -sum_d log_p_x                                            */
     double* scal;        /* [8]: 0 = sum_b nll, 1 = KL(q || N(0,I)) of the batch (extension), 2.. reserved */
     double* klpart;      /* [Bp/4] KL partial sums, one per 4 rows (k_mid_fwd_fused)            */
