@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -102,6 +102,14 @@ _SIGS = {
     "hlvae_gp_param_grad": (C.c_int, [C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp,
                                       C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "hlvae_gp_transform": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "hlvae_gp_spd_inv2": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "hlvae_gp_gemm": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, C.c_int64, _vp, C.c_int, C.c_int64, _vp, C.c_int,
+                                C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
+    "hlvae_gp_bmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
+    "hlvae_gp_resid": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "hlvae_gp_gemv_t_f32": (C.c_int, [_vp, _vp, C.c_long, C.c_long, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "hlvae_gp_natgrad": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "hlvae_gp_natgrad_apply": (C.c_int, [_vp, _vp, C.c_double, C.c_int, C.c_int, _vp]),
     "hlvae_gp_bmm": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
     "hlvae_gp_gemv_t": (C.c_int, [_vp, _vp, C.c_long, C.c_long, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "hlvae_gp_gkxz": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, _vp, _vp]),

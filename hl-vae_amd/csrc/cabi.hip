@@ -30,6 +30,7 @@ int hl_launch_conv_dec_fwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t)
 int hl_launch_conv_dec_bwd(const hlvae_plan*, const hlvae_ws*, int, int, hipStream_t);
 int hl_launch_conv_enc_bwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
 int hl_launch_gemm_f32_group(GemmGroup, const char*, hipStream_t);
+int hl_wgrad_ksplit(long, int);
 int hl_launch_transpose_bf16(const bf16_t*, int, bf16_t*, int, int, int, const char*, hipStream_t);
 int hl_adam_grid(const hlvae_plan*, const hlvae_ws*, unsigned, int);
 int hl_adam_part(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, unsigned, int,
@@ -462,6 +463,10 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     g.p[0] = GemmProb{ws->dtT, ws->xnT, ws->G + d.o_w1, nullptr, Bp, Bp, d.Xe, d.h_e, d.Xe, 0, 0};
     g.p[1] = GemmProb{ws->duT, ws->zbT, ws->G + d.o_wd, nullptr, Bp, Bp, d.L, d.h_d, d.L, 0, 0};
     g.p[2] = GemmProb{ws->dmlT, ws->tT, ws->G + d.o_wmu, ws->G + d.o_wlv, Bp, Bp, d.h_e, 2 * d.Lp, d.h_e, d.Lp, d.L};
+    // few output tiles and a long batch axis (a 64-feature model at 4096 rows: 24 tiles x 64 k-steps): split-K with fp32 atomics
+    // into the (cleared) gradient slices -- they are neighbours in the arena: [Wd | Wmu | Wlv | W1]
+    g.ksplit = hl_wgrad_ksplit((long)((d.h_e + 63) / 64) * ((d.Xe + 63) / 64), Bp);
+    if (g.ksplit > 1) HL_CHECK(hipMemsetAsync(ws->G + d.o_wd, 0, sizeof(float) * (size_t)(d.o_wy - d.o_wd), st));
     if ((rc = hl_launch_gemm_f32_group(g, "dW1_dWd_dWmu", st))) return rc;
     const bool conv_opt = d.conv && opt != nullptr && !skip_wy;
     if (d.conv) {   // the convolutional features receive a gradient: d feat = dT W1, then conv2 / conv1 / representation layer

@@ -57,6 +57,7 @@ struct GemmProb {
 struct GemmGroup {
     GemmProb p[3];
     int n, K;
+    int ksplit, kper, tiles_total;      // split-K over the whole group (launcher fills kper / tiles_total)
 };
 
 enum { HL_PEND_METRICS = 1, HL_PEND_FINALIZE = 2, HL_PEND_RUNNING = 4, HL_PEND_FEED = 8,

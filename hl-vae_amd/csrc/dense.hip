@@ -39,18 +39,31 @@ template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32(const bf16_t* __restrict__ A, int lda,
                                                          const bf16_t* __restrict__ B, int ldb, float* __restrict__ C,
                                                          int ldc, int M, int N, int K, int band, int band_rows,
-                                                         float* __restrict__ C2, int tiles_m, int tiles_n, int n_fast) {
+                                                         float* __restrict__ C2, int tiles_m, int tiles_n, int n_fast, int kper) {
+    // kper < K: split-K -- gridDim.x = tiles x slices, slice s covers k in [s kper, (s + 1) kper) and ADDS its partial tile
+    // (fp32 atomics) into a C the launcher has cleared.  For weight gradients with few output tiles and a long batch axis
+    // (64-feature models at 4096 rows: 40 tiles x 64 k-steps otherwise)
     using G = GemmNT<BM, BN, BK, WM, WN>;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
     // consecutive logical ids (= same XCD) walk the tiles that share the LARGER operand panel
-    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tiles = tiles_m * tiles_n;
+    const int ks = blockIdx.x / tiles;
+    const int lid = xcd_remap(blockIdx.x - ks * tiles, tiles);
     const int tm = n_fast ? lid / tiles_n : lid % tiles_m, tn = n_fast ? lid % tiles_n : lid / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     typename G::Acc acc;
     G::zero(acc);
-    G::run(A, lda, B, ldb, m0, n0, M, N, 0, K, smem, acc);
+    G::run(A, lda, B, ldb, m0, n0, M, N, ks * kper, min(K, (ks + 1) * kper), smem, acc);
     G::to_lds(acc, smem);
     const float* Cs = reinterpret_cast<const float*>(smem);
+    if (kper < K) {
+        for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
+            const int r = idx / BN, c = idx % BN;
+            const int gr = m0 + r, gc = n0 + c;
+            if (gr < M && gc < N) atomicAdd(C + (size_t)gr * ldc + gc, Cs[r * G::CLD + c]);
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
         const int r = idx / BN, c = idx % BN;
         const int gr = m0 + r, gc = n0 + c;
@@ -73,13 +86,16 @@ template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32_group(GemmGroup g) {
     using G = GemmNT<BM, BN, BK, WM, WN>;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
+    // split-K (g.ksplit > 1): gridDim.x = tiles of all problems x slices; every slice adds its partial tiles with fp32 atomics
+    // into outputs the launcher has cleared
+    const int bid = (int)blockIdx.x % g.tiles_total, ks = (int)blockIdx.x / g.tiles_total;
     int pi = 0;
 #pragma unroll
     for (int k = 1; k < 3; ++k)
-        if (k < g.n && (int)blockIdx.x >= g.p[k].tile0) pi = k;
+        if (k < g.n && bid >= g.p[k].tile0) pi = k;
     const GemmProb& q = g.p[pi];
     // problem 0 starts at workgroup 0, so its XCD-contiguous remap is exact; the small problems do not care
-    const int lid = pi == 0 ? xcd_remap(blockIdx.x, q.tiles_m * q.tiles_n) : (int)blockIdx.x - q.tile0;
+    const int lid = pi == 0 ? xcd_remap(bid, q.tiles_m * q.tiles_n) : bid - q.tile0;
     const int tm = q.n_fast ? lid / q.tiles_n : lid % q.tiles_m, tn = q.n_fast ? lid % q.tiles_n : lid / q.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int M = q.M, N = q.N, ldc = q.ldc, band = q.band, band_rows = q.band_rows;
@@ -87,9 +103,22 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32_group(GemmGroup g) {
     float* __restrict__ C2 = q.C2;
     typename G::Acc acc;
     G::zero(acc);
-    G::run(q.A, q.lda, q.B, q.ldb, m0, n0, M, N, 0, g.K, smem, acc);
+    G::run(q.A, q.lda, q.B, q.ldb, m0, n0, M, N, ks * g.kper, min(g.K, (ks + 1) * g.kper), smem, acc);
     G::to_lds(acc, smem);
     const float* Cs = reinterpret_cast<const float*>(smem);
+    if (g.ksplit > 1) {
+        for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
+            const int r = idx / BN, c = idx % BN;
+            const int gr = m0 + r, gc = n0 + c;
+            if (gr >= M || gc >= N) continue;
+            float* dst = nullptr;
+            if (band <= 0) dst = C + (size_t)gr * ldc + gc;
+            else if (gr < band_rows) dst = C + (size_t)gr * ldc + gc;
+            else if (gr >= band && gr < band + band_rows) dst = C2 + (size_t)(gr - band) * ldc + gc;
+            if (dst != nullptr) atomicAdd(dst, Cs[r * G::CLD + c]);
+        }
+        return;
+    }
     // (applying Adam to the finished tile right here -- no gradient round trip through HBM, no optimiser launch -- was
     // built and measured: 0.190 vs 0.166 ms/step.  1-2 workgroups per CU cannot keep enough bytes in flight for a streaming
     // epilogue, and the two fused launches contend for HBM exactly when the critical path needs it.)
@@ -184,16 +213,30 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_act(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------------
 // host launchers (called from cabi.hip)
 // ------------------------------------------------------------------------------------------------
+// slices of K for a weight-gradient GEMM with `tiles` 64 x 64 output tiles: none when the tiles alone fill the chip
+int hl_wgrad_ksplit(long tiles, int K) {
+    int ks = 1;
+    while (tiles * ks < 192 && K / (2 * ks) >= 256 && ks < 16) ks *= 2;
+    return ks;
+}
+
 int hl_launch_gemm_f32(const bf16_t* A, int lda, const bf16_t* B, int ldb, float* C, int ldc, int M, int N, int K,
                        int band, int band_rows, float* C2, const char* label, hipStream_t s) {
     HL_REQUIRE(K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0, HLVAE_ESHAPE, "gemm_f32: K=%d lda=%d ldb=%d", K, lda, ldb);
-    HL_PROF(label, s);
     const int n_fast = M >= N;      // A is the larger operand: its row panel is reused by consecutive ids
+    // split-K: few 64 x 64 output tiles and a long K (the batch axis of a weight gradient)
+    const int ksplit = band <= 0 ? hl_wgrad_ksplit((long)((M + 63) / 64) * ((N + 63) / 64), K) : 1;
+    const int kper = ksplit > 1 ? ru((K + ksplit - 1) / ksplit, 64) : K;
+    if (ksplit > 1) {
+        HL_REQUIRE(ldc == N, HLVAE_ESHAPE, "gemm_f32: split-K needs a dense C");
+        HL_CHECK(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s));
+    }
+    HL_PROF(label, s);
 #define HL_GO(BMv, BNv, BKv, WMv, WNv)                                                                          \
     {                                                                                                           \
         const int tm = (M + BMv - 1) / BMv, tn = (N + BNv - 1) / BNv;                                           \
-        k_gemm_f32<BMv, BNv, BKv, WMv, WNv><<<tm * tn, HL_THREADS, 0, s>>>(A, lda, B, ldb, C, ldc, M, N, K, band, \
-                                                                          band_rows, C2, tm, tn, n_fast);       \
+        k_gemm_f32<BMv, BNv, BKv, WMv, WNv><<<tm * tn * ((K + kper - 1) / kper), HL_THREADS, 0, s>>>(A, lda, B, ldb, C, ldc, M, N, K, \
+                                                                          band, band_rows, C2, tm, tn, n_fast, kper); \
     }
     if (N <= 32) {
         if (K % 64 == 0) HL_GO(64, 32, 64, 4, 1) else HL_GO(64, 32, 32, 4, 1)
@@ -210,6 +253,10 @@ int hl_launch_gemm_f32(const bf16_t* A, int lda, const bf16_t* B, int ldb, float
 // grouped launch: every problem uses the tile shape chosen for problem 0 (the large one)
 int hl_launch_gemm_f32_group(GemmGroup g, const char* label, hipStream_t s) {
     HL_REQUIRE(g.n >= 1 && g.n <= 3 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm group: n=%d K=%d", g.n, g.K);
+    // g.ksplit (set by the caller, who clears the outputs when it is > 1) slices K for every problem of the group
+    if (g.ksplit < 1) g.ksplit = 1;
+    g.kper = g.ksplit > 1 ? ru((g.K + g.ksplit - 1) / g.ksplit, 64) : g.K;
+    const int slices = (g.K + g.kper - 1) / g.kper;
     const bool big = !(g.p[0].M <= 64 || (long)((g.p[0].M + 127) / 128) * ((g.p[0].N + 63) / 64) < 192);
     const int BMv = big ? 128 : 64;
     int t = 0;
@@ -222,6 +269,8 @@ int hl_launch_gemm_f32_group(GemmGroup g, const char* label, hipStream_t s) {
         q.tile0 = t;
         t += q.tiles_m * q.tiles_n;
     }
+    g.tiles_total = t;
+    t *= slices;
     HL_PROF(label, s);
     if (big) {
         if (g.K % 64 == 0) k_gemm_f32_group<128, 64, 64, 2, 2><<<t, HL_THREADS, 0, s>>>(g);

@@ -7,11 +7,14 @@
 // k_colstats / k_normalize_pack on the expanded fp64 form (one-hot / thermometer columns are regenerated on the fly).
 #include "common.h"
 
-__global__ __launch_bounds__(256) void k_colstats_compact(const float* __restrict__ vals, const uint8_t* __restrict__ mk,
+__global__ __launch_bounds__(1024) void k_colstats_compact(const float* __restrict__ vals, const uint8_t* __restrict__ mk,
                                                           const int32_t* __restrict__ rows, const hlvae_var* __restrict__ vars,
                                                           const int32_t* __restrict__ stat_var, int n_stat, int D, int B,
                                                           double* __restrict__ sums) {
-    __shared__ double red[3][4][64];
+    // blockDim = (64 statistic columns, RL row lanes): RL = 4, or 16 for chunks of >= 128 rows (batches of >= 2048 rows: with 4
+    // lanes a 64-feature model's whole input stage was 16 workgroups walking 256 rows each, 28 us)
+    __shared__ double red[3][16][64];
+    const int RL = blockDim.y;
     const int sc = blockIdx.x * 64 + threadIdx.x;
     const int rpc = (B + HL_STAT_CHUNKS - 1) / HL_STAT_CHUNKS;
     const int b_lo = blockIdx.y * rpc, b_hi = min(B, b_lo + rpc);
@@ -22,12 +25,12 @@ __global__ __launch_bounds__(256) void k_colstats_compact(const float* __restric
         // two dependent gathers per entry (row index, then value + mask): 8 entries in flight per lane -- at 512 rows the
         // kernel is one such round, pure latency
         constexpr int U = 8;
-        for (int bb = b_lo + threadIdx.y; bb < b_hi; bb += 4 * U) {
+        for (int bb = b_lo + threadIdx.y; bb < b_hi; bb += RL * U) {
             int rr[U];
             float xv[U];
             uint8_t mm[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) rr[u] = bb + 4 * u < b_hi ? rows[bb + 4 * u] : -1;
+            for (int u = 0; u < U; ++u) rr[u] = bb + RL * u < b_hi ? rows[bb + RL * u] : -1;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const size_t o = (size_t)max(rr[u], 0) * D + d;
@@ -51,9 +54,11 @@ __global__ __launch_bounds__(256) void k_colstats_compact(const float* __restric
     __syncthreads();
     if (threadIdx.y == 0 && sc < n_stat) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            sums[((size_t)blockIdx.y * 3 + k) * n_stat + sc] =
-                red[k][0][threadIdx.x] + red[k][1][threadIdx.x] + red[k][2][threadIdx.x] + red[k][3][threadIdx.x];
+        for (int k = 0; k < 3; ++k) {
+            double t = 0.0;
+            for (int y = 0; y < RL; ++y) t += red[k][y][threadIdx.x];
+            sums[((size_t)blockIdx.y * 3 + k) * n_stat + sc] = t;
+        }
     }
 }
 
@@ -152,7 +157,7 @@ int hl_launch_stats_compact(const hlvae_plan* p, const hlvae_ws* ws, const float
     const hlvae_dims& d = p->d;
     if (d.n_stat == 0) return 0;
     HL_PROF("colstats", s);
-    k_colstats_compact<<<dim3((d.n_stat + 63) / 64, HL_STAT_CHUNKS), dim3(64, 4), 0, s>>>(vals, mk, rows, p->vars_dev, p->stat_var_dev,
+    k_colstats_compact<<<dim3((d.n_stat + 63) / 64, HL_STAT_CHUNKS), dim3(64, B >= 2048 ? 16 : 4), 0, s>>>(vals, mk, rows, p->vars_dev, p->stat_var_dev,
                                                                                           d.n_stat, d.D, B, ws->sums);
     HL_LAUNCH_CHECK();
     return 0;

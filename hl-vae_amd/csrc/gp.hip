@@ -206,7 +206,8 @@ __device__ __forceinline__ void gj_pivots(double (&a)[NB][NB], double* row, doub
 }
 
 __global__ __launch_bounds__(256) void k_gp_spd_inv(const double* __restrict__ A, int N, double* __restrict__ inv,
-                                                    double* __restrict__ logdet, int* __restrict__ fail) {
+                                                    double* __restrict__ logdet, int* __restrict__ fail, int n_neg,
+                                                    double* __restrict__ logdet_neg) {
     __shared__ double row[2 * GP_MMAX], col[2 * GP_MMAX];
     __shared__ double pv[GP_MMAX];
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
@@ -246,7 +247,10 @@ __global__ __launch_bounds__(256) void k_gp_spd_inv(const double* __restrict__ A
         }
         ld = wave_sum_d(ld);
         if (bad && fail != nullptr) atomicExch(fail, 1);
-        if (tid == 0) logdet[blockIdx.x] = ld;
+        if (tid == 0) {
+            logdet[blockIdx.x] = ld;
+            if ((int)blockIdx.x < n_neg) logdet_neg[blockIdx.x] = -ld;       // log det of the INVERSE (H_new from iH_new)
+        }
     }
 }
 
@@ -698,6 +702,189 @@ __global__ __launch_bounds__(256) void k_gp_bmm(const double* __restrict__ A, co
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// general batched fp64 product on the matrix cores (the rectangular products of the bound that round 1 left to the library):
+//     C[l] (M x N) = alpha op(A[l]) B[l] + beta D[l],      op(A) = A ([M][K] rows, lda) or A^T (A stored [K][M], lda)
+//     W = Kxz^T V   (TA, M = N = inducing points, K = batch rows)        elbo_functions.py:256-261 summed over subjects
+//     Y = V (iK - iK H iK)   (M = batch rows, K = N = inducing points)
+// One workgroup = one TM x 32 tile; K walks through LDS in chunks of 32 with the next chunk's global loads in flight in
+// registers while the MFMAs (v_mfma_f64_16x16x4_f64) run on the current one.  split-K (gridDim.x > tiles): the slices add
+// their partial tiles with fp64 atomics into a C the launcher has cleared (beta / D then belong to slice 0).
+// ------------------------------------------------------------------------------------------------------------
+#define GP_GK 32
+template <int TM, int TA>
+__global__ __launch_bounds__(256) void k_gp_gemm(const double* __restrict__ A, int lda, long sA, const double* __restrict__ B, int ldb,
+                                                 long sB, const double* D, int ldd, long sD, double* C, int ldc, long sC, int M,
+                                                 int N, int K, int tiles_n, int ksplit, double alpha, double beta) {
+    constexpr int LA = GP_GK + 1, LB = 32 + 1;
+    __shared__ double As[TM * LA], Bs[GP_GK * LB];
+    const int l = blockIdx.z, ks = blockIdx.y;
+    const int m0 = (blockIdx.x / tiles_n) * TM, n0 = (blockIdx.x % tiles_n) * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* Al = A + (size_t)l * sA;
+    const double* Bl = B + (size_t)l * sB;
+    const int kper = ((K + ksplit - 1) / ksplit + GP_GK - 1) / GP_GK * GP_GK;
+    const int kb = ks * kper, ke = min(K, kb + kper);
+    constexpr int NA = TM * GP_GK / 256, NBv = GP_GK * 32 / 256;       // elements per thread and chunk
+    double ra[NA], rb[NBv];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int e = tid + 256 * u;
+            int r, k;
+            if (TA) { k = e / TM; r = e - k * TM; } else { r = e / GP_GK; k = e - r * GP_GK; }     // contiguous axis fastest
+            const bool in = m0 + r < M && k0 + k < ke;
+            ra[u] = in ? (TA ? Al[(size_t)(k0 + k) * lda + m0 + r] : Al[(size_t)(m0 + r) * lda + k0 + k]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NBv; ++u) {
+            const int e = tid + 256 * u, k = e >> 5, c = e & 31;
+            rb[u] = (k0 + k < ke && n0 + c < N) ? Bl[(size_t)(k0 + k) * ldb + n0 + c] : 0.0;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int e = tid + 256 * u;
+            int r, k;
+            if (TA) { k = e / TM; r = e - k * TM; } else { r = e / GP_GK; k = e - r * GP_GK; }
+            As[r * LA + k] = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NBv; ++u) {
+            const int e = tid + 256 * u;
+            Bs[(e >> 5) * LB + (e & 31)] = rb[u];
+        }
+    };
+    // waves: TM = 32 -> 2 x 2 fragments of 16 x 16; TM = 64 -> 4 row blocks x 2 column fragments each
+    constexpr int NJ = TM == 32 ? 1 : 2;
+    const int wr = TM == 32 ? (wave & 1) : wave, wc = TM == 32 ? (wave >> 1) : 0;
+    f64x4_t acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    if (kb < ke) {
+        gload(kb);
+        for (int k0 = kb; k0 < ke; k0 += GP_GK) {
+            __syncthreads();                               // the previous chunk's MFMAs have read their operands
+            lstore();
+            __syncthreads();
+            if (k0 + GP_GK < ke) gload(k0 + GP_GK);
+            const double* ap = As + (wr * 16 + (lane & 15)) * LA + (lane >> 4);
+            const double* bp = Bs + (lane >> 4) * LB + wc * 16 + (lane & 15);
+#pragma unroll
+            for (int k = 0; k < GP_GK; k += 4) {
+                const double a = ap[k];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * LB + 16 * j], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    const double* Dl = D != nullptr ? D + (size_t)l * sD : nullptr;
+    double* Cl = C + (size_t)l * sC;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wr * 16 + (lane >> 4) + 4 * r, col = n0 + wc * 16 + 16 * j + (lane & 15);
+            if (row < M && col < N) {
+                double v = alpha * acc[j][r];
+                if (ksplit > 1) {
+                    if (ks == 0 && Dl != nullptr) v += beta * Dl[(size_t)row * ldd + col];
+                    atomicAdd(Cl + (size_t)row * ldc + col, v);
+                } else {
+                    if (Dl != nullptr) v += beta * Dl[(size_t)row * ldd + col];
+                    Cl[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+}
+
+// out[l] = alpha A[l] x[l] + beta y[l]      (A: [batch][N][N] row-major, x, y, out: [batch][N]; y may be null or alias out)
+// eight lanes per row, one workgroup per matrix: the matrix-vector products of the natural gradient (iK m, Bm m, iK P1, H tmp)
+__global__ __launch_bounds__(1024) void k_gp_bmv(const double* __restrict__ A, const double* __restrict__ x, const double* y,
+                                                 double* out, int N, double alpha, double beta) {
+    const int l = blockIdx.x, sub = threadIdx.x & 7;
+    const double* Al = A + (size_t)l * N * N;
+    const double* xl = x + (size_t)l * N;
+    for (int i = threadIdx.x >> 3; i < N; i += 128) {
+        double s = 0.0;
+        for (int j = sub; j < N; j += 8) s += Al[(size_t)i * N + j] * xl[j];
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (sub == 0) out[(size_t)l * N + i] = alpha * s + (y != nullptr ? beta * y[(size_t)l * N + i] : 0.0);
+    }
+}
+
+// resid[l][b] = sum_m Kxz[l][b][m] w[l][m] - mu[b][l]      (A_part of elbo_functions.py:230; mu = the VAE's fp32 encoder means)
+__global__ __launch_bounds__(256) void k_gp_resid(const double* __restrict__ Kxz, const double* __restrict__ w,
+                                                  const float* __restrict__ mu, int L, int Bn, int M, double* __restrict__ out) {
+    const int sub = threadIdx.x & 7;
+    const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);       // (l, b) flattened
+    if (row >= (long)L * Bn) return;
+    const int l = (int)(row / Bn), b = (int)(row - (long)l * Bn);
+    const double* kr = Kxz + (size_t)row * M;
+    const double* wl = w + (size_t)l * M;
+    double s = 0.0;
+    for (int m = sub; m < M; m += 8) s += kr[m] * wl[m];
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    if (sub == 0) out[row] = s - (double)mu[(size_t)b * L + l];
+}
+
+// Natural-gradient terms and the right-hand side of the (m, H) update in one launch per latent (elbo_functions.py:279-283,
+// training.py:130-137):
+//     grad_m = -(iK P1) + Bm m,   grad_H = (Bm - iH) / 2,
+//     tmp    = iH m - lr (grad_m - 2 grad_H m)      (H_new tmp = the updated m, once iH has been updated and inverted)
+// Bm = iK W iK + iK.  One workgroup per latent, eight lanes per matrix row.
+__global__ __launch_bounds__(1024) void k_gp_natgrad(const double* __restrict__ Bm, const double* __restrict__ iK,
+                                                     const double* __restrict__ iH, const double* __restrict__ m,
+                                                     const double* __restrict__ P1, double lr, int N, double* __restrict__ grad_m,
+                                                     double* __restrict__ tmp) {
+    __shared__ double ms[GP_MMAX], ps[GP_MMAX];
+    const int l = blockIdx.x, sub = threadIdx.x & 7;
+    const size_t o = (size_t)l * N * N;
+    if (threadIdx.x < N) { ms[threadIdx.x] = m[(size_t)l * N + threadIdx.x]; ps[threadIdx.x] = P1[(size_t)l * N + threadIdx.x]; }
+    __syncthreads();
+    for (int i = threadIdx.x >> 3; i < N; i += 128) {
+        double bm = 0.0, kp = 0.0, hm = 0.0;
+        for (int j = sub; j < N; j += 8) {
+            bm += Bm[o + (size_t)i * N + j] * ms[j];
+            kp += iK[o + (size_t)i * N + j] * ps[j];
+            hm += iH[o + (size_t)i * N + j] * ms[j];
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            bm += __shfl_xor(bm, off, 64);
+            kp += __shfl_xor(kp, off, 64);
+            hm += __shfl_xor(hm, off, 64);
+        }
+        if (sub == 0) {
+            const double gm = bm - kp;                           // grad_m
+            const double ghm = 0.5 * (bm - hm);                  // grad_H m
+            grad_m[(size_t)l * N + i] = gm;
+            tmp[(size_t)l * N + i] = hm - lr * (gm - 2.0 * ghm);
+        }
+    }
+}
+
+// grad_H = (Bm - iH) / 2, element-wise (elbo_functions.py:283)
+__global__ __launch_bounds__(256) void k_gp_natgrad_h(const double* __restrict__ Bm, const double* __restrict__ iH, int n,
+                                                      double* __restrict__ grad_H) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n) grad_H[e] = 0.5 * (Bm[e] - iH[e]);
+}
+// iH <- iH + lr (grad_H + grad_H^T)   (training.py:131-133), in place: the input of the end-of-step inversion
+__global__ __launch_bounds__(256) void k_gp_ih_update(const double* __restrict__ grad_H, double* __restrict__ iH, double lr, int N,
+                                                      int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int NN = N * N, l = e / NN, ij = e - l * NN, i = ij / N, j = ij - i * N;
+    iH[e] += lr * (grad_H[e] + grad_H[(size_t)l * NN + (size_t)j * N + i]);
+}
+
 // R + R^T of the inducing-point covariance gradient in one pass (elbo_functions.py of this package, kl_and_grads):
 //     out = c (u m^T + m u^T - W + X + X^T) + H + m m^T           per latent, N x N, u and m are N-vectors
 __global__ __launch_bounds__(256) void k_gp_rsym(const double* __restrict__ u, const double* __restrict__ m, const double* __restrict__ W,
@@ -714,12 +901,13 @@ __global__ __launch_bounds__(256) void k_gp_rsym(const double* __restrict__ u, c
 // out[l][m] = sum_b A[l][b][m] x[l][b]: the two matrix^T-vector products of the bound (Kxz^T v, V^T mu).  As batched GEMMs with
 // one column the library reads the 15.7 MB operand at 0.5 TB/s (32 us each); here one workgroup per latent streams its slab:
 // thread = (column m, one of 1024 / 128 row groups), partials folded through LDS -- no atomics, nothing to zero.
-__global__ __launch_bounds__(1024) void k_gp_gemv_t(const double* __restrict__ A, const double* __restrict__ x, long xs_l, long xs_b,
+template <typename XT>
+__global__ __launch_bounds__(1024) void k_gp_gemv_t(const double* __restrict__ A, const XT* __restrict__ x, long xs_l, long xs_b,
                                                     double* __restrict__ out, int Bn, int M) {
     __shared__ double red[8][GP_MMAX];
     const int l = blockIdx.x, m = threadIdx.x & 127, g = threadIdx.x >> 7;
     const double* Al = A + (size_t)l * Bn * M;
-    const double* xl = x + (size_t)l * xs_l;
+    const XT* xl = x + (size_t)l * xs_l;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     if (m < M) {
         int b = g;
@@ -728,12 +916,12 @@ __global__ __launch_bounds__(1024) void k_gp_gemv_t(const double* __restrict__ A
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 t[k] = Al[(size_t)(b + 8 * k) * M + m];
-                xv[k] = xl[(size_t)(b + 8 * k) * xs_b];
+                xv[k] = (double)xl[(size_t)(b + 8 * k) * xs_b];
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k & 3] += t[k] * xv[k];
         }
-        for (; b < Bn; b += 8) acc[0] += Al[(size_t)b * M + m] * xl[(size_t)b * xs_b];
+        for (; b < Bn; b += 8) acc[0] += Al[(size_t)b * M + m] * (double)xl[(size_t)b * xs_b];
     }
     red[g][m] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
@@ -773,7 +961,7 @@ __global__ __launch_bounds__(256) void k_gp_bound(const double* __restrict__ par
     double ac = 0.0, au = 0.0;
     for (int e = g; e < LMM; e += stride) {
         const double w = W[e], ik = iK[e];
-        ac += (Qm[e] - ik) * w;
+        ac -= Qm[e] * w;                                   // Qm holds N1 = iK - iK H iK:  sum((Q - iK) o W)
         au += ik * H[e];
     }
     for (int e = g; e < n_part; e += stride) ac += part[e];
@@ -868,7 +1056,7 @@ int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* hyp, int n_sl
 int hlvae_gp_chol_inv(const double* A, int n, int N, double* inv, double* logdet, int* fail, hlvae_stream s) {
     HL_REQUIRE(A && inv && logdet && n > 0 && N > 0 && N <= GP_MMAX, HLVAE_EINVAL, "gp_chol_inv: N=%d (max %d)", N, GP_MMAX);
     HL_PROF("gp_spd_inv", (hipStream_t)s);
-    k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail);
+    k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, 0, nullptr);
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -943,7 +1131,7 @@ int hlvae_gp_gemv_t(const double* A, const double* x, long x_stride_l, long x_st
                     hlvae_stream s) {
     HL_REQUIRE(A && x && out && L >= 1 && B >= 1 && M >= 1 && M <= GP_MMAX, HLVAE_EINVAL, "gp_gemv_t: L=%d B=%d M=%d", L, B, M);
     HL_PROF("gp_gemv_t", (hipStream_t)s);
-    k_gp_gemv_t<<<L, 1024, 0, (hipStream_t)s>>>(A, x, x_stride_l, x_stride_b, out, B, M);
+    k_gp_gemv_t<double><<<L, 1024, 0, (hipStream_t)s>>>(A, x, x_stride_l, x_stride_b, out, B, M);
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -976,6 +1164,95 @@ int hlvae_gp_bound(const double* part, int S, const double* W, const double* iK,
     HL_PROF("gp_bound", (hipStream_t)s);
     k_gp_bound<<<128, 256, 0, (hipStream_t)s>>>(part, S * L * 4, W, iK, Qm, H, L * M * M, m, iKm, L * M, ldK, ldH, L, lv, B * L, c,
                                               rep, konst, out);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_spd_inv2(const double* A, int n, int N, double* inv, double* logdet, int n_neg, double* logdet_neg, int* fail,
+                      hlvae_stream s) {
+    HL_REQUIRE(A && inv && logdet && n > 0 && N > 0 && N <= GP_MMAX && n_neg >= 0 && n_neg <= n && (n_neg == 0 || logdet_neg),
+               HLVAE_EINVAL, "gp_spd_inv2: N=%d (max %d) n=%d n_neg=%d", N, GP_MMAX, n, n_neg);
+    HL_PROF("gp_spd_inv", (hipStream_t)s);
+    k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, n_neg, logdet_neg);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_gemm(const double* A, int lda, int64_t strideA, int transA, const double* B, int ldb, int64_t strideB, const double* D,
+                  int ldd, int64_t strideD, double* C, int ldc, int64_t strideC, int M, int N, int K, int batch, double alpha,
+                  double beta, hlvae_stream s) {
+    HL_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && batch >= 1, HLVAE_EINVAL, "gp_gemm: M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    HL_REQUIRE(lda >= (transA ? M : K) && ldb >= N && ldc >= N && (D == nullptr || ldd >= N), HLVAE_ESHAPE, "gp_gemm: leading dimensions");
+    hipStream_t st = (hipStream_t)s;
+    const int TM = M >= 256 ? 64 : 32;
+    const int tiles_n = (N + 31) / 32, tiles_m = (M + TM - 1) / TM;
+    // few output tiles and a long K (W = Kxz^T V: 16 tiles per latent, K = batch rows): slices of K add into a cleared C
+    int ksplit = 1;
+    while ((long)tiles_m * tiles_n * batch * ksplit < 1024 && K / (2 * ksplit) >= 4 * GP_GK) ksplit *= 2;
+    if (ksplit > 1) {
+        HL_REQUIRE(D == nullptr || D != C, HLVAE_EINVAL, "gp_gemm: D aliasing C is not available with split-K");
+        HL_REQUIRE(ldc == N && strideC == (int64_t)M * N, HLVAE_ESHAPE, "gp_gemm: split-K needs a dense C");
+        HL_CHECK(hipMemsetAsync(C, 0, sizeof(double) * (size_t)batch * M * N, st));
+    }
+    HL_PROF("gp_gemm", st);
+    const dim3 grid(tiles_m * tiles_n, ksplit, batch);
+#define HL_GG(TMv, TAv) k_gp_gemm<TMv, TAv><<<grid, 256, 0, st>>>(A, lda, strideA, B, ldb, strideB, D, ldd, strideD, C, ldc, strideC, M, \
+                                                                N, K, tiles_n, ksplit, alpha, beta)
+    if (TM == 64) { if (transA) HL_GG(64, 1); else HL_GG(64, 0); }
+    else { if (transA) HL_GG(32, 1); else HL_GG(32, 0); }
+#undef HL_GG
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_bmv(const double* A, const double* x, const double* y, double* out, int N, int batch, double alpha, double beta,
+                 hlvae_stream s) {
+    HL_REQUIRE(A && x && out && N >= 1 && N <= GP_MMAX && batch >= 1, HLVAE_EINVAL, "gp_bmv: N=%d batch=%d", N, batch);
+    HL_PROF("gp_bmv", (hipStream_t)s);
+    k_gp_bmv<<<batch, 1024, 0, (hipStream_t)s>>>(A, x, y, out, N, alpha, beta);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_resid(const double* Kxz, const double* w, const float* mu, int L, int B, int M, double* out, hlvae_stream s) {
+    HL_REQUIRE(Kxz && w && mu && out && L >= 1 && B >= 1 && M >= 1, HLVAE_EINVAL, "gp_resid: bad arguments");
+    const long rows = (long)L * B;
+    HL_PROF("gp_resid", (hipStream_t)s);
+    k_gp_resid<<<(int)((rows + 31) / 32), 256, 0, (hipStream_t)s>>>(Kxz, w, mu, L, B, M, out);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_gemv_t_f32(const double* A, const float* x, long x_stride_l, long x_stride_b, double* out, int L, int B, int M,
+                        hlvae_stream s) {
+    HL_REQUIRE(A && x && out && L >= 1 && B >= 1 && M >= 1 && M <= GP_MMAX, HLVAE_EINVAL, "gp_gemv_t_f32: L=%d B=%d M=%d", L, B, M);
+    HL_PROF("gp_gemv_t", (hipStream_t)s);
+    k_gp_gemv_t<float><<<L, 1024, 0, (hipStream_t)s>>>(A, x, x_stride_l, x_stride_b, out, B, M);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_natgrad(const double* Bm, const double* iK, const double* iH, const double* m, const double* P1, double lr, int N,
+                     int batch, double* grad_m, double* grad_H, double* tmp, hlvae_stream s) {
+    HL_REQUIRE(Bm && iK && iH && m && P1 && grad_m && grad_H && tmp && N >= 1 && N <= GP_MMAX && batch >= 1, HLVAE_EINVAL,
+               "gp_natgrad: bad arguments");
+    {
+        HL_PROF("gp_natgrad", (hipStream_t)s);
+        k_gp_natgrad<<<batch, 1024, 0, (hipStream_t)s>>>(Bm, iK, iH, m, P1, lr, N, grad_m, tmp);
+        HL_LAUNCH_CHECK();
+    }
+    const int n = batch * N * N;
+    HL_PROF("gp_natgrad_h", (hipStream_t)s);
+    k_gp_natgrad_h<<<(n + 255) / 256, 256, 0, (hipStream_t)s>>>(Bm, iH, n, grad_H);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_natgrad_apply(const double* grad_H, double* iH, double lr, int N, int batch, hlvae_stream s) {
+    HL_REQUIRE(grad_H && iH && N >= 1 && batch >= 1, HLVAE_EINVAL, "gp_natgrad_apply: bad arguments");
+    const int n = batch * N * N;
+    HL_PROF("gp_ih_update", (hipStream_t)s);
+    k_gp_ih_update<<<(n + 255) / 256, 256, 0, (hipStream_t)s>>>(grad_H, iH, lr, N, n);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -762,32 +762,32 @@ __global__ __launch_bounds__(1024) void k_elbo_finalize(const float* __restrict_
 //   k_metrics_partial  grid (D/64, 16 row chunks): part[chunk][6][D] = {max, min, sum_obs, sum_miss, n_obs, n_miss}
 //   k_metrics_finish   combines the 16 partials -> err[3][D] = observed, missing, all
 #define HL_MET_CHUNKS 16
-__global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict__ xt, const uint8_t* __restrict__ m8,
+__global__ __launch_bounds__(1024) void k_metrics_partial(const float* __restrict__ xt, const uint8_t* __restrict__ m8,
                                                          const float* __restrict__ xhat, const hlvae_var* __restrict__ vars,
                                                          int B, int D, float* __restrict__ part, int conv) {
     // conv (types_info['conv'], read_functions.py:366-369): continuous data are divided by 255 (x_hat too for pos / count)
     // and the range normalisation is dropped
-    __shared__ float red[6][4][64];
-    const int d = blockIdx.x * 64 + threadIdx.x, g = threadIdx.y;
+    __shared__ float red[6][16][64];                            // blockDim = (64 variables, RL row lanes), RL = 4 or 16
+    const int d = blockIdx.x * 64 + threadIdx.x, g = threadIdx.y, RL = blockDim.y;
     const int rpc = (B + HL_MET_CHUNKS - 1) / HL_MET_CHUNKS;
     const int b_lo = blockIdx.y * rpc, b_hi = min(B, b_lo + rpc);
     int kind = -1, K = 1;
     if (d < D) { kind = vars[d].kind; K = vars[d].ncls; }
     float mx = -3.4e38f, mn = 3.4e38f, so = 0.f, sm = 0.f, no = 0.f, nm = 0.f;
     if (d < D)
-      for (int b0 = b_lo + g; b0 < b_hi; b0 += 4 * 8) {                      // 8 rows per pass: 24 loads in flight per lane (at 512
+      for (int b0 = b_lo + g; b0 < b_hi; b0 += RL * 8) {                      // 8 rows per pass: 24 loads in flight per lane (at 512
         float xv[8], xhv[8];                                                // rows the whole chunk is one pass: the kernel was a
         uint8_t mv[8];                                                      // chain of 8 dependent-latency iterations, 9.5 us)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const size_t o = (size_t)min(b0 + 4 * u, b_hi - 1) * D + d;
+            const size_t o = (size_t)min(b0 + RL * u, b_hi - 1) * D + d;
             xv[u] = xt[o];
             xhv[u] = xhat[o];
             mv[u] = m8[o];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (b0 + 4 * u >= b_hi) break;
+            if (b0 + RL * u >= b_hi) break;
             float x = xv[u];
             float xh = xhv[u];
             float e;
@@ -813,11 +813,18 @@ __global__ __launch_bounds__(256) void k_metrics_partial(const float* __restrict
     __syncthreads();
     if (g == 0 && d < D) {
         float* out = part + (size_t)blockIdx.y * 6 * D + d;
-        out[0] = fmaxf(fmaxf(red[0][0][threadIdx.x], red[0][1][threadIdx.x]), fmaxf(red[0][2][threadIdx.x], red[0][3][threadIdx.x]));
-        out[D] = fminf(fminf(red[1][0][threadIdx.x], red[1][1][threadIdx.x]), fminf(red[1][2][threadIdx.x], red[1][3][threadIdx.x]));
+        float a = red[0][0][threadIdx.x], b = red[1][0][threadIdx.x], t[4] = {red[2][0][threadIdx.x], red[3][0][threadIdx.x],
+                                                                             red[4][0][threadIdx.x], red[5][0][threadIdx.x]};
+        for (int y = 1; y < RL; ++y) {
+            a = fmaxf(a, red[0][y][threadIdx.x]);
+            b = fminf(b, red[1][y][threadIdx.x]);
 #pragma unroll
-        for (int k = 2; k < 6; ++k)
-            out[(size_t)k * D] = red[k][0][threadIdx.x] + red[k][1][threadIdx.x] + red[k][2][threadIdx.x] + red[k][3][threadIdx.x];
+            for (int k = 0; k < 4; ++k) t[k] += red[k + 2][y][threadIdx.x];
+        }
+        out[0] = a;
+        out[D] = b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[(size_t)(k + 2) * D] = t[k];
     }
 }
 
@@ -855,7 +862,7 @@ int hl_launch_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float
                "step_metrics: needs ws->xhat (decoder_fwd with want_params), ws->metpart and err");
     {
         HL_PROF("metrics_partial", s);
-        k_metrics_partial<<<dim3((d.D + 63) / 64, HL_MET_CHUNKS), dim3(64, 4), 0, s>>>(ws->xt, ws->m8, ws->xhat, p->vars_dev, B,
+        k_metrics_partial<<<dim3((d.D + 63) / 64, HL_MET_CHUNKS), dim3(64, B >= 2048 ? 16 : 4), 0, s>>>(ws->xt, ws->m8, ws->xhat, p->vars_dev, B,
                                                                                       d.D, ws->metpart, d.conv);
     }
     HL_LAUNCH_CHECK();

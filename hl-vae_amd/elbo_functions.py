@@ -320,7 +320,8 @@ class GPPriorHIP:
         self._xchg = torch.zeros(L * M * M + 2 * L * M + 1, **f64)    # [W | P1 | u | bound]: the one DP exchange buffer
         self.last_kld = self._xchg[-1:]
         self._groups = _GroupCache()
-        self._grad_m = self._grad_H = self._iH = None
+        self._grad_m = self._grad_H = self._iH = self._tmp = None
+        self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
             for t in (self._theta, self.m, self._KH):
                 dp.broadcast_(t)
@@ -378,9 +379,63 @@ class GPPriorHIP:
                                             _C.c_double(beta), self._stream()), "gp_bmm")
         return out
 
-    def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None):
+    # ---- device buffers of a step, allocated once per batch geometry (graph capture keeps reading the same addresses) --------
+    def _step_buffers(self, B, S, T, dev):
+        key = (B, S, T)
+        buf = self._bufs.get(key)
+        if buf is None:
+            L, M = self.L, self.M
+            f64 = dict(dtype=torch.float64, device=dev)
+            e = lambda *sh: torch.empty(*sh, **f64)
+            buf = dict(Kxz=e(L, B, M), V=e(L, B, M), Y=e(L, B, M), G_Kxz=e(L, B, M), v=e(L, B), resid=e(L, B),
+                       iB=e(S, L, T, T), K0s=e(S, L, T, T), part=e(S, L, 4),
+                       g_mu=torch.empty(B, L, dtype=torch.float32, device=dev), g_lv=torch.empty(B, L, dtype=torch.float32, device=dev))
+            self._bufs[key] = buf
+            while len(self._bufs) > 8:
+                self._bufs.pop(next(iter(self._bufs)))
+        if self._mm is None:
+            L, M = self.L, self.M
+            f64 = dict(dtype=torch.float64, device=dev)
+            self._mm = {k: torch.empty(L, M, M, **f64) for k in ("HiK", "N1", "T1", "Bm", "HiKW", "Rs", "G_Kzz", "grad_H")}
+            self._mm.update({k: torch.empty(L, M, 1, **f64) for k in ("iKm", "grad_m", "tmp")})
+        return buf
+
+    def _gemm(self, A, transA, Bm_, C, Mo, N, K, alpha=1.0, beta=0.0, D=None):
+        """C[l] = alpha op(A[l]) B[l] + beta D[l] for dense contiguous [L, ., .] fp64 operands (csrc/gp.hip: k_gp_gemm)"""
+        lda, ldb = A.shape[2], Bm_.shape[2]
+        _lib.check(_lib.load().hlvae_gp_gemm(_lib.ptr(A), lda, A.stride(0), int(transA), _lib.ptr(Bm_), ldb, Bm_.stride(0),
+                                             _lib.ptr(D), N if D is not None else 0, D.stride(0) if D is not None else 0,
+                                             _lib.ptr(C), N, C.stride(0), Mo, N, K, self.L, _C.c_double(alpha), _C.c_double(beta),
+                                             self._stream()), "gp_gemm")
+        return C
+
+    def _bmm_into(self, A, B, out, D=None, alpha=1.0, beta=1.0):
+        L, M = self.L, self.M
+        _lib.check(_lib.load().hlvae_gp_bmm(_lib.ptr(A), _lib.ptr(B), _lib.ptr(D), _lib.ptr(out), M, L, _C.c_double(alpha),
+                                            _C.c_double(beta), self._stream()), "gp_bmm")
+        return out
+
+    def _bmv(self, A, x, out, y=None, alpha=1.0, beta=0.0):
+        _lib.check(_lib.load().hlvae_gp_bmv(_lib.ptr(A), _lib.ptr(x), _lib.ptr(y), _lib.ptr(out), self.M, self.L, _C.c_double(alpha),
+                                            _C.c_double(beta), self._stream()), "gp_bmv")
+        return out
+
+    def _spd_inv(self, A, inv, logdet, n_neg=0, logdet_neg=None):
+        _lib.check(_lib.load().hlvae_gp_spd_inv2(_lib.ptr(A), A.shape[0], A.shape[-1], _lib.ptr(inv), _lib.ptr(logdet), n_neg,
+                                                 _lib.ptr(logdet_neg), _lib.ptr(self.fail), self._stream()), "gp_spd_inv2")
+
+    def check(self):
+        """raises if an SPD inversion met a non-positive pivot since the last check (the reference's torch.cholesky raises at
+        once, elbo_functions.py:225-228; here the flag lives on the device and is read where the host reads scalars anyway)"""
+        self.join()
+        if int(self.fail.item()) != 0:
+            self.fail.zero_()
+            raise RuntimeError("GPPriorHIP: a covariance (K0zz, H, iH_new or a subject block) is not positive definite")
+
+    def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None, join=True):
         """mu, log_v: fp32 [B, L] (the workspace tensors of the VAE); returns fp32 [B, L] gradients.  Hyper-parameter
-        and inducing-point gradients are left in ``prm.grad`` / ``zt_list.grad``."""
+        and inducing-point gradients are left in ``prm.grad`` / ``zt_list.grad``.  Every product, reduction and element-wise
+        step runs in the kernels of csrc/gp.hip; no host synchronisation when ``groups`` comes from the sampler."""
         lib, st = _lib.load(), self._stream()
         L, M, Q, B = self.L, self.M, self.Q, mu.shape[0]
         dev = mu.device
@@ -392,75 +447,104 @@ class GPPriorHIP:
         if idx.dtype != torch.int32 or not idx.is_contiguous() or idx.dim() != 2:
             raise ValueError("groups: contiguous int32 [S, T] tensor of batch-row indices, -1 = padding")
         S, T = idx.shape
+        if mu.dtype != torch.float32 or log_v.dtype != torch.float32 or not mu.is_contiguous() or not log_v.is_contiguous():
+            mu, log_v = mu.to(torch.float32).contiguous(), log_v.to(torch.float32).contiguous()
         k0, k1, z = self.k0, self.k1, self.zt_list
+        buf = self._step_buffers(B, S, T, dev)
+        mm = self._mm
         hyp = self._transform()
-        f64 = dict(dtype=torch.float64, device=dev)
-        Kxz = self.kernel_matrix(k0, x, z)
+        Kxz = self.kernel_matrix(k0, x, z, out=buf["Kxz"])
         if self._fact_key != (self._theta._version, self._KH._version):
-            # no factorisation left behind by the previous optimiser step (first step, or parameters touched since):
-            # K0zz (written next to H) and H inverted in one batched launch
+            # no factorisation left behind by the previous optimiser step (first step, or parameters touched since): K0zz
+            # (written next to H) and H inverted straight into their homes
             self.kernel_matrix(k0, z, z, jitter=self.eps, out=self._KH[:L])
-            inv, logdet = self.chol_inv(self._KH)
-            self._iK.copy_(inv[:L]); self._iHb.copy_(inv[L:]); self._ldK.copy_(logdet[:L]); self._ldH.copy_(logdet[L:])
+            self._spd_inv(self._KH[:L], self._iK, self._ldK)
+            self._spd_inv(self.H, self._iHb, self._ldH)
         iK, iH, ldK, ldH = self._iK, self._iHb, self._ldK, self._ldH
         self._iH = iH
-        mu64 = mu.to(torch.float64)
-        iKm = iK @ self.m                                                    # [L,M,1]
-        resid = torch.baddbmm(mu64.t().unsqueeze(2), Kxz, iKm, beta=-1.0).squeeze(2)   # K0xz iK m - mu^T   [L,B]
-        lv32 = log_v.to(torch.float32).contiguous()
-        iB = torch.empty(S, L, T, T, **f64); K0s = torch.empty(S, L, T, T, **f64)
-        V = torch.empty(L, B, M, **f64); v = torch.empty(L, B, **f64); part = torch.empty(S, L, 4, **f64)
-        g_mu = torch.empty(B, L, dtype=torch.float32, device=dev); g_lv = torch.empty(B, L, dtype=torch.float32, device=dev)
+        iKm = self._bmv(iK, self.m, mm["iKm"])                               # [L,M,1]
+        resid = buf["resid"]                                                 # K0xz iK m - mu^T   [L,B]
+        _lib.check(lib.hlvae_gp_resid(_lib.ptr(Kxz), _lib.ptr(iKm), _lib.ptr(mu), L, B, M, _lib.ptr(resid), st), "gp_resid")
+        iB, K0s, V, v, part, g_mu, g_lv = (buf[k] for k in ("iB", "K0s", "V", "v", "part", "g_mu", "g_lv"))
         _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x),
                                             _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(Kxz), B, M, _lib.ptr(resid),
-                                            _lib.ptr(lv32), _C.c_double(c), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
+                                            _lib.ptr(log_v), _C.c_double(c), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
                                             _lib.ptr(part), _lib.ptr(g_mu), _lib.ptr(g_lv), st), "gp_subject_fwd")
-        KxzT = Kxz.transpose(1, 2)
+        # g_mu / g_lv -- all the VAE's backward pass needs -- are final here.  What follows (the bound's value, the natural-gradient
+        # terms, the chain rule into hyper-parameters and inducing points) is two independent chains of latency-bound kernels:
+        # they run side by side on two streams of ours, and with join = False also beside whatever the caller queues next on
+        # its own stream (ELBOTrainer: the VAE's backward pass + optimiser); optimizer_step() / join() wait for them.
+        main = torch.cuda.current_stream(dev)
+        sA, sC = self._streams(dev)
+        HiK = self._bmm_into(self.H, iK, mm["HiK"])
+        N1 = self._bmm_into(iK, HiK, mm["N1"], D=iK, alpha=-1.0, beta=1.0)   # iK - iK H iK
+        sA.wait_stream(main)
+        sC.wait_stream(main)
         LMM, LM = L * M * M, L * M
         W = self._xchg[:LMM].view(L, M, M)
         P1 = self._xchg[LMM:LMM + LM].view(L, M, 1)
         u = self._xchg[LMM + LM:LMM + 2 * LM].view(L, M, 1)
-        torch.bmm(KxzT, V, out=W)                                            # sum_s Ks^T iB Ks   [L,M,M]
-        # P1 = V^T mu (natural-gradient term, elbo_functions.py:262-266) and u = Kxz^T v: one streaming pass per latent each
-        _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(V), _lib.ptr(mu64), mu64.stride(1), mu64.stride(0), _lib.ptr(P1), L, B, M, st), "gp_gemv_t")
-        _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(Kxz), _lib.ptr(v), v.stride(0), v.stride(1), _lib.ptr(u), L, B, M, st), "gp_gemv_t")
-        HiK = self.bmm(self.H, iK)
-        Qm = self.bmm(iK, HiK)                                               # iK H iK
         world = 1 if self.dp is None else self.dp.world
-        _lib.check(lib.hlvae_gp_bound(_lib.ptr(part), S, _lib.ptr(W), _lib.ptr(iK), _lib.ptr(Qm), _lib.ptr(self.H), _lib.ptr(self.m),
-                                      _lib.ptr(iKm), _lib.ptr(ldK), _lib.ptr(ldH), _lib.ptr(lv32), B, L, M, _C.c_double(c),
-                                      _C.c_double(float(self.N_total)), _C.c_double(1.0 / world), _lib.ptr(self.last_kld), st),
-                   "gp_bound")
-        if self.dp is not None:
-            self.dp.allreduce_(self._xchg)                                   # W, P1, u, bound of the GLOBAL batch
-        # natural-gradient terms (elbo_functions.py:279-283)
-        Bm = self.bmm(self.bmm(iK, W), iK, D=iK)                             # iK W iK + iK
-        self._grad_m = torch.baddbmm(Bm @ self.m, iK, P1, alpha=-1.0)        # -(iK P1) + Bm m
-        self._grad_H = 0.5 * (Bm - iH)
-        # analytic gradients w.r.t. kernel matrices, chained into hyper-parameters / inducing points by the HIP kernels
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
-        Y = V @ (iK - Qm)                                                    # [L,B,M]  (local rows)
-        G_Kxz = torch.empty_like(Y)                                          # c [ v (iK m)^T + V (Q - iK) ]
-        _lib.check(lib.hlvae_gp_gkxz(_lib.ptr(Y), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), L, B, M, _lib.ptr(G_Kxz), st), "gp_gkxz")
-        HiKW = self.bmm(HiK, W)
-        # R + R^T with R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T): K0zz's gradient is needed symmetrised.
-        # It is built from global sums only, i.e. replicated: each rank contributes 1 / world of it
-        Rs = torch.empty_like(W)
-        _lib.check(lib.hlvae_gp_rsym(_lib.ptr(u), _lib.ptr(self.m), _lib.ptr(W), _lib.ptr(HiKW), _lib.ptr(self.H), _C.c_double(c), M, L,
-                                     _lib.ptr(Rs), st), "gp_rsym")
-        G_Kzz_s = self.bmm(self.bmm(iK, Rs), iK, D=iK, alpha=-1.0)           # (G + G^T),  G = -(iK R iK) + iK / 2
-        if world > 1:
-            G_Kzz_s = G_Kzz_s / world
-        _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
-                                            S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y),
-                                            _lib.ptr(lv32), _C.c_double(c), _lib.ptr(gprm), st), "gp_subject_bwd")
-        _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
-                                           _lib.ptr(G_Kxz), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kxz)")
-        _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
-                                           _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
-        if self.dp is not None:
-            self.dp.allreduce_(self._gtheta)
+        with torch.cuda.stream(sC):      # chain C: gradient w.r.t. K0xz and the subject blocks
+            st = self._stream()
+            Y = self._gemm(V, False, N1, buf["Y"], B, M, M)                  # V (iK - Q)   [L,B,M]  (local rows)
+            G_Kxz = buf["G_Kxz"]                                             # c [ v (iK m)^T + V (Q - iK) ]
+            _lib.check(lib.hlvae_gp_gkxz(_lib.ptr(Y), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), L, B, M, _lib.ptr(G_Kxz), st), "gp_gkxz")
+            _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
+                                               _lib.ptr(G_Kxz), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kxz)")
+            _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
+                                                S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y),
+                                                _lib.ptr(log_v), _C.c_double(c), _lib.ptr(gprm), st), "gp_subject_bwd")
+        with torch.cuda.stream(sA):      # chain A: the sums over subjects, the bound, natural gradient, gradient w.r.t. K0zz
+            st = self._stream()
+            self._gemm(Kxz, True, V, W, M, M, B)                             # sum_s Ks^T iB Ks = Kxz^T V   [L,M,M]
+            # P1 = V^T mu (natural-gradient term, elbo_functions.py:262-266) and u = Kxz^T v: one streaming pass per latent each
+            _lib.check(lib.hlvae_gp_gemv_t_f32(_lib.ptr(V), _lib.ptr(mu), 1, L, _lib.ptr(P1), L, B, M, st), "gp_gemv_t_f32")
+            _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(Kxz), _lib.ptr(v), v.stride(0), v.stride(1), _lib.ptr(u), L, B, M, st), "gp_gemv_t")
+            _lib.check(lib.hlvae_gp_bound(_lib.ptr(part), S, _lib.ptr(W), _lib.ptr(iK), _lib.ptr(N1), _lib.ptr(self.H), _lib.ptr(self.m),
+                                          _lib.ptr(iKm), _lib.ptr(ldK), _lib.ptr(ldH), _lib.ptr(log_v), B, L, M, _C.c_double(c),
+                                          _C.c_double(float(self.N_total)), _C.c_double(1.0 / world), _lib.ptr(self.last_kld), st),
+                       "gp_bound")
+            if self.dp is not None:
+                self.dp.allreduce_(self._xchg)                               # W, P1, u, bound of the GLOBAL batch
+            # natural-gradient terms (elbo_functions.py:279-283)
+            T1 = self._bmm_into(iK, W, mm["T1"])
+            Bm = self._bmm_into(T1, iK, mm["Bm"], D=iK)                      # iK W iK + iK
+            self._grad_m, self._grad_H, self._tmp = mm["grad_m"], mm["grad_H"], mm["tmp"]
+            _lib.check(lib.hlvae_gp_natgrad(_lib.ptr(Bm), _lib.ptr(iK), _lib.ptr(iH), _lib.ptr(self.m), _lib.ptr(P1),
+                                            _C.c_double(self.ng_lr), M, L, _lib.ptr(self._grad_m), _lib.ptr(self._grad_H),
+                                            _lib.ptr(self._tmp), st), "gp_natgrad")
+            HiKW = self._bmm_into(HiK, W, mm["HiKW"])
+            # R + R^T with R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T): K0zz's gradient is needed symmetrised.
+            # It is built from global sums only, i.e. replicated: each rank contributes 1 / world of it
+            Rs = mm["Rs"]
+            _lib.check(lib.hlvae_gp_rsym(_lib.ptr(u), _lib.ptr(self.m), _lib.ptr(W), _lib.ptr(HiKW), _lib.ptr(self.H), _C.c_double(c), M, L,
+                                         _lib.ptr(Rs), st), "gp_rsym")
+            T1 = self._bmm_into(iK, Rs, mm["T1"])
+            G_Kzz_s = self._bmm_into(T1, iK, mm["G_Kzz"], D=iK, alpha=-1.0 / world, beta=1.0 / world)   # (G + G^T), G = -(iK R iK) + iK / 2
+            _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
+                                               _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
+        self._pending = True
+        if join:
+            self.join()
         return g_mu, g_lv
+
+    def _streams(self, dev):
+        if self._side is None:
+            self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return self._side
+
+    def join(self):
+        """the caller's stream waits for the two chains kl_and_grads left running; (data parallel) the hyper-parameter /
+        inducing-point gradients are then summed over the ranks"""
+        if self._pending:
+            main = torch.cuda.current_stream(self.zt_list.device)
+            for s_ in self._side:
+                main.wait_stream(s_)
+            self._pending = False
+            if self.dp is not None:
+                self.dp.allreduce_(self._gtheta)
 
     # ---- evaluation surface: posterior mean of the latent at new covariates ------------------------------------------
     @torch.no_grad()
@@ -516,25 +600,22 @@ class GPPriorHIP:
         return (a + b).squeeze(2).t().contiguous()                                       # :188
 
     def optimizer_step(self):
-        # Adam on [hyper-parameters | inducing points] (HLVAE_main.py:277-278), one fused kernel, device-side step counter
-        _lib.check(_lib.load().hlvae_gp_adam(_lib.ptr(self._theta), _lib.ptr(self._gtheta), _lib.ptr(self._adam_m),
-                                             _lib.ptr(self._adam_v), self._theta.numel(), _lib.ptr(self._adam_step),
-                                             _C.c_double(self.lr), _C.c_double(0.9), _C.c_double(0.999), _C.c_double(1e-8),
-                                             self._stream()), "gp_adam")
-        # natural-gradient update of (m, H), training.py:130-137, with the register Gauss-Jordan inverse kernel; the same
-        # launch inverts K0zz of the hyper-parameters / inducing points Adam has just produced, for the next step
-        L = self.L
-        iH = self._iH if self._iH is not None else self.chol_inv(self.H.contiguous())[0]
+        """Adam on [hyper-parameters | inducing points] (HLVAE_main.py:277-278; one fused kernel, device-side step counter), then
+        the natural-gradient update of (m, H), training.py:130-137: iH_new = iH + lr (gH + gH^T) in place, ONE batched inversion
+        of [iH_new | K0zz of the parameters Adam has just produced] -> [H_new | iK] straight into their homes (the next step
+        starts with both factorisations and log-determinants in hand), m_new = H_new (iH m - lr (grad_m - 2 gH m))."""
+        if self._iH is None:
+            raise RuntimeError("GPPriorHIP.optimizer_step: call kl_and_grads first (it leaves grad_m, grad_H and the update's right-hand side)")
+        self.join()
+        lib, st, L, M = _lib.load(), self._stream(), self.L, self.M
+        _lib.check(lib.hlvae_gp_adam(_lib.ptr(self._theta), _lib.ptr(self._gtheta), _lib.ptr(self._adam_m),
+                                     _lib.ptr(self._adam_v), self._theta.numel(), _lib.ptr(self._adam_step),
+                                     _C.c_double(self.lr), _C.c_double(0.9), _C.c_double(0.999), _C.c_double(1e-8), st), "gp_adam")
+        _lib.check(lib.hlvae_gp_natgrad_apply(_lib.ptr(self._grad_H), _lib.ptr(self._iHb), _C.c_double(self.ng_lr), M, L, st),
+                   "gp_natgrad_apply")                                       # iH_new, in place in _KH2[:L]
         self._iH = None
-        gH = self._grad_H
-        rhs = torch.baddbmm(self._grad_m, gH, self.m, alpha=-2.0)            # grad_m - 2 grad_H m
-        tmp = torch.baddbmm(rhs, iH, self.m, beta=-self.ng_lr)               # iH m - lr rhs  (the OLD iH: before its update)
-        torch.add(iH, gH + gH.transpose(-1, -2), alpha=self.ng_lr, out=self._iHb)               # iH_new, in place in _KH2[:L]
         self._transform()
         self.kernel_matrix(self.k0, self.zt_list, self.zt_list, jitter=self.eps, out=self._KH2[L:])
-        # [iH_new | K0zz] -> [H_new | iK] straight into their homes (self.H, self._iK) and [. | log det K0zz] into _ldK:
-        # everything stays in place, a captured HIP graph keeps reading the same buffers
-        self.chol_inv(self._KH2, out=(self._HiK, self._ld2))
-        torch.bmm(self.H, tmp, out=self.m)
-        torch.neg(self._ld2[:L], out=self._ldH)                              # log det H_new = - log det iH_new
+        self._spd_inv(self._KH2, self._HiK, self._ld2, n_neg=L, logdet_neg=self._ldH)      # log det H_new = - log det iH_new
+        self._bmv(self.H, self._tmp, self.m)                                 # m_new = H_new tmp
         self._fact_key = (self._theta._version, self._KH._version)

@@ -268,7 +268,10 @@ class ELBOTrainer:
         g_mu = g_lv = None
         kl_w = 1.0 if self.kl == "normal" else 0.0
         if self.kl == "gp":
-            g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch, groups=groups)
+            # the GP prior's own chains (bound, natural gradient, hyper-parameter gradients) keep running on its streams beside
+            # the VAE's backward pass; gp.optimizer_step() below joins them
+            kw = {"join": False} if hasattr(self.gp, "join") else {}
+            g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch, groups=groups, **kw)
         fused_opt = self.dp is None
         if fused_opt:
             # backward and optimiser in one call: y_layer's Adam update runs under the rest of the backward pass

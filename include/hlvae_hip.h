@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 23
+#define HLVAE_ABI_VERSION 24
 #define HLVAE_STAT_CHUNKS 16
 /* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
 #define HLVAE_HEAD_ACC 95
@@ -316,9 +316,35 @@ int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, c
 int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots, int L, int Q, const double* x1, int n1,
                         int per_latent1, const double* x2, int n2, int both_args, const double* G, double* gprm, double* gx2,
                         hlvae_stream s);
+/* hlvae_gp_chol_inv that also writes -logdet of the first n_neg matrices to logdet_neg[0 .. n_neg): the end-of-step inversion of
+ * [iH_new | K0zz] yields [H_new | iK] and needs log det H_new = -log det iH_new (training.py:131-135) */
+int hlvae_gp_spd_inv2(const double* A, int n, int N, double* inv, double* logdet, int n_neg, double* logdet_neg, int* fail,
+                      hlvae_stream s);
+/* batched fp64 product on the matrix cores: C[l] (M x N, ldc) = alpha op(A[l]) B[l] + beta D[l]; op(A) = A ([M][K] rows, lda)
+ * or, transA != 0, A^T with A stored [K][M]; B stored [K][N] (ldb); strides in elements between batch items; D may be NULL.
+ * The rectangular products of the bound: W = Kxz^T V (sum_s Ks^T iB Ks, elbo_functions.py:256-261) and Y = V (iK - iK H iK). */
+int hlvae_gp_gemm(const double* A, int lda, int64_t strideA, int transA, const double* B, int ldb, int64_t strideB, const double* D,
+                  int ldd, int64_t strideD, double* C, int ldc, int64_t strideC, int M, int N, int K, int batch, double alpha,
+                  double beta, hlvae_stream s);
+/* out[l] = alpha A[l] x[l] + beta y[l]  (A [batch][N][N] row-major; x, y, out [batch][N]; y may be NULL or alias out) */
+int hlvae_gp_bmv(const double* A, const double* x, const double* y, double* out, int N, int batch, double alpha, double beta,
+                 hlvae_stream s);
+/* resid[l][b] = sum_m Kxz[l][b][m] w[l][m] - mu[b][l]  (A_part of elbo_functions.py:230; mu fp32 [B][L] = the VAE's encoder means) */
+int hlvae_gp_resid(const double* Kxz, const double* w, const float* mu, int L, int B, int M, double* out, hlvae_stream s);
+/* hlvae_gp_gemv_t with an fp32 vector operand (V^T mu straight from the VAE's fp32 means) */
+int hlvae_gp_gemv_t_f32(const double* A, const float* x, long x_stride_l, long x_stride_b, double* out, int L, int B, int M,
+                        hlvae_stream s);
+/* natural-gradient terms (elbo_functions.py:279-283) and the right-hand side of the (m, H) update (training.py:130-137):
+ *   grad_m = -(iK P1) + Bm m;  grad_H = (Bm - iH) / 2;  tmp = iH m - lr (grad_m - 2 grad_H m)
+ * with Bm = iK W iK + iK [batch][N][N]; m, P1, grad_m, tmp [batch][N].  hlvae_gp_natgrad_apply then updates the precision in
+ * place, iH <- iH + lr (grad_H + grad_H^T) (training.py:131-133): the input of the end-of-step inversion, after which
+ * m_new = H_new tmp (hlvae_gp_bmv). */
+int hlvae_gp_natgrad(const double* Bm, const double* iK, const double* iH, const double* m, const double* P1, double lr, int N,
+                     int batch, double* grad_m, double* grad_H, double* tmp, hlvae_stream s);
+int hlvae_gp_natgrad_apply(const double* grad_H, double* iH, double lr, int N, int batch, hlvae_stream s);
 /* all scalar reductions of the bound (elbo_functions.py:268-285) into *out (device double):
- *   c/2 [sum(part) - sum(W o iK) + sum(Qm o W) - sum(log_var)] + 1/2 [sum(iK o H) + m.iKm - L M + sum ldK - sum ldH] - L N/2
- * W = sum_s Ks^T iB Ks, Qm = iK H iK, all [L][M][M]; m, iKm [L][M]; ldK, ldH [L]; lv fp32 [B][L].
+ *   c/2 [sum(part) - sum(N1 o W) - sum(log_var)] + 1/2 [sum(iK o H) + m.iKm - L M + sum ldK - sum ldH] - L N/2
+ * W = sum_s Ks^T iB Ks, N1 = iK - iK H iK (passed as Qm), all [L][M][M]; m, iKm [L][M]; ldK, ldH [L]; lv fp32 [B][L].
  * rep scales the second bracket and the constant: 1 in a single process; 1 / world under data parallelism, where every
  * rank passes its local part / W / lv and the bound of the global batch is the SUM of the ranks' results. */
 int hlvae_gp_bound(const double* part, int S, const double* W, const double* iK, const double* Qm, const double* H,

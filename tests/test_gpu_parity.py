@@ -7,7 +7,9 @@ Tolerances (bf16 MFMA inputs, fp32 accumulation, fp32 heads/ELBO; reference is f
   * ELBO / NLL totals:        1e-4 relative   (BASELINE.json north_star)
   * per-element log_p_x:      3e-2 absolute + 2e-2 relative (bf16 rounding of y, amplified by 1/var in the real head)
   * mu / log_var:             2e-2 absolute
-  * gradients, per tensor:    3e-2 relative L2 (bf16 activations and weights in both backward GEMMs)
+  * gradients, per tensor:    2.5e-2 relative L2 (bf16 activations and weights in both backward GEMMs: the first encoder
+                              Linear of the D4 model measures 2.2e-2 at 512 rows -- ReLU gates that flip under bf16 rounding --,
+                              every other tensor <= 1e-2)
 """
 import json
 import os
@@ -23,6 +25,7 @@ from hlvae_amd import synthetic       # noqa: E402
 from tests_common import MIX_SPEC, load_mix_case, max_abs_err, rel_err   # noqa: E402
 
 ELBO_RTOL = 1e-4
+GRAD_RTOL = 2.5e-2
 REPORT = {}
 
 
@@ -97,7 +100,7 @@ def test_forward_backward_against_reference_fixture(golden_dir, name):
     assert e_mu < 2e-2 and e_lv < 2e-2
     assert np.all(e_lpx <= 3e-2 + 2e-2 * np.abs(g["log_p_x"]))
     assert np.all(e_lpm <= 3e-2 + 2e-2 * np.abs(g["log_p_x_missing"]))
-    assert abs(elbo - elbo_ref) <= 10 * ELBO_RTOL * abs(elbo_ref)     # 24 rows only: few terms to average over
+    assert abs(elbo - elbo_ref) <= ELBO_RTOL * abs(elbo_ref)          # measured 3e-7 / 7e-6 on the two fixtures
     # p_params per type block, reference shapes
     for i, p in enumerate(p_params["x"]):
         ref = g[f"p_params_{i}"]
@@ -109,7 +112,7 @@ def test_forward_backward_against_reference_fixture(golden_dir, name):
     loss = float(g["nll_scale"][0]) * nll.sum() + kl
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(g["loss"][0])) <= 10 * ELBO_RTOL * abs(float(g["loss"][0]))
+    assert abs(float(loss) - float(g["loss"][0])) <= ELBO_RTOL * abs(float(g["loss"][0]))
     worst = 0.0
     sd = dict(model.named_parameters())
     for k in g.files:
@@ -121,7 +124,7 @@ def test_forward_backward_against_reference_fixture(golden_dir, name):
         e = rel_err(gr.double().cpu().numpy(), g[k])
         _report(name + "_grads", **{pname: e})
         worst = max(worst, e)
-        assert e < 3e-2, (pname, e)
+        assert e < GRAD_RTOL, (pname, e)
     assert worst > 0
 
 
@@ -196,7 +199,7 @@ def test_d4_batch512_against_oracle():
             continue
         e = rel_err(p.grad.double().cpu().numpy(), st[k].grad.numpy())
         _report("d4_b512_grads", **{k: e})
-        assert e < 3e-2, (k, e)
+        assert e < GRAD_RTOL, (k, e)
 
 
 def test_properties_at_full_size():
@@ -440,6 +443,7 @@ def test_ragged_batch_sizes_against_oracle(B):
         # finite; the undefined statistics still surface as NaN in log_p_x_missing of that column.  Documented difference.
         assert torch.isnan(out[4]).any()
         return
+    _report(f"ragged_{B}", loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), mu=max_abs_err(out[1], ref["mu"]))
     assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
     assert max_abs_err(out[1], ref["mu"]) < 3e-2
     # the device-side KL(q || N(0, I)) scalar (one partial per 16-row tile) against the same sum over the device mu / log_var
@@ -450,6 +454,7 @@ def test_ragged_batch_sizes_against_oracle(B):
     assert np.all(e <= 5e-2 + 3e-2 * np.abs(ref["log_p_x"].detach().numpy()))
     sd = dict(model.named_parameters())
     for k in ("y_layer.0.weight", "VAE_encoder_common_layers.0.weight", "d_layers.0.bias", "obs_layer.1.weight"):
+        _report(f"ragged_{B}_grads", **{k: rel_err(sd[k].grad, st[k].grad)})
         assert rel_err(sd[k].grad, st[k].grad) < 5e-2, k
 
 
@@ -478,7 +483,7 @@ def test_tabular_config4_batch4096_against_oracle():
             continue
         e = rel_err(p.grad, st[k].grad)
         _report("tabular_b4096_grads", **{k: e})
-        assert e < 3e-2, (k, e)
+        assert e < 1.5e-2, (k, e)                  # measured <= 5.6e-3
 
 
 def test_data_parallel_code_path_single_rank_rccl(golden_dir):
