@@ -63,7 +63,10 @@ def parse():
                     help="compact feed: run each batch's input stage at the top of its own step instead of beside the previous "
                          "step's backward pass")
     ap.add_argument("--no-graph-chain", dest="graph_chain", action="store_false",
-                    help="one HIP graph per step (default: the 4-batch ring is also captured as one graph of 4 steps)")
+                    help="one HIP graph per step (default: the 4-batch ring is also captured as one graph of --chain steps)")
+    ap.add_argument("--chain", type=int, default=8,
+                    help="steps per HIP-graph launch (a multiple of the 4-batch ring): between two graph launches the executor "
+                         "joins and re-forks its queues (~25 us on MI355X), inside a graph consecutive steps abut")
     ap.add_argument("--sharded", action="store_true",
                     help="N = 1: run the data-parallel optimiser path (flat sharded Adam -> bf16 copy -> shadows) instead of the "
                          "fused tile Adam, to price the code path the multi-GPU step uses")
@@ -283,8 +286,9 @@ def main():
             try:
                 for i in range(len(ring)):
                     trainer.capture_rows(i, dsd, R[i], PB[i], next_rows=nx[i] if feed_pf else None, groups=Gr[i])
-                if a.graph_chain:      # the whole ring (4 consecutive steps, one per batch) as ONE graph; a replay = 4 steps
-                    trainer.capture_rows("ring", dsd, R, PB, next_rows=nx if feed_pf else None, groups=Gr)
+                if a.graph_chain:      # the ring, `reps` times over, as ONE graph: a replay = a.chain consecutive steps
+                    reps = max(1, a.chain // len(ring))
+                    trainer.capture_rows("ring", dsd, R * reps, PB * reps, next_rows=(nx * reps) if feed_pf else None, groups=Gr * reps)
                 ok = 1
             except Exception as e:     # noqa: BLE001 -- a failed capture must not cost the whole measurement
                 ok, graph_note = 0, f"capture failed: {type(e).__name__}: {e}"
@@ -312,15 +316,16 @@ def main():
 
     it = [0]                                   # the batch chain continues across warm-up and the timed region
     chain = use_graph and compact and a.graph_chain
+    n_chain = len(ring) * max(1, a.chain // len(ring))
 
     def run(n):
         left = n
         while left > 0:
             i = it[0]
-            if chain and i % len(ring) == 0 and left >= len(ring):      # 4 steps per launch; the ragged ends one by one
+            if chain and i % len(ring) == 0 and left >= n_chain:        # n_chain steps per launch; the ragged ends one by one
                 trainer.replay("ring")
-                it[0] += len(ring)
-                left -= len(ring)
+                it[0] += n_chain
+                left -= n_chain
                 continue
             it[0] += 1
             left -= 1
@@ -395,7 +400,7 @@ def main():
             "config": {"workload": f"{cfg_name}: " + what + f"batch {a.batch} rows/GPU, "
                                    + ("compact dataset (5 B/entry) resident in HBM, batches = row-index vectors" if compact
                                       else "fp64 inputs resident in HBM"),
-                       "kl": a.kl, "hip_graph": use_graph, "steps_per_graph_launch": (len(ring) if chain else 1),
+                       "kl": a.kl, "hip_graph": use_graph, "steps_per_graph_launch": (n_chain if chain else 1),
                        "input_stage_prefetch": bool(pipelined or (compact and feed_pf)), "rows_per_step_per_gpu": a.batch,
                        "optimizer": "fused tile Adam" if dp is None else f"reduce-scatter + sharded Adam + bf16 all-gather (world {world})",
                        "final_nll_sum": nll_last, **({"graph_note": graph_note} if graph_note else {}), **({"tag": a.tag} if a.tag else {})},

@@ -43,9 +43,12 @@ class Observation_Count(nn.Module):                      # reference HLVAE.py:11
         self.bias = nn.Parameter(torch.empty(n, 1))
 
 
-class Observation_Real_Pos_Beta(nn.Module):              # reference HLVAE.py:25-51 (logvar_network=False)
-    def __init__(self, n, y_dim):
+class Observation_Real_Pos_Beta(nn.Module):              # reference HLVAE.py:25-51
+    def __init__(self, n, y_dim, logvar_network=False):
         super().__init__()
+        if logvar_network:                               # registered first, as in the reference (state_dict key order)
+            self.weight_logvar = nn.Parameter(torch.empty(n, y_dim, 1))
+            self.bias_logvar = nn.Parameter(torch.empty(n, 1))
         self.weight_mean = nn.Parameter(torch.empty(n, y_dim, 1))
         self.bias_mean = nn.Parameter(torch.empty(n, 1))
 
@@ -110,8 +113,9 @@ class HLVAE(nn.Module):
         if conv and (n_variables != 36 * 36 or y_dim != 5):
             raise ValueError("conv=True views the variables as one 36 x 36 image with y_dim = 5 output channels "
                              "(reference HLVAE.py:305, 257-258)")
-        if logvar_network:
-            raise NotImplementedError("logvar_network=True is outside the hot path (SURVEY.md section 8)")
+        if logvar_network and conv:
+            raise NotImplementedError("logvar_network=True with the convolutional decoder is not built (the shipped configuration "
+                                      "uses logvar_network=False, config/hlvae_config_file.txt)")
         if not (isinstance(h_dim_e, (list, tuple)) and len(h_dim_e) == 1 and isinstance(h_dim_d, (list, tuple))
                 and len(h_dim_d) == 1):
             raise NotImplementedError("exactly one hidden layer per side is implemented (reference config: [500])")
@@ -122,6 +126,8 @@ class HLVAE(nn.Module):
         self.types_info = types_info
         self.materialize_samples = materialize_samples
         self.plan: ColumnPlan = compile_plan(types_info, y_dim)
+        if self.plan.logvar_network != bool(logvar_network):
+            raise ValueError("types_info['param_indexes'] was built for logvar_network=%s" % self.plan.logvar_network)
         if self.plan.X != x_dim or self.plan.D != n_variables:
             raise ValueError(f"dims[0]={x_dim}/n_variables={n_variables} do not match types_info "
                              f"(X={self.plan.X}, D={self.plan.D})")
@@ -150,8 +156,11 @@ class HLVAE(nn.Module):
         self.VAE_encoder_common_layers = nn.Sequential(nn.Linear(x_enc, self.h_e), nn.ReLU())
         self.mean_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
         self.log_var_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
-        self._log_vy_real = nn.Parameter(torch.empty(pl.n_real))
-        self._log_vy_pos = nn.Parameter(torch.empty(pl.n_pos))
+        if logvar_network:                                                           # HLVAE.py:219-222: plain None attributes
+            self._log_vy_real = self._log_vy_pos = None
+        else:
+            self._log_vy_real = nn.Parameter(torch.empty(pl.n_real))
+            self._log_vy_pos = nn.Parameter(torch.empty(pl.n_pos))
         self._disp_param = nn.Parameter(torch.ones(1))
         self.d_layers = nn.ModuleList([nn.Linear(z_dim, self.h_d), nn.ReLU()])
         self.hidden = nn.Sequential(*self.d_layers)                                  # alias, HLVAE.py:242
@@ -168,7 +177,7 @@ class HLVAE(nn.Module):
             if b["type"] == "count":
                 self.obs_layer.append(Observation_Count(n, y_dim))
             elif b["type"] in ("real", "pos"):
-                self.obs_layer.append(Observation_Real_Pos_Beta(n, y_dim))
+                self.obs_layer.append(Observation_Real_Pos_Beta(n, y_dim, logvar_network))
             elif b["type"] == "cat":
                 self.obs_layer.append(Observation_Cat(n, y_dim, K))
             else:
@@ -177,7 +186,7 @@ class HLVAE(nn.Module):
             self.obs_layer.append(nn.Sigmoid())                                      # HLVAE.py:271-273 ('real' sorts last)
 
         # ---- flat arena: [atomically accumulated grads | dense weights] -------------------------
-        order: List[nn.Parameter] = [self._log_vy_real, self._log_vy_pos, self._disp_param]
+        order: List[nn.Parameter] = ([] if logvar_network else [self._log_vy_real, self._log_vy_pos]) + [self._disp_param]
         for m in self.obs_layer:
             order += list(m.parameters())
         if conv:      # small tensors whose gradients are accumulated with atomics by the convolution kernels
@@ -207,7 +216,7 @@ class HLVAE(nn.Module):
         with torch.no_grad():
             for p_, v_ in zip(conv_params, conv_init):
                 p_.copy_(v_)
-        if vy_fixed:
+        if vy_fixed and not logvar_network:
             self._log_vy_real.requires_grad_(False)
             self._log_vy_pos.requires_grad_(False)
         self._anchor = torch.zeros((), requires_grad=True)
@@ -239,8 +248,9 @@ class HLVAE(nn.Module):
                 if isinstance(m, Observation_Ordinal):
                     m.weight_thresholds.fill_(1.0)
             min_log_vy = torch.tensor([-8.0])
-            self._log_vy_real.fill_(float(torch.log(vy_init[0] - torch.exp(min_log_vy))))
-            self._log_vy_pos.fill_(float(torch.log(vy_init[1] - torch.exp(min_log_vy))))
+            if self._log_vy_real is not None:
+                self._log_vy_real.fill_(float(torch.log(vy_init[0] - torch.exp(min_log_vy))))
+                self._log_vy_pos.fill_(float(torch.log(vy_init[1] - torch.exp(min_log_vy))))
             self._disp_param.fill_(1.0)
 
     def _apply(self, fn, *a, **k):
@@ -298,6 +308,7 @@ class HLVAE(nn.Module):
         pl = self.plan
         d = _lib.HlvaeDims()
         d.D, d.X, d.y_dim, d.h_e, d.h_d, d.L = pl.D, pl.X, self.y_dim, self.h_e, self.h_d, self.z_dim
+        d.Theta = pl.Theta
         d.n_real, d.n_pos = pl.n_real, pl.n_pos
         d.conv = int(bool(self.conv))
         ao = self.arena_offset
@@ -315,7 +326,7 @@ class HLVAE(nn.Module):
         d.o_wy, d.o_by = ao(self.y_layer[0].weight), ao(self.y_layer[0].bias)
         d.arena_size, d.atomic_region = self._arena_size, self._atomic_region
         d.frozen_lo = d.frozen_hi = 0
-        if not self._log_vy_real.requires_grad and not self._log_vy_pos.requires_grad:      # vy_fixed (HLVAE.py:209-216)
+        if self._log_vy_real is not None and not self._log_vy_real.requires_grad and not self._log_vy_pos.requires_grad:      # vy_fixed (HLVAE.py:209-216)
             d.frozen_lo = ao(self._log_vy_real)                   # the two tensors are neighbours at the start of the arena
             d.frozen_hi = _ru(ao(self._log_vy_pos) + self._log_vy_pos.numel(), 4)
         _lib.load().hlvae_dims_fill(C.byref(d))
@@ -325,13 +336,15 @@ class HLVAE(nn.Module):
         pl = self.plan
         arr = (_lib.HlvaeVar * pl.D)()
         ao = self.arena_offset
-        o_real, o_pos = ao(self._log_vy_real), ao(self._log_vy_pos)
+        lvn = self.logvar_network
+        o_real, o_pos = (0, 0) if lvn else (ao(self._log_vy_real), ao(self._log_vy_pos))
         for d in range(pl.D):
             v = arr[d]
             kind, K, bi = int(pl.kind[d]), int(pl.ncls[d]), int(pl.bidx[d])
             m = self.obs_layer[int(pl.blk[d])]
             v.kind, v.ncls, v.xoff, v.sidx, v.e_off, v.pad = kind, K, int(pl.xoff[d]), -1, -1, 0
-            v.r_off = v.rb_off = -1
+            v.r_off = v.rb_off = v.w2_off = v.b2_off = -1
+            v.poff, v.poff2 = int(pl.poff[d]), int(pl.poff2[d])
             if self.conv and kind in (KIND_CAT, KIND_ORDINAL):
                 rep = self.representation_layer[self._rep_of_block[int(pl.blk[d])]]
                 v.r_off, v.rb_off = ao(rep.weight) + bi * K, ao(rep.bias) + bi
@@ -339,7 +352,10 @@ class HLVAE(nn.Module):
                 v.w_off, v.b_off = ao(m.weight_mean) + bi * self.y_dim, ao(m.bias_mean) + bi
                 si = int(pl.sidx[d])
                 v.sidx = si if kind == KIND_REAL else pl.n_real + si      # reals first, then pos
-                v.e_off = (o_real if kind == KIND_REAL else o_pos) + si
+                if lvn:
+                    v.w2_off, v.b2_off = ao(m.weight_logvar) + bi * self.y_dim, ao(m.bias_logvar) + bi
+                else:
+                    v.e_off = (o_real if kind == KIND_REAL else o_pos) + si
             elif kind == KIND_COUNT:
                 v.w_off, v.b_off = ao(m.weight) + bi * self.y_dim, ao(m.bias) + bi
             elif kind == KIND_CAT:
@@ -397,7 +413,7 @@ class HLVAE(nn.Module):
             zb=z(Bp, d.Lp), zbT=z(d.Lp, Bp), u=z(Bp, d.hdp), uT=z(d.hdp, Bp), dy=z(Bp, d.NYp), dyT=z(d.NY, Bp),
             log_p_x=z(Bp, d.D, dt=f32), log_p_x_missing=z(Bp, d.D, dt=f32), rowpart=z(NT, Bp, dt=f32), hgpart=z(Bp // 64, NT * 16, self._head_acc(), dt=f32),
             nll=z(Bp, dt=f32), scal=z(8, dt=torch.float64), klpart=z(max(Bp // 4, 1), dt=torch.float64),
-            eps=z(Bp, d.L, dt=f32), rng=z(2, dt=torch.int64), pfull=z(Bp, d.X, dt=f32), xhat=z(Bp, d.D, dt=f32),
+            eps=z(Bp, d.L, dt=f32), rng=z(2, dt=torch.int64), pfull=z(Bp, d.Theta, dt=f32), xhat=z(Bp, d.D, dt=f32),
             metpart=z(16, 6, d.D, dt=f32),
             du=z(Bp, d.hdp), duT=z(d.hdp, Bp), dz=z(Bp, d.Lp, dt=f32), dml=z(Bp, 2 * d.Lp), dmlT=z(2 * d.Lp, Bp),
             dt=z(Bp, d.hep), dtT=z(d.hep, Bp))
@@ -527,7 +543,12 @@ class HLVAE(nn.Module):
         out = []
         for b, cols in zip(self.plan.blocks, self._block_columns()):
             p = pf.index_select(1, cols)
-            out.append(p.reshape(B, b["n_vars"], b["nclass"]) if b["type"] in ("cat", "ordinal") else p)
+            if b["type"] in ("cat", "ordinal"):
+                out.append(p.reshape(B, b["n_vars"], b["nclass"]))
+            elif self.logvar_network and b["type"] in ("real", "pos"):
+                out.append([p[:, :b["n_vars"]], p[:, b["n_vars"]:]])        # [est_mean, est_var] (loglik.py:64-67, 112-115)
+            else:
+                out.append(p)
         return out
 
     def _norm_params(self):
@@ -546,7 +567,11 @@ class HLVAE(nn.Module):
         out = []
         for b, p in zip(pl.blocks, p_params):
             K = b["nclass"]
-            if b["type"] == "real":
+            if b["type"] == "real" and self.logvar_network:
+                out.append(p[0] + torch.sqrt(p[1]) * torch.randn_like(p[0]))
+            elif b["type"] == "pos" and self.logvar_network:
+                out.append(torch.clamp(torch.exp(p[0] + torch.sqrt(p[1]) * torch.randn_like(p[0])) - 1.0, 0, 1e20))
+            elif b["type"] == "real":
                 var_d = torch.clamp(nm[1, :pl.n_real], min=3e-4)
                 lvy = -8.0 + torch.nn.functional.softplus(self._log_vy_real.detach() + 8.0)
                 out.append(p + torch.sqrt(var_d * torch.exp(lvy)) * torch.randn_like(p))

@@ -9,8 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhlvae_hip.so")
-ABI_VERSION = 24
+LIB_PATH = os.environ.get("HLVAE_LIB_PATH", os.path.join(_HERE, "libhlvae_hip.so"))      # (override: diagnostic builds)
+ABI_VERSION = 25
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -18,11 +18,12 @@ _vp = C.c_void_p
 
 
 class HlvaeVar(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("kind", "ncls", "xoff", "sidx", "w_off", "b_off", "e_off", "r_off", "rb_off", "pad")]
+    _fields_ = [(n, C.c_int32) for n in ("kind", "ncls", "xoff", "sidx", "w_off", "b_off", "e_off", "r_off", "rb_off", "poff", "poff2", "w2_off",
+                                            "b2_off", "pad")]
 
 
 class HlvaeDims(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ("D", "X", "y_dim", "h_e", "h_d", "L", "n_real", "n_pos", "conv",
+    _fields_ = ([(n, C.c_int32) for n in ("D", "X", "y_dim", "h_e", "h_d", "L", "n_real", "n_pos", "conv", "Theta",
                                             "Xp", "hep", "hdp", "Lp", "NY", "NYp", "n_stat", "Xe", "Xep", "NYl", "NYlp")]
                 + [(n, C.c_int64) for n in ("o_w1", "o_b1", "o_wmu", "o_bmu", "o_wlv", "o_blv", "o_wd", "o_bd",
                                             "o_wy", "o_by", "o_c1w", "o_c1b", "o_c2w", "o_c2b", "o_t1w", "o_t1b", "o_t2w", "o_t2b",

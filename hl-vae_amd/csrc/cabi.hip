@@ -126,7 +126,7 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     HL_REQUIRE(out && dims && vars, HLVAE_EINVAL, "plan_create: null argument");
     hlvae_dims d = *dims;
     hlvae_dims_fill(&d);
-    HL_REQUIRE(d.D > 0 && d.X >= d.D && d.h_e > 0 && d.h_d > 0 && d.L > 0, HLVAE_EINVAL, "plan_create: bad dims");
+    HL_REQUIRE(d.D > 0 && d.X >= d.D && d.h_e > 0 && d.h_d > 0 && d.L > 0 && d.Theta >= d.X, HLVAE_EINVAL, "plan_create: bad dims");
     HL_REQUIRE(d.y_dim == 5 || d.y_dim == 3 || d.y_dim == 8, HLVAE_EINVAL, "plan_create: y_dim=%d (instantiated: 3, 5, 8)", d.y_dim);
     HL_REQUIRE(!d.conv || d.y_dim == 5, HLVAE_EINVAL, "plan_create: the convolutional decoder has y_dim = 5 output channels");
     HL_REQUIRE(d.Lp <= 64, HLVAE_EINVAL, "plan_create: latent_dim=%d > 64 unsupported", d.L);
@@ -158,10 +158,14 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
         HL_REQUIRE(!(disc && v.ncls > 8) || d.y_dim == 5, HLVAE_EINVAL, "variable %d: more than 8 classes is instantiated for "
                    "y_dim = 5 only", i);
         HL_REQUIRE(v.xoff == x, HLVAE_EINVAL, "variable %d: xoff %d, expected %d", i, v.xoff, x);
+        HL_REQUIRE(v.poff >= 0 && v.poff + v.ncls <= d.Theta, HLVAE_EINVAL, "variable %d: poff %d outside the %d parameter columns", i, v.poff, d.Theta);
         HL_REQUIRE(v.w_off >= 0 && v.b_off >= 0 && v.w_off < d.atomic_region && v.b_off < d.atomic_region,
                    HLVAE_EINVAL, "variable %d: head offsets outside the atomic gradient region", i);
         if (v.kind == HLVAE_REAL || v.kind == HLVAE_POS) {
-            HL_REQUIRE(v.sidx >= 0 && v.sidx < d.n_stat && v.e_off >= 0, HLVAE_EINVAL, "variable %d: sidx/e_off", i);
+            const bool lvn = v.w2_off >= 0;      // logvar_network: a second head (log-variance) instead of the free parameter
+            HL_REQUIRE(v.sidx >= 0 && v.sidx < d.n_stat && (lvn ? (v.b2_off >= 0 && v.w2_off < d.atomic_region && v.b2_off < d.atomic_region &&
+                                                                   v.poff2 >= 0 && v.poff2 < d.Theta && !d.conv)
+                                                                : v.e_off >= 0), HLVAE_EINVAL, "variable %d: sidx / variance parameter offsets", i);
             stat_var[v.sidx] = i;
             ++nstat_seen;
         }

@@ -38,7 +38,13 @@ struct HeadAcc {
 };
 
 // ---- real / pos:  HL_VAE/loglik.py:27-70 and :73-121 -------------------------------------------
-template <int YD, int BM, int CLD, int NACC>
+// LVN (logvar_network, HLVAE.py:25-51; a property of the whole model, so a compile-time variant chosen by a uniform branch):
+// the head has a second output, the log-variance parameter of every ENTRY (theta[:, n + j], loglik.py:45-47 / :105) instead of
+// the free per-variable parameter _log_vy_*; its weights sit behind the mean's in the staged parameter block (w[YD .. 2 YD),
+// b[1]); accumulators: mean weights / bias at 0 .. YD, log-variance weights / bias at YD + 1 .. 2 YD + 1.
+// (A single function selecting per lane between the two forms compiled into a kernel whose dY cells were occasionally wrong --
+// one 16-lane group's store of one column, differing from run to run; tests/test_gpu_configs.py::test_step_is_deterministic.)
+template <int YD, int BM, int CLD, int NACC, bool LVN>
 __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int rg, int m0, int B, int D, int d,
                                              const hlvae_var& var, const float* __restrict__ P,
                                              const float* __restrict__ norm, int n_stat, const float (&byv)[YD],
@@ -49,41 +55,56 @@ __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int 
                                              float (&acc)[NACC], float (&lpo)[BM / 16], bool conv_real) {
     // conv_real: real variable under the convolutional decoder -- sigmoid on the mean (HLVAE.py:271-273, 428-430), data
     // scaled by 1/255 (HLVAE.py:393-394), no batch statistics (norm holds mean 0 / var 1; loglik.py:40-41)
-    float w[YD];
+    float w[YD], w2[LVN ? YD : 1];
 #pragma unroll
     for (int k = 0; k < YD; ++k) w[k] = P[var.w_off + k];
+    if (LVN) {
+#pragma unroll
+        for (int k = 0; k < YD; ++k) w2[k] = P[var.w_off + YD + k];
+    }
     const float b = P[var.b_off];
-    const float p = P[var.e_off];
+    const float b2 = LVN ? P[var.b_off + 1] : 0.f;
     const float mean_d = norm[var.sidx];
     float vd = norm[n_stat + var.sidx];
     const float xscale = conv_real ? 1.f / 255.f : 1.f;
-    float ev, dp_fac;
-    if (!is_pos) {
-        vd = fmaxf(vd, 3e-4f);                                   // loglik.py:38
-        const float lvy = -8.f + softplus_f(p + 8.f);            // :51
-        ev = vd * __expf(lvy);                                   // :52,56
-        dp_fac = sigmoid_f(p + 8.f);
-    } else {
-        vd = fmaxf(vd, 1e-3f);                                   // :80
-        ev = vd * __expf(p);                                     // :100
-        dp_fac = 1.f;
+    vd = fmaxf(vd, is_pos ? 1e-3f : 3e-4f);                          // loglik.py:38 / :80
+    float ev = 1.f, dp_fac = 1.f, pos_var = 0.f;
+    if (!LVN) {                                                      // variance from the free per-variable parameter
+        const float p = P[var.e_off];
+        if (!is_pos) {
+            ev = vd * __expf(-8.f + softplus_f(p + 8.f));            // :51-52, :56
+            dp_fac = sigmoid_f(p + 8.f);
+        } else {
+            ev = vd * __expf(p);                                     // :100
+            pos_var = __expf(p);                                     // read_functions.py:285
+        }
     }
     const float sd = sqrtf(vd);
-    const float inv_ev = 1.f / ev;
-    const float c0 = -0.5f * HL_LOG2PI - 0.5f * __logf(ev);
-    const float pos_var = is_pos ? __expf(p) : 0.f;              // read_functions.py:285
+    float inv_ev = 1.f / ev;
+    float c0 = -0.5f * HL_LOG2PI - 0.5f * __logf(ev);
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) {
         const int r = HL_ROW(rg, i), gr = m0 + r;
         float* yrow = Cs + r * CLD + v * YD;
-        float th = b;
+        float th = b, tl = b2;
         float y[YD];
 #pragma unroll
         for (int k = 0; k < YD; ++k) {
             y[k] = yrow[k] + byv[k];
             th += w[k] * y[k];
+            if (LVN) tl += w2[k] * y[k];
         }
-        float lp_obs = 0.f, dth = 0.f;
+        if (LVN) {                                                   // variance of THIS entry from the head's second output
+            if (!is_pos) {
+                ev = vd * __expf(-8.f + softplus_f(tl + 8.f));       // :45-47, :56
+                dp_fac = sigmoid_f(tl + 8.f);
+            } else {
+                ev = vd * __expf(tl);                                // :105
+            }
+            inv_ev = 1.f / ev;
+            c0 = -0.5f * HL_LOG2PI - 0.5f * __logf(ev);
+        }
+        float lp_obs = 0.f, dth = 0.f, dtl = 0.f;
         if (gr < B) {
             const size_t o = (size_t)gr * D + d;
             const float x = xt[i * HL_THREADS] * xscale;         // raw x (real) or log1p x (pos): this thread's slot of the prefetched tile
@@ -103,17 +124,27 @@ __device__ __forceinline__ void proc_realpos(bool is_pos, float* Cs, int v, int 
                 const float g = g_elem != nullptr ? g_elem[o] : g_scale;
                 lp_obs = lp;
                 dth = g * rr * inv_ev * sd * dsig;
-                acc[YD + 1] += g * (0.5f * rr * rr * inv_ev - 0.5f) * dp_fac;
+                dtl = g * (0.5f * rr * rr * inv_ev - 0.5f) * dp_fac;
             }
-            if (pfull != nullptr) pfull[(size_t)gr * X + var.xoff] = mean;      // loglik.py:64-67 (mean only)
-            if (xhat != nullptr) xhat[o] = is_pos ? __expf(mean + 0.5f * pos_var) - 1.f : mean;   // read_functions.py:277,288
+            if (pfull != nullptr) {
+                pfull[(size_t)gr * X + var.poff] = mean;         // loglik.py:64-67 (mean only unless logvar_network: [mean, var])
+                if (LVN) pfull[(size_t)gr * X + var.poff2] = ev;
+            }
+            // read_functions.py:277, 283-290: under logvar_network the variance in the pos mean is est_var itself
+            if (xhat != nullptr) xhat[o] = is_pos ? __expf(mean + 0.5f * (LVN ? ev : pos_var)) - 1.f : mean;
         }
         lpo[i] = lp_obs;
         acc[YD] += dth;
+        acc[LVN ? 2 * YD + 1 : YD + 1] += dtl;
 #pragma unroll
         for (int k = 0; k < YD; ++k) {
             acc[k] += dth * y[k];
-            yrow[k] = dth * w[k];
+            if (LVN) {
+                acc[YD + 1 + k] += dtl * y[k];
+                yrow[k] = dth * w[k] + dtl * w2[k];
+            } else {
+                yrow[k] = dth * w[k];
+            }
         }
     }
 }
@@ -156,7 +187,7 @@ __device__ __forceinline__ void proc_count(float* Cs, int v, int rg, int m0, int
                 lp_obs = lp;
                 if (sp >= 1e-6f && sp <= 1e20f) dth = g * (x / lam - 1.f) * sigmoid_f(th);
             }
-            if (pfull != nullptr) pfull[(size_t)gr * X + var.xoff] = lam;
+            if (pfull != nullptr) pfull[(size_t)gr * X + var.poff] = lam;
             if (xhat != nullptr) xhat[o] = lam;                  // read_functions.py:294
         }
         lpo[i] = lp_obs;
@@ -235,7 +266,7 @@ __device__ __forceinline__ void proc_cat(float* Cs, int v, int rg, int m0, int B
                 lp_obs = lp;
             }
             if (pfull != nullptr) {
-                float* pf = pfull + (size_t)gr * X + var.xoff;
+                float* pf = pfull + (size_t)gr * X + var.poff;
                 pf[0] = -lse;                                    // params = normalised log_pi (:139)
 #pragma unroll
                 for (int j = 0; j < KM - 1; ++j)
@@ -364,7 +395,7 @@ __device__ __forceinline__ void proc_ord(float* Cs, int v, int rg, int m0, int B
                 dreg = dmv * sigmoid_f(reg);
             }
             if (pfull != nullptr) {
-                float* pf = pfull + (size_t)gr * X + var.xoff;
+                float* pf = pfull + (size_t)gr * X + var.poff;
 #pragma unroll
                 for (int c = 0; c < KM; ++c)
                     if (c < K) pf[c] = pc[c] * invS;             // params = normalised mean_probs (:183)
@@ -402,6 +433,8 @@ __device__ __forceinline__ int acc_dest(const hlvae_var& var, int n) {
     switch (var.kind) {
         case HLVAE_REAL:
         case HLVAE_POS:
+            if (var.w2_off >= 0)      // logvar_network: [mean weights, mean bias, log-variance weights, log-variance bias]
+                return n < YD ? var.w_off + n : (n == YD ? var.b_off : (n <= 2 * YD ? var.w2_off + (n - YD - 1) : (n == 2 * YD + 1 ? var.b2_off : -1)));
             return n < YD ? var.w_off + n : (n == YD ? var.b_off : (n == YD + 1 ? var.e_off : -1));
         case HLVAE_COUNT:
             return n < YD ? var.w_off + n : (n == YD ? var.b_off : -1);
@@ -429,7 +462,8 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     const float* __restrict__ xt, const uint8_t* __restrict__ m8, int D, const float* __restrict__ g_elem, float g_scale,
     bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dyT, int Bp, float* __restrict__ logpx,
     float* __restrict__ logpx_miss, float* __restrict__ rowpart, float* __restrict__ pfull, int X,
-    float* __restrict__ xhat, int B, int want_grad, const float* __restrict__ ysrc, int ldys, long long* __restrict__ clk) {
+    float* __restrict__ xhat, int B, int want_grad, const float* __restrict__ ysrc, int ldys, long long* __restrict__ clk,
+    int logvar) {
 #define HL_CLK(i) do { if (clk != nullptr && (threadIdx.x & 63) == 0) clk[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12 + (i)] = clock64(); } while (0)
     HL_CLK(0);
     // ysrc != nullptr: convolutional decoder -- the tile of y_grouped comes from the second ConvTranspose (csrc/conv.hip,
@@ -444,6 +478,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     // scratch behind the GEMM buffers, used strictly BEFORE the gradient reduction image that overlays them:
     //   [head parameters, statistics and y_layer bias of the 16 variables | likelihood targets | masks] of the tile
     constexpr int PW = YD * (KMAX - 1), PB = KMAX - 1, PS = PW + 2 * PB + 2 + YD;      // [w | b | e | mean, var | by]
+    static_assert(PW >= 2 * YD && PB >= 2 && HeadAcc<YD, KMAX>::N >= 2 * YD + 2, "room for the log-variance head of real / pos variables");
     constexpr int SCR_BYTES = 16 * PS * 4 + RPT * HL_THREADS * 5;
     // after the epilogue: [C tile with dY | acc[n][thread] image]
     constexpr int POST_BYTES = BM * CLD * 4 + NACC * RST * 4;
@@ -490,13 +525,15 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
         if (tid < 16 && d < D) {
             const int K1 = var.ncls - 1;
             const bool cont = var.kind == HLVAE_REAL || var.kind == HLVAE_POS;
+            const bool lvn = cont && var.w2_off >= 0;
             const int nw = var.kind == HLVAE_CAT ? YD * K1 : YD, nb = var.kind == HLVAE_CAT ? K1 : 1;
-            const int ne = cont ? 1 : (var.kind == HLVAE_ORDINAL ? K1 : 0);
+            const int ne = cont ? (lvn ? 0 : 1) : (var.kind == HLVAE_ORDINAL ? K1 : 0);
 #pragma unroll
-            for (int i = 0; i < PW; ++i) pre[i] = i < nw ? P[var.w_off + i] : 0.f;
+            for (int i = 0; i < PW; ++i)       // logvar_network: the log-variance weights ride behind the mean's (PW >= 2 YD)
+                pre[i] = i < nw ? P[var.w_off + i] : ((lvn && i < 2 * YD) ? P[var.w2_off + (i - YD)] : 0.f);
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
-                pre[PW + i] = i < nb ? P[var.b_off + i] : 0.f;
+                pre[PW + i] = i < nb ? P[var.b_off + i] : ((lvn && i == 1) ? P[var.b2_off] : 0.f);
                 pre[PW + PB + i] = i < ne ? P[var.e_off + i] : 0.f;
             }
             pre[PW + 2 * PB] = cont ? norm[var.sidx] : 0.f;
@@ -551,13 +588,16 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
         float (&hacc)[NHEAD] = *reinterpret_cast<float (*)[NHEAD]>(&acc[0]);
         switch (var.kind) {
             case HLVAE_REAL:
-                proc_realpos<YD, BM, CLD, NHEAD>(false, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
-                                                 g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, conv);
+            case HLVAE_POS: {
+                const bool is_pos = var.kind == HLVAE_POS;
+                if (logvar)      // (uniform: a kernel argument)
+                    proc_realpos<YD, BM, CLD, NHEAD, true>(is_pos, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
+                                                           g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, false);
+                else
+                    proc_realpos<YD, BM, CLD, NHEAD, false>(is_pos, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
+                                                            g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, conv && !is_pos);
                 break;
-            case HLVAE_POS:
-                proc_realpos<YD, BM, CLD, NHEAD>(true, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
-                                                 g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, false);
-                break;
+            }
             case HLVAE_COUNT:
                 proc_count<YD, BM, CLD, NHEAD>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
                                                logpx_miss, pfull, X, xhat, hacc, lpo);
@@ -931,7 +971,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
         k_y_heads<YDv, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->hgpart, d.o_by,  \
                                                           ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, \
                                                           d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing,       \
-                                                          ws->rowpart, pf, d.X, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY, clk)
+                                                          ws->rowpart, pf, d.Theta, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY, clk, d.Theta != d.X)
         if (d.y_dim == 3) HL_LAUNCH_HEADS_Y(3, 64, 8);          // other y_dim (config/hlvae_config_file.txt: y_dim): all class counts up to 8
         else if (d.y_dim == 8) HL_LAUNCH_HEADS_Y(8, 64, 8);
         else if (p->kmax <= 3) HL_LAUNCH_HEADS(3);

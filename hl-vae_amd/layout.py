@@ -59,8 +59,6 @@ def build_types_info(types_dict: Sequence[Dict[str, str]], miss_mask: np.ndarray
     Returns the reference's ``types_info`` dict.  ``miss_mask`` ([N, D], 1 = observed)
     is only needed for ``param_miss_mask``.
     """
-    if logvar_network:
-        raise NotImplementedError("logvar_network=True is outside the MLP hot path (SURVEY.md section 8)")
     types_dict = [dict(t) for t in types_dict]
     D = len(types_dict)
     type_tuple = [(t["type"], str(t["nclass"])) for t in types_dict]
@@ -71,16 +69,19 @@ def build_types_info(types_dict: Sequence[Dict[str, str]], miss_mask: np.ndarray
         k = int(t["nclass"])
         sizes.append(k if t["type"] in ("cat", "ordinal") else 1)
     X = int(np.sum(sizes))
+    # parameter slots per variable (read_functions.py:162-171): real / pos carry (mean, log-variance) under logvar_network
+    psizes = [2 if (logvar_network and t["type"] in ("real", "pos")) else sz for t, sz in zip(types_dict, sizes)]
     types_indexes = np.zeros(D)
     exp_types_indexes = np.zeros(X)
-    param_indexes = np.zeros(X)
-    pos = 0
+    param_indexes = np.zeros(int(np.sum(psizes)))
+    pos = ppos = 0
     for i, t in enumerate(types_dict):
         tid = set_of_types.index((t["type"], str(t["nclass"])))
         types_indexes[i] = tid
         exp_types_indexes[pos:pos + sizes[i]] = tid
-        param_indexes[pos:pos + sizes[i]] = tid
+        param_indexes[ppos:ppos + psizes[i]] = tid
         pos += sizes[i]
+        ppos += psizes[i]
     info = {
         "types_dict": types_dict,
         "set_of_types": set_of_types,
@@ -93,7 +94,14 @@ def build_types_info(types_dict: Sequence[Dict[str, str]], miss_mask: np.ndarray
         "conv_range": False,
     }
     if miss_mask is not None:
-        info["param_miss_mask"] = expand_mask(np.asarray(miss_mask, dtype=np.float64), sizes)
+        mm = np.asarray(miss_mask, dtype=np.float64)
+        pm = expand_mask(mm, psizes)
+        if logvar_network:      # read_functions.py:179-183: a real / pos block's slots are [all means | all log-variances]
+            for i, tpl in enumerate(set_of_types):
+                if tpl[0] in ("real", "pos"):
+                    blk = mm[:, types_indexes == i]
+                    pm[:, param_indexes == i] = np.concatenate([blk, blk], 1)
+        info["param_miss_mask"] = pm
     return info
 
 
@@ -120,6 +128,8 @@ class ColumnPlan:
     sidx: np.ndarray
     n_real: int
     n_pos: int
+    poff2: np.ndarray = None        # column of the log-variance slot of a real / pos variable under logvar_network, else -1
+    logvar_network: bool = False
     blocks: List[dict] = field(default_factory=list)   # per type-block summary
 
 
@@ -146,6 +156,15 @@ def compile_plan(types_info: dict, y_dim: int) -> ColumnPlan:
     counters = [0] * len(sot)
     x = 0
     n_real = n_pos = 0
+    n_cont = sum(1 for t in td if t["type"] in ("real", "pos"))
+    if len(pti) not in (len(eti), len(eti) + n_cont):
+        raise ValueError("types_info['param_indexes'] has %d slots: expected %d, or %d with logvar_network" % (len(pti), len(eti), len(eti) + n_cont))
+    logvar = len(pti) != len(eti)
+    # columns of every block inside the parameter matrix [B, Theta], in order (theta of a block is scattered into them in order:
+    # HLVAE.py:448; a real / pos block under logvar_network is [means | log-variances], HLVAE.py:50)
+    pcols = [np.nonzero(pti == b)[0] for b in range(len(sot))]
+    n_in_block = [int(np.sum(dti == b)) for b in range(len(sot))]
+    poff2 = -np.ones(D, np.int32)
     for d, t in enumerate(td):
         ty = t["type"]
         if ty not in KIND_OF:
@@ -157,11 +176,19 @@ def compile_plan(types_info: dict, y_dim: int) -> ColumnPlan:
         b = sot.index((ty, str(t["nclass"])))
         if dti[d] != b:
             raise ValueError("types_info['data_types_indexes'] inconsistent with set_of_types")
-        kind[d], ncls[d], xoff[d], poff[d], blk[d] = KIND_OF[ty], K, x, x, b
-        if not (np.all(eti[x:x + K] == b) and np.all(pti[x:x + K] == b)):
+        kind[d], ncls[d], xoff[d], blk[d] = KIND_OF[ty], K, x, b
+        if not np.all(eti[x:x + K] == b):
             raise ValueError("types_info index vectors inconsistent at variable %d" % d)
         bidx[d] = counters[b]
         counters[b] += 1
+        if ty in ("cat", "ordinal"):
+            poff[d] = pcols[b][bidx[d] * K]
+            if not np.all(pcols[b][bidx[d] * K:(bidx[d] + 1) * K] == poff[d] + np.arange(K)):
+                raise ValueError("types_info['param_indexes'] inconsistent at variable %d" % d)
+        else:
+            poff[d] = pcols[b][bidx[d]]
+            if logvar and ty in ("real", "pos"):
+                poff2[d] = pcols[b][n_in_block[b] + bidx[d]]
         if ty == "real":
             sidx[d] = n_real
             n_real += 1
@@ -169,12 +196,12 @@ def compile_plan(types_info: dict, y_dim: int) -> ColumnPlan:
             sidx[d] = n_pos
             n_pos += 1
         x += K
-    if x != len(eti) or x != len(pti):
-        raise ValueError("expanded width mismatch: %d vs %d/%d" % (x, len(eti), len(pti)))
+    if x != len(eti):
+        raise ValueError("expanded width mismatch: %d vs %d" % (x, len(eti)))
     blocks = []
     for b, (ty, k) in enumerate(sot):
         sel = np.nonzero(blk == b)[0]
         blocks.append({"type": ty, "nclass": int(k), "n_vars": int(len(sel)), "vars": sel})
-    return ColumnPlan(D=D, X=x, Theta=x, y_dim=y_dim, set_of_types=sot, kind=kind, ncls=ncls,
+    return ColumnPlan(D=D, X=x, Theta=len(pti), y_dim=y_dim, set_of_types=sot, kind=kind, ncls=ncls,
                       xoff=xoff, poff=poff, blk=blk, bidx=bidx, sidx=sidx,
-                      n_real=n_real, n_pos=n_pos, blocks=blocks)
+                      n_real=n_real, n_pos=n_pos, blocks=blocks, poff2=poff2, logvar_network=logvar)

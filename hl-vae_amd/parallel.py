@@ -168,10 +168,11 @@ class ShardedState:
         pb[k] [world * chunk_k] bf16         <-  all_gather(slice k)
     """
 
-    def __init__(self, dp: DataParallel, plan: ShardPlan, device, grad_dtype=torch.float32, copy_dtype=torch.bfloat16):
+    def __init__(self, dp: DataParallel, plan: ShardPlan, device, grad_dtype=torch.float32, copy_dtype=torch.bfloat16, slack=0):
+        """slack: extra zero elements behind every gathered copy (a consumer that reads a padded matrix straight out of the copy)"""
         self.dp, self.plan = dp, plan
         self.gsh = [torch.zeros(max(s.chunk, 1), dtype=grad_dtype, device=device) for s in plan.slices]
-        self.pb = [torch.zeros(max(plan.world * s.chunk, 1), dtype=copy_dtype, device=device) for s in plan.slices]
+        self.pb = [torch.zeros(max(plan.world * s.chunk, 1) + slack, dtype=copy_dtype, device=device) for s in plan.slices]
 
     def reduce_scatter_slice(self, k: int, G: torch.Tensor, async_op: bool = False):
         s = self.plan.slices[k]

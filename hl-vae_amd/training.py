@@ -68,9 +68,29 @@ class ShardedAdam:
         self.plan = ShardPlan(ranges, dp.world, dp.rank)
         if self.plan.pad > GRAD_SLACK:
             raise ValueError(f"world size {dp.world}: slice padding {self.plan.pad} exceeds the gradient arena's slack")
-        self.state = ShardedState(dp, self.plan, dev)
+        # The gathered bf16 copy of the first encoder Linear [h_e][X] IS its row-major shadow when X needs no column padding
+        # (D4: 5184 = 81 x 64): the MFMA kernels then read it where the all-gather puts it, and only the small matrices of that
+        # slice are rebuilt.  The padding rows h_e .. hep-1 fall into the (zero) slack behind the copy.
+        self._w1_alias = (not model.conv) and int(d.Xe) == int(d.Xep)
+        slack = (int(d.hep) - int(d.h_e)) * int(d.Xep) + 64 if self._w1_alias else 0
+        self.state = ShardedState(dp, self.plan, dev, slack=slack)
+        if self._w1_alias:
+            self.plan.slices[-1].which &= ~0x02
+            self._alias_w1(first=True)
         model._master_sync = self.sync_masters
         self._masters_stale = False
+        self._pending = None            # (work handle of y_layer's all-gather, slice index) left running by the last step
+
+    def _alias_w1(self, first=False):
+        """point the workspace's first-Linear shadow at its place inside the gathered copy (again after a workspace re-allocation)"""
+        m, d, k = self.model, self.model._dims, len(self.plan.slices) - 1
+        off = int(d.o_w1) - self.plan.slices[k].lo
+        alias = self.state.pb[k][off:off + int(d.hep) * int(d.Xep)]
+        if m._ws.w1s == alias.data_ptr() and m._ws_alt.w1s == alias.data_ptr():
+            return
+        alias.copy_(m._ws_t["w1s"].reshape(-1))                           # current shadow (incl. its zero padding rows)
+        m._ws.w1s = m._ws_alt.w1s = alias.data_ptr()
+        m._ws_t["w1s"] = alias.view(int(d.hep), int(d.Xep))
 
     def _args(self):
         return (C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), C.c_float(1.0))
@@ -102,13 +122,26 @@ class ShardedAdam:
 
     def rebuild_shadows(self, k: int):
         m, s = self.model, self.plan.slices[k]
-        _lib.check(_lib.load().hlvae_shadows_from_bf16(m._plan_handle, C.byref(m._ws), _lib.ptr(self.state.pb[k]), s.lo, s.which,
-                                                       m._stream()), "hlvae_shadows_from_bf16")
+        if self._w1_alias and k == len(self.plan.slices) - 1:
+            self._alias_w1()
+        if s.which:
+            _lib.check(_lib.load().hlvae_shadows_from_bf16(m._plan_handle, C.byref(m._ws), _lib.ptr(self.state.pb[k]), s.lo, s.which,
+                                                           m._stream()), "hlvae_shadows_from_bf16")
         self._masters_stale = self.plan.world > 1
         m.mark_shadows_fresh()
 
+    def finish_pending(self):
+        """y_layer's all-gather + shadow rebuild that the last step left running (they overlap the next step's first GEMM and
+        fused middle: its shadows are first read by the head kernel): the current stream waits for them"""
+        if self._pending is not None:
+            h, k = self._pending
+            self._pending = None
+            h.wait()
+            self.rebuild_shadows(k)
+
     def sync_masters(self):
         """collective: brings the fp32 masters of the other ranks' slices up to date (state_dict, checkpoints)"""
+        self.finish_pending()
         if self._masters_stale:
             self.state.sync_masters(self.model._arena)
             self._masters_stale = False
@@ -132,7 +165,7 @@ class ELBOTrainer:
         model._max_batch = max(model._max_batch, max_batch)
         model._ensure_device_state(max_batch)
         frozen = [p for p in model._order if not p.requires_grad and p is not model._log_vy_real and p is not model._log_vy_pos]
-        if frozen or (model._log_vy_real.requires_grad != model._log_vy_pos.requires_grad):
+        if frozen or (model._log_vy_real is not None and model._log_vy_real.requires_grad != model._log_vy_pos.requires_grad):
             raise ValueError("the fused optimiser step freezes _log_vy_real / _log_vy_pos together (vy_fixed) and trains every other "
                              "parameter, as the reference does (HLVAE.py:209-216)")
         self.opt = FusedAdam(model, lr=lr) if dp is None else ShardedAdam(model, dp, lr=lr)
@@ -242,6 +275,8 @@ class ELBOTrainer:
             m._swap_input_buffers()
         if not m._grad_region_clean:     # normally the fused Adam leaves the atomically-accumulated region zeroed
             _lib.check(lib.hlvae_zero_grad(m._plan_handle, ws, s), "zero_grad")
+        if self.dp is not None:
+            self.opt.finish_pending()    # y_layer's shadows of the previous optimiser step (left gathering beside the code above)
         _lib.check(lib.hlvae_decoder_fwd(m._plan_handle, ws, None, C.c_float(-scale), 2, 2 if self.metrics else 0, 0, B, s), "decoder_fwd")     # want_grad = 2: ELBO scalars deferred to the backward's side stream
         if self.metrics:     # row M: imputed values + per-variable errors (training.py:84-101), device resident
             _lib.check(lib.hlvae_step_metrics(m._plan_handle, ws, B, _lib.ptr(self.err), s), "step_metrics")
@@ -296,16 +331,22 @@ class ELBOTrainer:
                 _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 1, B, s), "backward")
                 pend.append(o.reduce_scatter(1, async_op=True))
             small = self.dp.allreduce_async(G[:int(d.atomic_region)])
-            gath = []
-            for k, h in enumerate(pend):        # slice k: wait for its sums, update, start the all-gather of the bf16 copy
+            for k, h in enumerate(pend):        # slice k: wait for its sums, Adam on the owned part
                 h.wait()
                 o.step_slice(k)
-                gath.append(o.gather(k, async_op=True))
             small.wait()
             o.step_small()
-            for k, h in enumerate(gath):
-                h.wait()
-                o.rebuild_shadows(k)
+            # all-gathers of the bf16 copies, LAST slice first: it holds the first encoder Linear, which the next step reads at
+            # once; y_layer's (slice 0, MLP) is first read by the head kernel, so its gather and shadow rebuild are left running
+            # and the next step waits for them right before that kernel
+            order = list(range(len(pend)))[::-1]
+            gath = [(k, o.gather(k, async_op=True)) for k in order]
+            for k, h in gath:
+                if k == 0 and len(pend) > 1:
+                    o._pending = (h, k)
+                else:
+                    h.wait()
+                    o.rebuild_shadows(k)
         m._fwd_token += 1
         m._grad_region_clean = True
         if self.kl == "gp":
@@ -344,6 +385,8 @@ class ELBOTrainer:
             torch.cuda.synchronize()
         with torch.cuda.graph(g):
             self.step(data, mask, P_batch, train_x=train_x, prefetch=prefetch, prepacked=(prefetch is not None) or None)
+            if self.dp is not None:
+                self.opt.finish_pending()
         self._graphs[key] = g
         return g
 
@@ -378,6 +421,8 @@ class ELBOTrainer:
         with torch.cuda.graph(g):
             for (r, pb), nr, gr in zip(chain, nxt, grp):
                 self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None, groups=gr)
+            if self.dp is not None:
+                self.opt.finish_pending()          # nothing may stay in flight across the end of a graph
         self._graphs[key] = g
         return g
 

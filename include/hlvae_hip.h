@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 24
+#define HLVAE_ABI_VERSION 25
 #define HLVAE_STAT_CHUNKS 16
 /* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
 #define HLVAE_HEAD_ACC 95
@@ -48,6 +48,10 @@ typedef struct {
     int32_t e_off;   /* arena offset of _log_vy_{real,pos}[i] or ordinal thresholds[K-1], -1 if none */
     int32_t r_off;   /* conv only: arena offset of representation_layer weight[d][K] (HLVAE.py:94), -1 otherwise */
     int32_t rb_off;  /* conv only: arena offset of representation_layer bias[d], -1 otherwise                     */
+    int32_t poff;    /* first column in the likelihood-parameter matrix [B, Theta] (= xoff unless logvar_network) */
+    int32_t poff2;   /* logvar_network, real / pos: column of the variance parameter, -1 otherwise                  */
+    int32_t w2_off;  /* logvar_network, real / pos: arena offset of weight_logvar [y_dim] (HLVAE.py:31-37), -1 otherwise */
+    int32_t b2_off;  /* logvar_network, real / pos: arena offset of bias_logvar, -1 otherwise                      */
     int32_t pad;
 } hlvae_var;
 
@@ -56,6 +60,7 @@ typedef struct {
     int32_t D, X, y_dim, h_e, h_d, L;          /* reference dims = [X, [h_e], L, [h_d], y_dim], D = n_variables */
     int32_t n_real, n_pos;
     int32_t conv;                              /* 1 = convolutional front / back end (HLVAE.py:139-152, 253-259): D must be 36 * 36 */
+    int32_t Theta;                             /* columns of the likelihood-parameter matrix: X, or X + n_real + n_pos under logvar_network */
     /* derived */
     int32_t Xp, hep, hdp, Lp, NY, NYp, n_stat;
     int32_t Xe, Xep;                           /* width of the first encoder Linear's input: X, or 32*9*9 under conv            */
@@ -122,7 +127,7 @@ typedef struct {
     double* klpart;      /* [Bp/4] KL partial sums, one per 4 rows (k_mid_fwd_fused)            */
     float* eps;          /* [Bp][L] reparameterisation noise actually used (kept for backward) */
     uint64_t* rng;       /* [2]: Philox seed, offset (advanced by one per step on device)    */
-    float* pfull;        /* [Bp][X]  likelihood parameters concatenated by key (row M), optional */
+    float* pfull;        /* [Bp][Theta]  likelihood parameters concatenated by key (row M), optional */
     float* xhat;         /* [Bp][D]  per-variable imputed value (statistics mean), optional */
     float* metpart;      /* [16][6][D] partials of the row-M metrics kernel                  */
     /* backward activations */

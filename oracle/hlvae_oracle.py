@@ -45,7 +45,8 @@ def block_indices(types_info):
 CONV_FEATURES = 32 * 9 * 9                                               # HLVAE.py:155
 
 
-def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.05, dtype=DT, conv=False) -> Dict[str, torch.Tensor]:
+def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.05, dtype=DT, conv=False,
+               logvar_network=False) -> Dict[str, torch.Tensor]:
     """Deterministic parameter set with the reference's shapes, key names and init
     distributions (row P: HLVAE.py:109-281 -- N(0, 0.05^2) everywhere, thresholds = 1,
     _log_vy = log(vy_init - e^-8), _disp_param = 1).  Uses its own generator, so the same
@@ -61,8 +62,9 @@ def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.
     real_dim = sum(1 for t in types_info["types_dict"] if t["type"] == "real")
     pos_dim = sum(1 for t in types_info["types_dict"] if t["type"] == "pos")
     min_log_vy = torch.tensor([-8.0])                                    # float32 as in HLVAE.py:206-209
-    st["_log_vy_real"] = torch.log(vy_init[0] - torch.exp(min_log_vy)).to(dtype).repeat(real_dim)
-    st["_log_vy_pos"] = torch.log(vy_init[1] - torch.exp(min_log_vy)).to(dtype).repeat(pos_dim)
+    if not logvar_network:                                               # HLVAE.py:204-222 (None, i.e. no state_dict key, otherwise)
+        st["_log_vy_real"] = torch.log(vy_init[0] - torch.exp(min_log_vy)).to(dtype).repeat(real_dim)
+        st["_log_vy_pos"] = torch.log(vy_init[1] - torch.exp(min_log_vy)).to(dtype).repeat(pos_dim)
     st["_disp_param"] = torch.ones(1, dtype=dtype)
     n_in = x_dim
     if conv:                                                             # HLVAE.py:139-155 (conv layers: torch default init
@@ -103,6 +105,8 @@ def init_state(dims, types_info, n_variables, vy_init=(1.0, 0.5), seed=0, std=0.
         if tpl[0] == "count":
             st[f"obs_layer.{i}.weight"], st[f"obs_layer.{i}.bias"] = nrm(n, y_dim, 1), nrm(n, 1)
         elif tpl[0] in ("real", "pos"):
+            if logvar_network:                                           # HLVAE.py:31-37 (registered before the mean parameters)
+                st[f"obs_layer.{i}.weight_logvar"], st[f"obs_layer.{i}.bias_logvar"] = nrm(n, y_dim, 1), nrm(n, 1)
             st[f"obs_layer.{i}.weight_mean"], st[f"obs_layer.{i}.bias_mean"] = nrm(n, y_dim, 1), nrm(n, 1)
         elif tpl[0] == "cat":
             st[f"obs_layer.{i}.weight"], st[f"obs_layer.{i}.bias"] = nrm(n, y_dim, K - 1), nrm(n, K - 1)
@@ -166,6 +170,9 @@ def heads(y_grouped, blocks, st, Theta, conv=False):
             t = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight_mean"]) + st[f"obs_layer.{i}.bias_mean"]
             if conv and b["type"] == "real":
                 t = torch.sigmoid(t)
+            if f"obs_layer.{i}.weight_logvar" in st:                     # logvar_network: [theta_mean | theta_logvar], HLVAE.py:42-51
+                tl = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight_logvar"]) + st[f"obs_layer.{i}.bias_logvar"]
+                t = torch.cat([t, tl], 1)
         elif b["type"] == "cat":
             t = torch.einsum("bdy,dya->bda", yb, st[f"obs_layer.{i}.weight"]) + st[f"obs_layer.{i}.bias"]
             t = torch.cat([torch.zeros(B, t.shape[1], 1, dtype=t.dtype), t], -1)        # HLVAE.py:66-67
@@ -196,19 +203,24 @@ def loglik_blocks(theta, data, mask, blocks, st, norm, noise=None, conv=False):
             else:
                 mean_d, var_d = norm[0]
             var_d = torch.clamp(var_d, 3e-4, np.inf)                      # :38
-            log_vy = -8.0 + F.softplus(st["_log_vy_real"] + 8.0)          # :51
+            n = x.shape[1]
+            free = "_log_vy_real" in st and st["_log_vy_real"] is not None
+            raw = st["_log_vy_real"] if free else th[:, n:]               # :45-52 (logvar_network: the head's second output)
+            log_vy = -8.0 + F.softplus(raw + 8.0)                         # :47 / :51
             est_var = var_d * torch.exp(log_vy)                           # :52,56
-            est_mean = torch.sqrt(var_d) * th + mean_d                    # :55
+            est_mean = torch.sqrt(var_d) * th[:, :n] + mean_d             # :55
             lp = -0.5 * (x - est_mean) ** 2 / est_var - 0.5 * math.log(2 * math.pi) - 0.5 * torch.log(est_var)  # :58
-            params.append(est_mean)                                       # :64-67 (mean only)
+            params.append(est_mean if free else [est_mean, est_var])      # :64-67 (mean only when the variance is a free parameter)
         elif b["type"] == "pos":                                          # loglik.py:73-121
             mean_d, var_d = norm[1]
             var_d = torch.clamp(var_d, 1e-3, np.inf)                      # :80
             lx = torch.log(1.0 + x)                                       # :84
-            est_mean = torch.sqrt(var_d) * th + mean_d                    # :96
-            est_var = var_d * torch.exp(st["_log_vy_pos"])                # :100
+            n = x.shape[1]
+            free = "_log_vy_pos" in st and st["_log_vy_pos"] is not None
+            est_mean = torch.sqrt(var_d) * th[:, :n] + mean_d             # :96
+            est_var = var_d * torch.exp(st["_log_vy_pos"] if free else th[:, n:])   # :100 / :105 (logvar_network)
             lp = -0.5 * (lx - est_mean) ** 2 / est_var - 0.5 * torch.log(2 * math.pi * est_var) - lx     # :102
-            params.append(est_mean)
+            params.append(est_mean if free else [est_mean, est_var])
         elif b["type"] == "count":                                        # loglik.py:191-213
             lam = torch.clamp(F.softplus(th), 1e-6, 1e20)                 # :203
             lp = x * torch.log(lam) - lam - torch.lgamma(x + 1)           # Poisson.log_prob :205-206
@@ -239,7 +251,8 @@ def loglik_blocks(theta, data, mask, blocks, st, norm, noise=None, conv=False):
 
 
 class OracleHLVAE:
-    """Functional float64 restatement of reference HLVAE (logvar_network=False; MLP or convolutional front/back end)."""
+    """Functional float64 restatement of reference HLVAE (MLP or convolutional front/back end; any number of hidden layers;
+    logvar_network False or True -- told apart by the keys of ``state``: weight_logvar / bias_logvar instead of _log_vy_*)."""
 
     def __init__(self, dims, types_info, n_variables, state: Dict[str, torch.Tensor], conv: bool = False):
         self.conv = conv
@@ -299,7 +312,11 @@ class OracleHLVAE:
         # stop-gradient through missing entries (HLVAE.py:435-452): same value, gradient only where observed
         pm = torch.zeros_like(theta)
         for b in self.blocks:
-            pm[:, b["par"]] = mask[:, b["var"]].repeat_interleave(b["K"], dim=1)
+            mb = mask[:, b["var"]]
+            if len(b["par"]) == 2 * len(b["var"]) and b["type"] in ("real", "pos"):      # logvar_network: [means | log-variances]
+                pm[:, b["par"]] = torch.cat([mb, mb], 1)                  # read_functions.py:179-183
+            else:
+                pm[:, b["par"]] = mb.repeat_interleave(b["K"], dim=1)
         theta = pm * theta + (1.0 - pm) * theta.detach()
         log_p_x, log_p_x_missing, params = loglik_blocks(theta, data, mask, self.blocks, self.st, norm, conv=self.conv)
         return log_p_x, log_p_x_missing, params, theta

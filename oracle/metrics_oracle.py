@@ -18,6 +18,8 @@ def params_by_key(p_params, blocks, B, Theta):
     """read_functions.py:206-218: per-block params -> [B, Theta]."""
     out = torch.zeros(B, Theta, dtype=DT)
     for b, p in zip(blocks, p_params):
+        if isinstance(p, (list, tuple)):                                 # [mean, var] of a real / pos block under logvar_network (:211-213)
+            p = torch.cat(list(p), 1)
         out[:, b["par"]] = p.reshape(B, -1)
     return out
 
@@ -44,13 +46,16 @@ def statistics(params_full, blocks, D, log_vy_pos):
     mode = torch.zeros(B, D, dtype=DT)
     for b in blocks:
         p = params_full[:, b["par"]]
+        n = len(b["var"])
         if b["type"] == "real":
-            mean[:, b["var"]] = p
-            mode[:, b["var"]] = p
+            mean[:, b["var"]] = p[:, :n]                                  # :276-277 (indx = the first sz columns)
+            mode[:, b["var"]] = p[:, :n]
         elif b["type"] == "pos":
-            var = torch.exp(log_vy_pos)                                   # :285 (log_vy[1])
-            mean[:, b["var"]] = torch.exp(p + 0.5 * var) - 1.0            # :288
-            mode[:, b["var"]] = torch.exp(p - var) - 1.0                  # :290
+            # :283-286: exp(log_vy[1]) when the variance is a free parameter, otherwise (logvar_network: log_vy[1] is None, the
+            # exp raises) the est_var columns of the parameter block
+            var = torch.exp(log_vy_pos) if log_vy_pos is not None else p[:, n:]
+            mean[:, b["var"]] = torch.exp(p[:, :n] + 0.5 * var) - 1.0     # :288
+            mode[:, b["var"]] = torch.exp(p[:, :n] - var) - 1.0           # :290
         elif b["type"] == "count":
             mean[:, b["var"]] = p
             mode[:, b["var"]] = torch.floor(p)

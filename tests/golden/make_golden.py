@@ -70,16 +70,20 @@ MIX_SPEC = [("real", 1), ("cat", 3), ("pos", 1), ("ordinal", 4), ("count", 1), (
             ("ordinal", 5), ("pos", 1), ("cat", 5), ("count", 1), ("cat", 3), ("real", 1), ("ordinal", 4)]
 
 
-def run_reference_model(src, rows, dims, state, seed, nll_scale, conv=False):
+def run_reference_model(src, rows, dims, state, seed, nll_scale, conv=False, logvar_network=False):
     """reference forward + loss + backward; returns dict of arrays."""
     info = dict(src.types_info, conv=conv)
-    model = ref_hlvae.HLVAE(dims, info, src.n_variables, vy_init=[1.0, 0.5], logvar_network=False,
+    if logvar_network:      # parameter layout with (mean, log-variance) slots for real / pos (read_functions.py:162-183)
+        info = dict(layout.build_types_info(src.types_info["types_dict"], miss_mask=src.mask, logvar_network=True), conv=conv)
+        for t in info["types_dict"]:
+            t["dim"], t["nclass"] = int(t["dim"]), int(t["nclass"])
+    model = ref_hlvae.HLVAE(dims, info, src.n_variables, vy_init=[1.0, 0.5], logvar_network=logvar_network,
                             conv=conv).to(T64)
     missing = model.load_state_dict(state, strict=True)
     model = model.double()
     data = torch.tensor(src.data[rows], dtype=T64)
     mask = torch.tensor(src.mask[rows], dtype=T64)
-    pmask = torch.tensor(src.param_mask[rows], dtype=T64)
+    pmask = torch.tensor((info["param_miss_mask"] if logvar_network else src.param_mask)[rows], dtype=T64)
     B = data.shape[0]
     torch.manual_seed(seed)
     eps = torch.randn(B, dims[2], dtype=T64)
@@ -96,11 +100,12 @@ def run_reference_model(src, rows, dims, state, seed, nll_scale, conv=False):
                nll=np64(nll), loss=np64(loss.reshape(1)), nll_scale=np.array([nll_scale]))
     for i, p in enumerate(p_params["x"]):
         out[f"p_params_{i}"] = np64(p if not isinstance(p, list) else torch.cat(p, 1))
+    log_vy = [getattr(model, "_log_vy_real", None), getattr(model, "_log_vy_pos", None)]
     grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
     # metrics (training.py:84-95)
     full = ref_rf.p_params_concatenation_by_key([p_params], info, B, data.device, "x")
     dtr = ref_rf.discrete_variables_transformation(data, info)
-    xh, xmode = ref_rf.statistics(full, info, data.device, False, [model._log_vy_real, model._log_vy_pos])
+    xh, xmode = ref_rf.statistics(full, info, data.device, False, log_vy)
     e_obs, e_mis, _ = ref_rf.error_computation(dtr, xh, info, mask, dim=0)
     out.update(p_params_full=np64(full), x_transformed=np64(dtr), x_hat_mean=np64(xh), x_hat_mode=np64(xmode),
                err_observed=np64(e_obs), err_missing=np64(e_mis))
@@ -135,6 +140,29 @@ def case_mix(name, seed_state, std, nll_scale):
     out["dims"] = np.array([dims[0], dims[1][0], dims[2], dims[3][0], dims[4]])
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "loss", out["loss"])
+
+
+def case_mix_logvar_deep():
+    """logvar_network=True (HLVAE.py:25-51, loglik.py:45-47, 105: the variance of every real / pos ENTRY comes from a second head)
+    together with TWO hidden layers per side (HLVAE.py:125-137, 232-242; h_dim_d is reversed, :113): the two modes of the
+    reference's constructor that the shipped configuration does not use."""
+    src = synthetic.make_tabular(n_rows=24, T=6, seed=7, spec=MIX_SPEC)
+    for name, hid_e, hid_d, lvn in (("mix_logvar", [16], [16], True), ("mix_deep", [24, 16], [12, 20], False),
+                                    ("mix_logvar_deep", [24, 16], [12, 20], True)):
+        dims = [src.cov_dim_ext, hid_e, 4, hid_d, 5]
+        info = src.types_info
+        if lvn:
+            info = layout.build_types_info(src.types_info["types_dict"], miss_mask=src.mask, logvar_network=True)
+        state = orc.init_state(dims, info, src.n_variables, seed=17, std=0.2, logvar_network=lvn)
+        out, grads = run_reference_model(src, np.arange(24), dims, state, seed=13, nll_scale=3.0, logvar_network=lvn)
+        for k, g in grads.items():
+            out["grad__" + k] = np64(g)
+        for k, v in state.items():
+            out["state__" + k] = np64(v)
+        out["hid_e"], out["hid_d"], out["logvar_network"] = np.array(hid_e), np.array(hid_d), np.array([int(lvn)])
+        out["param_indexes"] = np.asarray(info["param_indexes"])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "loss", out["loss"])
 
 
 def case_d4():
@@ -389,3 +417,4 @@ if __name__ == "__main__":
     case_d4_conv()
     case_gp()
     case_gp_predict()
+    case_mix_logvar_deep()

@@ -128,14 +128,13 @@ def test_conv_forward_backward_against_reference_fixture(golden_dir):
     e_lpm = np.abs(lpm.detach().double().cpu().numpy() - g["log_p_x_missing"])
     assert np.all(e_lpm <= 3e-2 + 2e-2 * np.abs(g["log_p_x_missing"]))
     elbo, elbo_ref = float(lpx.double().sum()), float(g["log_p_x"].sum())
-    print("CONVFIX elbo_rel", abs(elbo - elbo_ref) / abs(elbo_ref))
-    assert abs(elbo - elbo_ref) <= 1e-3 * abs(elbo_ref), (elbo, elbo_ref)
+    assert abs(elbo - elbo_ref) <= 1e-4 * abs(elbo_ref), (elbo, elbo_ref)          # measured 1e-7
     nll = model.loss_function(lpx)
     kl = -0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
     loss = float(g["nll_scale"][0]) * nll.sum() + kl
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(g["loss"][0])) <= 1e-3 * abs(float(g["loss"][0]))
+    assert abs(float(loss) - float(g["loss"][0])) <= 1e-4 * abs(float(g["loss"][0]))
     sd = dict(model.named_parameters())
     errs = {}
     for k in g.files:
@@ -150,7 +149,8 @@ def test_conv_forward_backward_against_reference_fixture(golden_dir):
     #     convolutional encoder, which an 8-row batch does not average out -> 12 % for the parameters below the first
     #     Linear, 6 % elsewhere;  (2) against the exact gradient of the bf16-rounded forward pass: 2 %
     enc_side = ("conv1.", "conv2.", "representation_layer.")
-    print("CONVFIX grads", {k: round(v, 4) for k, v in errs.items()})
+    # measured on MI355X: conv1 / representation_layer 0.10, conv2 0.08, first Linear's bias 0.045 (8 rows: a handful of ReLU /
+    # max-pool gates that flip under bf16 storage, see _bf16_forward_statement), decoder side <= 0.035
     bad = {k: v for k, v in errs.items() if not v < (0.12 if k.startswith(enc_side) else 6e-2)}
     assert not bad, (bad, errs)
     stmt = _bf16_forward_statement(g, src, om, st)

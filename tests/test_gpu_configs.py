@@ -381,6 +381,7 @@ def test_sharded_optimizer_path_matches_fused_path():
         for i in range(3):
             tr.step_rows(ds, rows[i % 2], 26, eps=eps[i], prefetch_rows=rows[(i + 1) % 2], prepacked=True)
             nll.append(float(tr.scalars()["nll_sum"]))
+        model.state_dict()              # (data-parallel path: finishes y_layer's all-gather + shadow rebuild left running)
         torch.cuda.synchronize()
         assert int(tr.opt.step_count[0]) == 3
         res.append((nll, model._arena.clone(), {k: model._ws_t[k].clone() for k in ("wys", "wyTs", "w1s", "wds", "wdTs", "wmls", "wmlTs")}))
@@ -414,3 +415,102 @@ def test_vy_fixed_parameters_stay_put_under_the_fused_optimiser():
     d = model._dims
     assert float(tr.opt.m1[int(d.frozen_lo):int(d.frozen_hi)].abs().max()) == 0.0
     assert float(model._grad_arena[int(d.frozen_lo):int(d.frozen_hi)].abs().max()) == 0.0      # cleared for the next step's atomics
+
+
+@pytest.mark.parametrize("name", ["mix_logvar", "mix_deep", "mix_logvar_deep"])
+def test_constructor_modes_against_reference_fixture(golden_dir, name):
+    """The two constructor modes the shipped configuration does not use, against outputs of the reference itself
+    (tests/golden/make_golden.py: case_mix_logvar_deep): logvar_network=True -- the variance of every real / pos ENTRY comes
+    from a second head (HLVAE.py:25-51; loglik.py:45-47, 105) -- and two hidden layers per side (HLVAE.py:113, 125-137,
+    232-242).  Forward, loss, every gradient, p_params in the reference's shapes, state_dict keys, fused training steps."""
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    from tests_common import load_mode_case
+    g, src, dims, state, info, lvn = load_mode_case(golden_dir, name)
+    dev = _dev()
+    model = HLVAE(dims, info, src.n_variables, vy_init=[1.0, 0.5], logvar_network=lvn, conv=False, max_batch=128,
+                  materialize_samples=False)
+    assert set(model.state_dict().keys()) == set(state.keys())
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(state[k].shape), k
+    model.load_state_dict(state)
+    model = model.to(dev)
+    data, mask = torch.tensor(g["data"], device=dev), torch.tensor(g["mask"], device=dev)
+    eps = torch.tensor(g["eps"], device=dev)
+    p_samples, mu, lv, lpx, lpm, p_params, q_samples, q_params = model(data, mask, None, info, eps=eps)
+    torch.cuda.synchronize()
+    e_lpx = np.abs(lpx.detach().double().cpu().numpy() - g["log_p_x"])
+    elbo, elbo_ref = float(lpx.double().sum()), float(g["log_p_x"].sum())
+    _report(name, mu=max_abs_err(mu.cpu(), g["mu"]), lv=max_abs_err(lv.cpu(), g["log_var"]), lpx_max=e_lpx.max(),
+            elbo_rel=abs(elbo - elbo_ref) / abs(elbo_ref))
+    assert max_abs_err(mu.cpu(), g["mu"]) < 2e-2 and max_abs_err(lv.cpu(), g["log_var"]) < 2e-2
+    assert np.all(e_lpx <= 3e-2 + 2e-2 * np.abs(g["log_p_x"]))
+    assert abs(elbo - elbo_ref) <= ELBO_RTOL * abs(elbo_ref)
+    for i, p in enumerate(p_params["x"]):
+        ref = g[f"p_params_{i}"]
+        if isinstance(p, list):                       # [est_mean, est_var] of a real / pos block under logvar_network
+            assert len(p) == 2 and tuple(p[0].shape) == tuple(p[1].shape)
+            p = torch.cat(p, 1)
+        assert tuple(p.shape) == ref.shape, i
+        assert max_abs_err(p.cpu(), ref) <= 3e-2 + 2e-2 * np.abs(ref).max(), i
+    loss = float(g["nll_scale"][0]) * model.loss_function(lpx).sum() - 0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"][0])) <= ELBO_RTOL * abs(float(g["loss"][0]))
+    sd = dict(model.named_parameters())
+    errs = {}
+    for k in g.files:
+        if k.startswith("grad__"):
+            pn = k[len("grad__"):]
+            if pn.startswith("hidden."):
+                continue
+            assert sd[pn].grad is not None, pn
+            errs[pn] = rel_err(sd[pn].grad.double().cpu().numpy(), g[k])
+    _report(name + "_grads", **errs)
+    for k, e in errs.items():
+        assert e < GRAD_RTOL, (k, e)
+    assert len(errs) >= 15
+    # fused training steps run and reduce the loss of a fixed batch
+    tr = ELBOTrainer(model, P_total=12, kl="normal", max_batch=128, metrics=True)
+    nll = []
+    for _ in range(25):
+        tr.step(data, mask, 4)
+        nll.append(float(tr.scalars()["nll_sum"]))
+    assert np.isfinite(nll).all() and nll[-1] < nll[0], nll
+
+
+@pytest.mark.parametrize("workload", ["d4", "tabular"])
+def test_step_is_deterministic(workload):
+    """Identical steps (learning rate 0, the same noise) must leave bit-identical dY (both layouts), log-likelihoods and dense
+    gradients: nothing on that path uses atomics (except the split-K weight gradients of small models).  (Regression: one form of the real / pos head compiled into a kernel that
+    occasionally lost one 16-lane group's store of one dY column -- 15 wrong cells in 3.3 M, invisible to every tolerance.)"""
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    from hlvae_amd.datafeed import CompactDataset
+    dev = _dev()
+    if workload == "d4":
+        src, B = synthetic.make_d4(n_subjects=30, T=20, seed=11), 512
+    else:
+        src, B = synthetic.make_tabular(n_rows=1024, T=16, seed=5), 1024
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    rows = torch.tensor(np.arange(B).astype(np.int32), device=dev)
+    eps = torch.randn(B, 32, generator=torch.Generator().manual_seed(40)).to(dev)
+    torch.manual_seed(5)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=B, materialize_samples=False).to(dev)
+    tr = ELBOTrainer(model, P_total=30, kl="normal", max_batch=B, lr=0.0, metrics=True)
+    d = model._dims
+    snaps = []
+    for _ in range(4):
+        tr.step_rows(ds, rows, 26, eps=eps)
+        torch.cuda.synchronize()
+        t = model._ws_t
+        snaps.append([t["dy"].clone(), t["dyT"].clone(), t["log_p_x"].clone(), t["xhat"].clone(),
+                      t["G"][int(d.atomic_region):int(d.arena_size)].clone()])
+    for a, b in zip(snaps[1:-1], snaps[2:]):
+        for name, x, y in zip(("dy", "dyT", "log_p_x", "xhat", "dense gradients"), a, b):
+            if name == "dense gradients" and workload == "tabular":
+                # 64 features: few output tiles, the weight-gradient GEMMs slice the batch axis and add with fp32 atomics
+                assert rel_err(x, y) < 1e-6, name
+            else:
+                assert torch.equal(x, y), name

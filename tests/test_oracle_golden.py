@@ -168,3 +168,39 @@ def test_gp_predict(golden_dir):
     Zp = gpo.batch_predict_varying_T(spec, prm, torch.tensor(g["noise"]), L, torch.tensor(g["x"]), torch.tensor(g["test_x"]),
                                      torch.tensor(g["mu"]), torch.tensor(g["z"]), idc, eps)
     assert rel_err(Zp.numpy(), g["Z_pred"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["mix_logvar", "mix_deep", "mix_logvar_deep"])
+def test_constructor_modes(golden_dir, name):
+    """logvar_network=True (HLVAE.py:25-51; loglik.py:45-47, 105) and two hidden layers per side (HLVAE.py:113, 125-137, 232-242):
+    forward, every gradient, get_test_samples and the per-step metrics against the reference's own outputs."""
+    from tests_common import load_mode_case
+    g, src, dims, state, info, lvn = load_mode_case(golden_dir, name)
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    for k in list(st):
+        if k.startswith("hidden."):
+            st[k] = st["d_layers." + k[len("hidden."):]]
+    model = orc.OracleHLVAE(dims, info, src.n_variables, st)
+    data, mask = torch.tensor(g["data"]), torch.tensor(g["mask"])
+    out = model.forward(data, mask, torch.tensor(g["eps"]))
+    for k in ("mu", "log_var", "z", "log_p_x", "log_p_x_missing"):
+        assert rel_err(out[k].detach().numpy(), g[k]) < TOL, k
+    for i, p in enumerate(out["p_params"]):
+        p = torch.cat(p, 1) if isinstance(p, list) else p
+        assert rel_err(p.detach().numpy().reshape(g[f"p_params_{i}"].shape), g[f"p_params_{i}"]) < TOL, i
+    loss = float(g["nll_scale"][0]) * model.loss_function(out["log_p_x"]).sum() + orc.standard_normal_kl(out["mu"], out["log_var"])
+    assert rel_err(loss.detach().numpy(), g["loss"][0]) < TOL
+    loss.backward()
+    checked = 0
+    for k in g.files:
+        if k.startswith("grad__"):
+            name_ = k[len("grad__"):]
+            assert rel_err(st[name_].grad.numpy(), g[k]) < 1e-9, name_
+            checked += 1
+    assert checked >= (17 if lvn else 15) + (4 if "deep" in name else 0)
+    ts = model.test_samples(data, mask)
+    assert rel_err(ts["mu"].numpy(), g["test_mu"]) < TOL and rel_err(ts["log_p_x"].numpy(), g["test_log_p_x"]) < TOL
+    det = [([q.detach() for q in p] if isinstance(p, list) else p.detach()) for p in out["p_params"]]
+    xh, e_obs, e_mis, e_all = mo.step_metrics(det, data, mask, info, None if lvn else st["_log_vy_pos"].detach())
+    assert rel_err(xh.numpy(), g["x_hat_mean"]) < TOL
+    assert rel_err(e_obs.numpy(), g["err_observed"]) < TOL and rel_err(e_mis.numpy(), g["err_missing"]) < TOL

@@ -30,6 +30,10 @@ def measure(a, label):
         from hlvae_amd import synthetic
         n_subj = (a.rows or 1000) // 20
         src = synthetic.make_tabular(n_rows=n_subj * 20, T=20, seed=100, spec=[("cat", 5)] * 972 + [("real", 1)] * 324)
+    elif a.spec == "tabsorted":   # the 64-feature mix grouped by kind (no interleave)
+        from hlvae_amd import synthetic
+        n_subj = (a.rows or 65536) // 16
+        src = synthetic.make_tabular(n_rows=n_subj * 16, T=16, seed=100, spec=synthetic.tabular_type_spec(interleave=False), expanded=False)
     else:
         src, n_subj = B_.make_source(a, 0)
     dims = [src.cov_dim_ext, [500], 32, [500], 5]
