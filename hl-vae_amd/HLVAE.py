@@ -107,7 +107,7 @@ class HLVAE(nn.Module):
     """Heterogeneous longitudinal VAE, MLP or convolutional encoder/decoder, HIP hot path (see module docstring)."""
 
     def __init__(self, dims, types_info, n_variables, vy_init=[1., .5], vy_fixed=False, logvar_network=False,
-                 conv=True, max_batch=512, materialize_samples=True):
+                 conv=True, max_batch=512, materialize_samples=True, group_variables=True):
         super().__init__()
         [x_dim, h_dim_e, z_dim, h_dim_d, y_dim] = dims
         if conv and (n_variables != 36 * 36 or y_dim != 5):
@@ -125,6 +125,7 @@ class HLVAE(nn.Module):
         self.tau = 1e-3
         self.types_info = types_info
         self.materialize_samples = materialize_samples
+        self._group_variables = bool(group_variables)   # extension: kernel-facing variable order grouped by kind
         self.plan: ColumnPlan = compile_plan(types_info, y_dim)
         if self.plan.logvar_network != bool(logvar_network):
             raise ValueError("types_info['param_indexes'] was built for logvar_network=%s" % self.plan.logvar_network)
@@ -373,12 +374,33 @@ class HLVAE(nn.Module):
         if self._plan_handle is None:
             self._dims = self._build_dims()
             h = C.c_void_p()
-            _lib.check(lib.hlvae_plan_create(C.byref(h), C.byref(self._dims), self._build_vars()), "hlvae_plan_create")
+            order = self.kernel_var_order()
+            _lib.check(lib.hlvae_plan_create(C.byref(h), C.byref(self._dims), self._build_vars(),
+                                             None if order is None else order.ctypes.data_as(C.c_void_p)), "hlvae_plan_create")
             self._plan_handle = h
         Bp = _ru(max(B, 1), 128)
         if self._ws is None or Bp > self._ws.Bp_max:
             self._alloc_workspace(max(Bp, _ru(self._max_batch, 128)))
         self._sync_shadows()
+
+    def kernel_var_order(self):
+        """Order in which the head kernel walks the variables (int32 [D]; None = their own order): grouped by likelihood
+        kind, then class count, stable otherwise.  The external order is the reference's (read_functions.py:142-198: data
+        columns, p_params and log_p_x all follow types_info); only the bf16 shadows of y_layer's weight and dY use this one,
+        so that a 16-variable tile of the kernel runs ONE likelihood body (csrc/heads.hip, include/hlvae_hip.h)."""
+        if self.conv or not self._group_variables:
+            return None
+        key = np.asarray(self.plan.kind, dtype=np.int64) * 1024 + np.asarray(self.plan.ncls, dtype=np.int64)
+        order = np.argsort(key, kind="stable").astype(np.int32)
+        return None if np.array_equal(order, np.arange(len(order))) else np.ascontiguousarray(order)
+
+    def kernel_wy_rows(self):
+        """row of y_layer's weight held by each row of its bf16 shadow `wys` (tests, debugging)"""
+        order = self.kernel_var_order()
+        n = self.plan.D * self.y_dim
+        if order is None:
+            return np.arange(n)
+        return (order.astype(np.int64)[:, None] * self.y_dim + np.arange(self.y_dim)[None, :]).reshape(-1)
 
     def _head_acc(self) -> int:
         """accumulators per variable of the head-kernel instance this plan selects (csrc/heads.hip: HeadAcc + y_dim)"""

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HLVAE_LIB_PATH", os.path.join(_HERE, "libhlvae_hip.so"))      # (override: diagnostic builds)
-ABI_VERSION = 25
+ABI_VERSION = 26
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -64,7 +64,7 @@ _SIGS = {
     "hlvae_last_error": (C.c_char_p, []),
     "hlvae_struct_sizes": (None, [C.POINTER(C.c_int32)] * 3),
     "hlvae_dims_fill": (None, [C.POINTER(HlvaeDims)]),
-    "hlvae_plan_create": (C.c_int, [C.POINTER(_vp), C.POINTER(HlvaeDims), C.POINTER(HlvaeVar)]),
+    "hlvae_plan_create": (C.c_int, [C.POINTER(_vp), C.POINTER(HlvaeDims), C.POINTER(HlvaeVar), _vp]),
     "hlvae_plan_destroy": (None, [_vp]),
     "hlvae_refresh_shadows": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp]),
     "hlvae_normalize_stats": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_int, _vp]),

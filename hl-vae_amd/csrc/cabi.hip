@@ -7,7 +7,8 @@
 #include "common.h"
 
 // launchers implemented next to their kernels
-int hl_launch_gemm_f32(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, int, float*, const char*, hipStream_t);
+int hl_launch_gemm_f32(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, int, float*, const char*, hipStream_t,
+                       const int32_t* rowmap = nullptr);
 int hl_launch_gemm_splitk(const bf16_t*, int, const bf16_t*, int, float*, int, int, int, int, int, const char*, hipStream_t);
 int hl_launch_gemm_act(int, const bf16_t*, int, const bf16_t*, int, int, int, int, const float*, int, const bf16_t*,
                        bf16_t*, int, bf16_t*, int, int, float*, const char*, hipStream_t);
@@ -122,7 +123,7 @@ void hlvae_dims_fill(hlvae_dims* d) {
     d->NYlp = ru(d->NYl, 64);
 }
 
-int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var* vars) {
+int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var* vars, const int32_t* var_order) {
     HL_REQUIRE(out && dims && vars, HLVAE_EINVAL, "plan_create: null argument");
     hlvae_dims d = *dims;
     hlvae_dims_fill(&d);
@@ -178,9 +179,29 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     }
     HL_REQUIRE(x == d.X, HLVAE_EINVAL, "plan_create: variables cover %d columns, X=%d", x, d.X);
     HL_REQUIRE(nstat_seen == d.n_stat, HLVAE_EINVAL, "plan_create: %d statistic rows, n_stat=%d", nstat_seen, d.n_stat);
+    // kernel-facing order of the variables (head kernel, dY, y_layer's shadows)
+    std::vector<hlvae_var> sorted(vars, vars + d.D);
+    std::vector<int32_t> rowsrc;
+    bool permuted = false;
+    if (var_order != nullptr) {
+        HL_REQUIRE(!d.conv, HLVAE_EINVAL, "plan_create: var_order is not available for the convolutional model (its y_grouped is a pixel grid)");
+        std::vector<char> seen(d.D, 0);
+        for (int j = 0; j < d.D; ++j) {
+            const int o = var_order[j];
+            HL_REQUIRE(o >= 0 && o < d.D && !seen[o], HLVAE_EINVAL, "plan_create: var_order is not a permutation (position %d)", j);
+            seen[o] = 1;
+            sorted[j] = vars[o];
+            permuted |= o != j;
+        }
+    }
+    for (int j = 0; j < d.D; ++j) sorted[j].pad = var_order != nullptr ? var_order[j] : j;
+    if (permuted) {
+        rowsrc.resize(d.NYlp);
+        for (int r = 0; r < d.NYlp; ++r) rowsrc[r] = r < d.NY ? sorted[r / d.y_dim].pad * d.y_dim + r % d.y_dim : r;
+    }
     hlvae_plan* p = new hlvae_plan();
     p->d = d;
-    p->vars_dev = nullptr; p->col2var_dev = nullptr; p->stat_var_dev = nullptr;
+    p->vars_dev = nullptr; p->col2var_dev = nullptr; p->stat_var_dev = nullptr; p->vars_sorted_dev = nullptr; p->wy_rowsrc_dev = nullptr;
     p->kmax = 2;
     p->pend_flags = 0;
     for (int i = 0; i < d.D; ++i)
@@ -196,6 +217,10 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     if (e == hipSuccess) e = hipMalloc(&p->col2var_dev, sizeof(int32_t) * d.Xp);
     if (e == hipSuccess) e = hipMalloc(&p->stat_var_dev, sizeof(int32_t) * stat_var.size());
     if (e == hipSuccess) e = hipMemcpy(p->vars_dev, vars, sizeof(hlvae_var) * d.D, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->vars_sorted_dev, sizeof(hlvae_var) * d.D);
+    if (e == hipSuccess) e = hipMemcpy(p->vars_sorted_dev, sorted.data(), sizeof(hlvae_var) * d.D, hipMemcpyHostToDevice);
+    if (e == hipSuccess && permuted) e = hipMalloc(&p->wy_rowsrc_dev, sizeof(int32_t) * rowsrc.size());
+    if (e == hipSuccess && permuted) e = hipMemcpy(p->wy_rowsrc_dev, rowsrc.data(), sizeof(int32_t) * rowsrc.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->col2var_dev, col2var.data(), sizeof(int32_t) * d.Xp, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->stat_var_dev, stat_var.data(), sizeof(int32_t) * stat_var.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -210,6 +235,8 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
 void hlvae_plan_destroy(hlvae_plan* p) {
     if (!p) return;
     if (p->vars_dev) (void)hipFree(p->vars_dev);
+    if (p->vars_sorted_dev) (void)hipFree(p->vars_sorted_dev);
+    if (p->wy_rowsrc_dev) (void)hipFree(p->wy_rowsrc_dev);
     if (p->col2var_dev) (void)hipFree(p->col2var_dev);
     if (p->stat_var_dev) (void)hipFree(p->stat_var_dev);
     for (auto& st : p->side)
@@ -414,7 +441,7 @@ int hlvae_backward_wy(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stre
     // data-parallel host can start its all-reduce while hlvae_backward(skip_wy = 1) is still running
     HL_REQUIRE(!d.conv, HLVAE_EINVAL, "backward_wy: not available for the convolutional model (y_layer's gradient is final "
                "only after the transposed convolutions' backward)");
-    return hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", st);
+    return hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", st, p->wy_rowsrc_dev);
 }
 
 struct HlAdamArgs {
@@ -483,7 +510,9 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         if (d.conv)     // the batch-contiguous copy of d(y_layer output) that the weight-gradient GEMM reads
             if ((rc = hl_launch_transpose_bf16(ws->dyc, d.NYlp, ws->dycT, Bp, Bp, d.NYl, "dyc_transpose", s0))) return rc;
         // d Wy = dY^T U  [NYl][h_d]
-        if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0))) return rc;
+        // (rows of dY^T are in the head kernel's variable order: the store maps them back to the master's rows)
+        if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0,
+                                     d.conv ? nullptr : p->wy_rowsrc_dev))) return rc;
         if (opt != nullptr) {       // takes no completion ticket: the final launch below is ordered behind it by the join
             HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
             if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0x01, 0,

@@ -78,6 +78,9 @@ __device__ __forceinline__ float xor32_sum(float a) {
 struct hlvae_plan {
     hlvae_dims d;
     hlvae_var* vars_dev;      // [D]
+    hlvae_var* vars_sorted_dev;   // [D] the same rows in the head kernel's order (grouped by kind); .pad = the variable's own index
+    int32_t* wy_rowsrc_dev;       // [NYlp] row of y_layer's weight (master order) that shadow / dY row j (kernel order) holds;
+                                  // nullptr: identity (convolutional model, or variables already grouped)
     int32_t* col2var_dev;     // [Xp]  variable of an expanded column, -1 in the padding
     int32_t* stat_var_dev;    // [n_stat] variable index of each statistics row
     int kmax;                 // largest class count among cat / ordinal variables (selects the head-kernel instance)

@@ -39,7 +39,10 @@ template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32(const bf16_t* __restrict__ A, int lda,
                                                          const bf16_t* __restrict__ B, int ldb, float* __restrict__ C,
                                                          int ldc, int M, int N, int K, int band, int band_rows,
-                                                         float* __restrict__ C2, int tiles_m, int tiles_n, int n_fast, int kper) {
+                                                         float* __restrict__ C2, int tiles_m, int tiles_n, int n_fast, int kper,
+                                                         const int32_t* __restrict__ rowmap) {
+    // rowmap != nullptr: output row gr is stored at row rowmap[gr] of C (y_layer's weight gradient: dY^T arrives in the head
+    // kernel's variable order, the gradient arena keeps the master's)
     // kper < K: split-K -- gridDim.x = tiles x slices, slice s covers k in [s kper, (s + 1) kper) and ADDS its partial tile
     // (fp32 atomics) into a C the launcher has cleared.  For weight gradients with few output tiles and a long batch axis
     // (64-feature models at 4096 rows: 40 tiles x 64 k-steps otherwise)
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32(const bf16_t* __restric
         for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
             const int r = idx / BN, c = idx % BN;
             const int gr = m0 + r, gc = n0 + c;
-            if (gr < M && gc < N) atomicAdd(C + (size_t)gr * ldc + gc, Cs[r * G::CLD + c]);
+            if (gr < M && gc < N) atomicAdd(C + (size_t)(rowmap != nullptr ? rowmap[gr] : gr) * ldc + gc, Cs[r * G::CLD + c]);
         }
         return;
     }
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32(const bf16_t* __restric
         const int gr = m0 + r, gc = n0 + c;
         if (gr >= M || gc >= N) continue;
         if (band <= 0) {
-            C[(size_t)gr * ldc + gc] = Cs[r * G::CLD + c];
+            C[(size_t)(rowmap != nullptr ? rowmap[gr] : gr) * ldc + gc] = Cs[r * G::CLD + c];
         } else {   // rows [0,band_rows) -> C, rows [band, band+band_rows) -> C2, others dropped
             if (gr < band_rows) C[(size_t)gr * ldc + gc] = Cs[r * G::CLD + c];
             else if (gr >= band && gr < band + band_rows) C2[(size_t)(gr - band) * ldc + gc] = Cs[r * G::CLD + c];
@@ -221,7 +224,7 @@ int hl_wgrad_ksplit(long tiles, int K) {
 }
 
 int hl_launch_gemm_f32(const bf16_t* A, int lda, const bf16_t* B, int ldb, float* C, int ldc, int M, int N, int K,
-                       int band, int band_rows, float* C2, const char* label, hipStream_t s) {
+                       int band, int band_rows, float* C2, const char* label, hipStream_t s, const int32_t* rowmap = nullptr) {
     HL_REQUIRE(K % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0, HLVAE_ESHAPE, "gemm_f32: K=%d lda=%d ldb=%d", K, lda, ldb);
     const int n_fast = M >= N;      // A is the larger operand: its row panel is reused by consecutive ids
     // split-K: few 64 x 64 output tiles and a long K (the batch axis of a weight gradient)
@@ -236,7 +239,7 @@ int hl_launch_gemm_f32(const bf16_t* A, int lda, const bf16_t* B, int ldb, float
     {                                                                                                           \
         const int tm = (M + BMv - 1) / BMv, tn = (N + BNv - 1) / BNv;                                           \
         k_gemm_f32<BMv, BNv, BKv, WMv, WNv><<<tm * tn * ((K + kper - 1) / kper), HL_THREADS, 0, s>>>(A, lda, B, ldb, C, ldc, M, N, K, \
-                                                                          band, band_rows, C2, tm, tn, n_fast, kper); \
+                                                                          band, band_rows, C2, tm, tn, n_fast, kper, rowmap); \
     }
     if (N <= 32) {
         if (K % 64 == 0) HL_GO(64, 32, 64, 4, 1) else HL_GO(64, 32, 32, 4, 1)

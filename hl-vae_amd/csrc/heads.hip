@@ -496,8 +496,9 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     float* xs = pscr + 16 * PS;                                   // [RPT][256] this thread's targets at xs[i * 256 + tid]
     uint8_t* ms = reinterpret_cast<uint8_t*>(xs + RPT * HL_THREADS);
     const int tid = threadIdx.x, v = tid & 15, rg = tid >> 4;
-    const int d = tn * 16 + v;
+    const int d = tn * 16 + v;                                    // position in the kernel's variable order (`vars` is in that order)
     hlvae_var var = vars[d < D ? d : D - 1];                     // unconditional (a conditional copy makes hipcc wait for it at once);
+    const int dv = var.pad;                                       // the variable's own index: columns of the [B, D] buffers, y_layer's bias
     // Everything the epilogue reads from global memory is REQUESTED here, ahead of the GEMM, and parked in LDS by the hook
     // below while the GEMM's own first tiles are still in flight: the likelihood targets and masks of this thread's rows
     // (HBM-cold: they used to cost every wave a full memory latency at the top of the epilogue) and, by 16 lanes (one per
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int gr = min(m0 + HL_ROW(rg, i), B - 1);               // clamped, unconditional loads; rows >= B are masked when parked
-        const size_t o = (size_t)gr * D + (d < D ? d : D - 1);
+        const size_t o = (size_t)gr * D + dv;
         xv[i] = xt[o];
         mv[i] = m8[o];
     }
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
             pre[PW + 2 * PB] = cont ? norm[var.sidx] : 0.f;
             pre[PW + 2 * PB + 1] = cont ? norm[n_stat + var.sidx] : 1.f;
 #pragma unroll
-            for (int k = 0; k < YD; ++k) pre[PW + 2 * PB + 2 + k] = conv ? 0.f : P[o_by + (long)d * YD + k];
+            for (int k = 0; k < YD; ++k) pre[PW + 2 * PB + 2 + k] = conv ? 0.f : P[o_by + (long)dv * YD + k];
         }
     };
     auto park_params = [&]() {
@@ -591,34 +592,34 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
             case HLVAE_POS: {
                 const bool is_pos = var.kind == HLVAE_POS;
                 if (logvar)      // (uniform: a kernel argument)
-                    proc_realpos<YD, BM, CLD, NHEAD, true>(is_pos, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
+                    proc_realpos<YD, BM, CLD, NHEAD, true>(is_pos, Cs, v, rg, m0, B, D, dv, var, P, norm, n_stat, byv, xt, m8, g_elem,
                                                            g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, false);
                 else
-                    proc_realpos<YD, BM, CLD, NHEAD, false>(is_pos, Cs, v, rg, m0, B, D, d, var, P, norm, n_stat, byv, xt, m8, g_elem,
+                    proc_realpos<YD, BM, CLD, NHEAD, false>(is_pos, Cs, v, rg, m0, B, D, dv, var, P, norm, n_stat, byv, xt, m8, g_elem,
                                                             g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, conv && !is_pos);
                 break;
             }
             case HLVAE_COUNT:
-                proc_count<YD, BM, CLD, NHEAD>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                proc_count<YD, BM, CLD, NHEAD>(Cs, v, rg, m0, B, D, dv, var, P, byv, xt, m8, g_elem, g_scale, logpx,
                                                logpx_miss, pfull, X, xhat, hacc, lpo);
                 break;
             case HLVAE_CAT:
                 if (KMAX <= 3 || var.ncls <= 3)
-                    proc_cat<YD, BM, CLD, NHEAD, 3>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                    proc_cat<YD, BM, CLD, NHEAD, 3>(Cs, v, rg, m0, B, D, dv, var, P, byv, xt, m8, g_elem, g_scale, logpx,
                                                     logpx_miss, pfull, X, xhat, hacc, lpo);
                 else if (KMAX <= 5 || var.ncls <= 5)
-                    proc_cat<YD, BM, CLD, NHEAD, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem,
+                    proc_cat<YD, BM, CLD, NHEAD, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, dv, var, P, byv, xt, m8, g_elem,
                                                                        g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo);
                 else
-                    proc_cat<YD, BM, CLD, NHEAD, KMAX>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                    proc_cat<YD, BM, CLD, NHEAD, KMAX>(Cs, v, rg, m0, B, D, dv, var, P, byv, xt, m8, g_elem, g_scale, logpx,
                                                        logpx_miss, pfull, X, xhat, hacc, lpo);
                 break;
             case HLVAE_ORDINAL:
                 if (KMAX <= 5 || var.ncls <= 5)
-                    proc_ord<YD, BM, CLD, NHEAD, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem,
+                    proc_ord<YD, BM, CLD, NHEAD, (KMAX < 5 ? KMAX : 5)>(Cs, v, rg, m0, B, D, dv, var, P, byv, xt, m8, g_elem,
                                                                        g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo);
                 else
-                    proc_ord<YD, BM, CLD, NHEAD, KMAX>(Cs, v, rg, m0, B, D, d, var, P, byv, xt, m8, g_elem, g_scale, logpx,
+                    proc_ord<YD, BM, CLD, NHEAD, KMAX>(Cs, v, rg, m0, B, D, dv, var, P, byv, xt, m8, g_elem, g_scale, logpx,
                                                        logpx_miss, pfull, X, xhat, hacc, lpo);
                 break;
         }
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(256) void k_head_grad_reduce(const float* __restric
     int dst;
     if (n >= NHEAD) {
         if (conv) return;                                        // y_layer's bias gradient belongs to the convolution kernels there
-        dst = (int)o_by + dd * YD + (n - NHEAD);
+        dst = (int)o_by + vars[dd].pad * YD + (n - NHEAD);         // `vars` is in the kernel's order, the bias in the variables' own
     } else {
         dst = acc_dest<YD, KMAX>(vars[dd], n);
     }
@@ -736,7 +737,7 @@ int hl_launch_head_grad_reduce(const hlvae_plan* p, const hlvae_ws* ws, int Bp, 
     HL_PROF("head_grad_reduce", s);
 #define HL_RED(YDv, KMv)                                                                                               \
     k_head_grad_reduce<YDv, KMv><<<(NTV * (HeadAcc<YDv, KMv>::N + YDv) + 255) / 256, 256, 0, s>>>(ws->hgpart, tiles_m, NTV, d.D,    \
-                                                                                                p->vars_dev, ws->G, d.o_by, d.conv)
+                                                                                                p->vars_sorted_dev, ws->G, d.o_by, d.conv)
     if (d.y_dim == 3) HL_RED(3, 8);
     else if (d.y_dim == 8) HL_RED(8, 8);
     else if (p->kmax <= 3) HL_RED(5, 3);
@@ -914,12 +915,12 @@ int hl_launch_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float
 
 // dY *= g[b][d] after the fact (autograd path with a non-uniform upstream gradient)
 __global__ void k_scale_dy(bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dyT, int Bp,
-                           const float* __restrict__ g, int B, int D, int YD) {
-    const int NY = D * YD;
+                           const float* __restrict__ g, int B, int D, int YD, const hlvae_var* __restrict__ vars) {
+    const int NY = D * YD;                                        // (dY's columns follow `vars`, the kernel's variable order; g the variables' own)
     const long n = (long)B * NY;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int b = (int)(i / NY), c = (int)(i % NY);
-        const float s = g[(size_t)b * D + c / YD];
+        const float s = g[(size_t)b * D + vars[c / YD].pad];
         const size_t o = (size_t)b * lddy + c;
         const bf16_t r = f2bf(bf2f(dy[o]) * s);
         dy[o] = r;
@@ -968,7 +969,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
         long long* clk = hl_heads_clk_buffer(grid);
 #define HL_LAUNCH_HEADS(KMv) HL_LAUNCH_HEADS_Y(5, 64, KMv)
 #define HL_LAUNCH_HEADS_Y(YDv, BMv, KMv)                                                                               \
-        k_y_heads<YDv, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_dev, ws->P, ws->hgpart, d.o_by,  \
+        k_y_heads<YDv, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_sorted_dev, ws->P, ws->hgpart, d.o_by,  \
                                                           ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, \
                                                           d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing,       \
                                                           ws->rowpart, pf, d.Theta, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY, clk, d.Theta != d.X)
@@ -997,7 +998,7 @@ int hl_launch_elbo_finalize(const hlvae_plan* p, const hlvae_ws* ws, int B, int 
 int hl_launch_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g, int B, int Bp, hipStream_t s) {
     const hlvae_dims& d = p->d;
     HL_PROF("scale_dy", s);
-    k_scale_dy<<<1024, 256, 0, s>>>(ws->dy, d.NYp, ws->dyT, Bp, g, B, d.D, d.y_dim);
+    k_scale_dy<<<1024, 256, 0, s>>>(ws->dy, d.NYp, ws->dyT, Bp, g, B, d.D, d.y_dim, p->vars_sorted_dev);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -21,6 +21,7 @@ struct ShadowMat {
     bf16_t* dstT;      // [..][ldT] transposed bf16 or nullptr
     int ldT;
     int Rcover, Ccover;   // region of dst (rows, cols) to fill, zero outside [R][C]
+    const int32_t* rowsrc;   // master row that tile row r holds (y_layer: the head kernel's variable order), nullptr = r
     int tiles_c, tile0;   // tiles per row of tiles, first block index (a multiple of 8)
     int npad, remap;      // workgroups owned (tiles rounded up to a multiple of 8); XCD-contiguous tile order
 };
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
     for (int i = 0; i < 4; ++i) {
         const int r = rq + 16 * i;
         in[i] = r0 + r < mt.R && c0 + c4 < mt.C;
-        o[i] = in[i] ? mt.off + (long)(r0 + r) * mt.C + c0 + c4 : mt.off;
+        const long srow = (in[i] && mt.rowsrc != nullptr) ? mt.rowsrc[r0 + r] : r0 + r;       // shadows: tile order; masters: their own
+        o[i] = in[i] ? mt.off + srow * mt.C + c0 + c4 : mt.off;
         p[i] = ld4(P, o[i]);
     }
     if (update) {
@@ -199,6 +201,7 @@ static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws, unsigned whic
         ShadowMat& m = s.m[i];
         m.off = off; m.R = R; m.C = C; m.dst = dst; m.ldd = ldd; m.row_off = row_off; m.dstT = dstT; m.ldT = ldT;
         m.Rcover = Rc; m.Ccover = Cc;
+        m.rowsrc = nullptr;
         m.tiles_c = (Cc + 63) / 64;
     };
     // Wy [NY][h_d] -> wys [NY][hdp] (+ [hdp][NYp]);  W1 [h_e][X] -> w1s [hep][Xp];
@@ -206,6 +209,7 @@ static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws, unsigned whic
     // (conv: y_layer is [2592][h_d], the first encoder Linear is [h_e][2592] and also needs its transpose: the convolutional
     //  features receive a gradient, the raw inputs of the MLP path do not)
     put(0, d.o_wy, d.NYl, d.h_d, ws->wys, d.hdp, 0, ws->wyTs, d.NYlp, d.NYl, d.hdp);
+    s.m[0].rowsrc = d.conv ? nullptr : p->wy_rowsrc_dev;
     put(1, d.o_w1, d.h_e, d.Xe, ws->w1s, d.Xep, 0, d.conv ? ws->w1Ts : nullptr, d.hep, d.hep, d.Xep);
     put(2, d.o_wd, d.h_d, d.L, ws->wds, d.Lp, 0, ws->wdTs, d.hdp, d.hdp, d.Lp);
     put(3, d.o_wmu, d.L, d.h_e, ws->wmls, d.hep, 0, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep);

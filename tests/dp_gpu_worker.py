@@ -92,7 +92,7 @@ def main():
     out["replica_drift"] = drift
     # the shadows ARE the bf16 rounding of the gathered masters
     d = model_d._dims
-    wy = model_d.y_layer[0].weight.detach()
+    wy = model_d.y_layer[0].weight.detach()[torch.as_tensor(model_d.kernel_wy_rows(), device=dev)]   # shadow rows: kernel's variable order
     out["shadow_vs_master"] = float((model_d._ws_t["wys"][:wy.shape[0], :wy.shape[1]].float() - wy.to(torch.bfloat16).float()).abs().max())
     if rank == 0:
         print("DPRESULT " + json.dumps(out), flush=True)

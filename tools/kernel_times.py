@@ -38,7 +38,8 @@ def measure(a, label):
         src, n_subj = B_.make_source(a, 0)
     dims = [src.cov_dim_ext, [500], 32, [500], 5]
     torch.manual_seed(0)
-    model = HLVAE(dims, src.types_info, src.n_variables, conv=a.conv, max_batch=a.batch, materialize_samples=False).to(dev)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=a.conv, max_batch=a.batch, materialize_samples=False,
+                  group_variables=not a.no_group).to(dev)
     gp = None
     if a.kl == "gp":
         from hlvae_amd.elbo_functions import GPPriorHIP
@@ -110,6 +111,7 @@ def main():
     ap.add_argument("-n", type=int, default=30)
     ap.add_argument("--env", default=None)
     ap.add_argument("--spec", default=None)
+    ap.add_argument("--no-group", action="store_true", help="head kernel walks the variables in their own order")
     a = ap.parse_args()
     if a.env:
         name, vals = a.env.split("=")
