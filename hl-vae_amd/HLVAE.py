@@ -116,10 +116,15 @@ class HLVAE(nn.Module):
         if logvar_network and conv:
             raise NotImplementedError("logvar_network=True with the convolutional decoder is not built (the shipped configuration "
                                       "uses logvar_network=False, config/hlvae_config_file.txt)")
-        if not (isinstance(h_dim_e, (list, tuple)) and len(h_dim_e) == 1 and isinstance(h_dim_d, (list, tuple))
-                and len(h_dim_d) == 1):
-            raise NotImplementedError("exactly one hidden layer per side is implemented (reference config: [500])")
-        h_dim_d = [i for i in reversed(h_dim_d)]                                    # HLVAE.py:113
+        if not (isinstance(h_dim_e, (list, tuple)) and isinstance(h_dim_d, (list, tuple))
+                and 1 <= len(h_dim_e) <= 1 + _lib.MAX_EXTRA and 1 <= len(h_dim_d) <= 1 + _lib.MAX_EXTRA
+                and all(int(w) > 0 for w in list(h_dim_e) + list(h_dim_d))):
+            raise NotImplementedError(f"dims[1] / dims[3] must list 1..{1 + _lib.MAX_EXTRA} positive hidden widths per side (reference "
+                                      "config: [500]; the reference's h_dim = [] / 0 'no hidden layer' variants are not built)")
+        if conv and (len(h_dim_e) != 1 or len(h_dim_d) != 1):
+            raise NotImplementedError("the convolutional model is built with one hidden layer per side (config/hlvae_config_file.txt)")
+        h_dim_e = [int(w) for w in h_dim_e]
+        h_dim_d = [int(i) for i in reversed(h_dim_d)]                               # HLVAE.py:113
         self.z_dim, self.num_dim, self.y_dim = z_dim, n_variables, y_dim
         self.logvar_network, self.conv = logvar_network, conv
         self.tau = 1e-3
@@ -132,7 +137,9 @@ class HLVAE(nn.Module):
         if self.plan.X != x_dim or self.plan.D != n_variables:
             raise ValueError(f"dims[0]={x_dim}/n_variables={n_variables} do not match types_info "
                              f"(X={self.plan.X}, D={self.plan.D})")
-        self.h_e, self.h_d = int(h_dim_e[0]), int(h_dim_d[0])
+        # h_e: the LAST encoder layer (feeds mean / log-var); h_d: the LAST decoder layer (y_layer's input); h_d0: the first
+        self.h_e, self.h_d, self.h_d0 = h_dim_e[-1], h_dim_d[-1], h_dim_d[0]
+        self._h_dim_e, self._h_dim_d = h_dim_e, h_dim_d
         pl = self.plan
         # bookkeeping attributes the reference exposes (HLVAE.py:180-201)
         self.real_dim, self.pos_dim = pl.n_real, pl.n_pos
@@ -154,7 +161,11 @@ class HLVAE(nn.Module):
             x_enc = _lib.CONV_FEATURES
         else:
             x_enc = x_dim
-        self.VAE_encoder_common_layers = nn.Sequential(nn.Linear(x_enc, self.h_e), nn.ReLU())
+        e_layers, n_in = [], x_enc                                                   # HLVAE.py:128-137 / 156-165
+        for w in h_dim_e:
+            e_layers += [nn.Linear(n_in, w), nn.ReLU()]
+            n_in = w
+        self.VAE_encoder_common_layers = nn.Sequential(*e_layers)
         self.mean_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
         self.log_var_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
         if logvar_network:                                                           # HLVAE.py:219-222: plain None attributes
@@ -163,7 +174,12 @@ class HLVAE(nn.Module):
             self._log_vy_real = nn.Parameter(torch.empty(pl.n_real))
             self._log_vy_pos = nn.Parameter(torch.empty(pl.n_pos))
         self._disp_param = nn.Parameter(torch.ones(1))
-        self.d_layers = nn.ModuleList([nn.Linear(z_dim, self.h_d), nn.ReLU()])
+        self.d_layers = nn.ModuleList()                                              # HLVAE.py:232-240
+        n_in = z_dim
+        for w in h_dim_d:
+            self.d_layers.append(nn.Linear(n_in, w))
+            self.d_layers.append(nn.ReLU())
+            n_in = w
         self.hidden = nn.Sequential(*self.d_layers)                                  # alias, HLVAE.py:242
         self.y_layer = nn.Sequential(nn.Linear(self.h_d, _lib.CONV_FEATURES if conv else y_dim * n_variables))   # HLVAE.py:244-248
         if conv:                                                                     # HLVAE.py:253-259
@@ -194,13 +210,19 @@ class HLVAE(nn.Module):
             for m in self.representation_layer:
                 order += [m.weight, m.bias]
             order += conv_params
+        # the fused kernels' "first encoder Linear" is the LAST of the stack, their decoder trunk the FIRST decoder Linear;
+        # the other hidden layers are the "extra" ones (include/hlvae_hip.h: hlvae_layer)
+        # (plain attribute slots: assigning a Module to self would register it under a second state_dict key)
+        object.__setattr__(self, "_enc_last", self.VAE_encoder_common_layers[2 * (len(h_dim_e) - 1)])
+        object.__setattr__(self, "_extra_enc", [self.VAE_encoder_common_layers[2 * i] for i in range(len(h_dim_e) - 1)])
+        object.__setattr__(self, "_extra_dec", [self.d_layers[2 * j] for j in range(1, len(h_dim_d))])
         order += [self.y_layer[0].bias, self.d_layers[0].bias, self.mean_layer[0].bias, self.log_var_layer[0].bias,
-                  self.VAE_encoder_common_layers[0].bias]
+                  self._enc_last.bias] + [m.bias for m in self._extra_enc + self._extra_dec]
         n_small = len(order)
         # y_layer's weight LAST: its gradient is final first and is all-reduced on its own while the rest of the backward
         # pass runs; everything before it is then ONE contiguous slice for the second all-reduce
-        order += [self.d_layers[0].weight, self.mean_layer[0].weight, self.log_var_layer[0].weight,
-                  self.VAE_encoder_common_layers[0].weight, self.y_layer[0].weight]
+        order += ([self.d_layers[0].weight, self.mean_layer[0].weight, self.log_var_layer[0].weight, self._enc_last.weight]
+                  + [m.weight for m in self._extra_enc + self._extra_dec] + [self.y_layer[0].weight])
         self._order = order
         offs, o = [], 0
         for i, p in enumerate(order):
@@ -320,11 +342,17 @@ class HLVAE(nn.Module):
             first = self.representation_layer[0].weight if len(self.representation_layer) else self.conv1.weight
             d.o_cv_lo = ao(first)                         # the arena order puts these tensors back to back (see __init__)
             d.cv_n = ao(self.y_layer[0].bias) + self.y_layer[0].bias.numel() - d.o_cv_lo
-        d.o_w1, d.o_b1 = ao(self.VAE_encoder_common_layers[0].weight), ao(self.VAE_encoder_common_layers[0].bias)
+        d.o_w1, d.o_b1 = ao(self._enc_last.weight), ao(self._enc_last.bias)
         d.o_wmu, d.o_bmu = ao(self.mean_layer[0].weight), ao(self.mean_layer[0].bias)
         d.o_wlv, d.o_blv = ao(self.log_var_layer[0].weight), ao(self.log_var_layer[0].bias)
         d.o_wd, d.o_bd = ao(self.d_layers[0].weight), ao(self.d_layers[0].bias)
         d.o_wy, d.o_by = ao(self.y_layer[0].weight), ao(self.y_layer[0].bias)
+        d.n_xe, d.n_xd, d.h_d0 = len(self._extra_enc), len(self._extra_dec), self.h_d0
+        for arr, mods in ((d.xe, self._extra_enc), (d.xd, self._extra_dec)):
+            for i, m in enumerate(mods):
+                arr[i].n_in, arr[i].n_out, arr[i].o_w, arr[i].o_b = m.in_features, m.out_features, ao(m.weight), ao(m.bias)
+        extra = self._extra_enc + self._extra_dec
+        d.o_xw = ao(extra[0].weight) if extra else d.o_wy
         d.arena_size, d.atomic_region = self._arena_size, self._atomic_region
         d.frozen_lo = d.frozen_hi = 0
         if self._log_vy_real is not None and not self._log_vy_real.requires_grad and not self._log_vy_pos.requires_grad:      # vy_fixed (HLVAE.py:209-216)
@@ -412,7 +440,7 @@ class HLVAE(nn.Module):
         d, dev = self._dims, self.device
         bf, f32 = torch.bfloat16, torch.float32
         z = lambda *s, dt=bf: torch.zeros(*s, dtype=dt, device=dev)
-        ksteps_e, ksteps_d = d.Xep // 64, d.NYlp // 64
+        ksteps_e, ksteps_d = d.K1p // 64, d.NYlp // 64
         # split-K: a multiple of 8 slices when K allows it (one K-slice per XCD: each slice of the operands is pulled
         # into exactly one L2), enough blocks for about two waves of the 256 CUs, and no empty split
         def pick(ksteps, tiles):
@@ -426,29 +454,46 @@ class HLVAE(nn.Module):
         NT = (d.D + 15) // 16
         t = dict(
             G=z(self._arena_size + GRAD_SLACK, dt=f32),      # tail slack: the padded extent of the last reduce-scatter slice
-            w1s=z(d.hep, d.Xep), wmls=z(2 * d.Lp, d.hep), wmlTs=z(d.hep, 2 * d.Lp), wds=z(d.hdp, d.Lp),
-            wdTs=z(d.Lp, d.hdp), wys=z(d.NYlp if d.conv else d.NYl, d.hdp), wyTs=z(d.hdp, d.NYlp),
+            w1s=z(d.hep, d.K1p), wmls=z(2 * d.Lp, d.hep), wmlTs=z(d.hep, 2 * d.Lp), wds=z(d.hd0p, d.Lp),
+            wdTs=z(d.Lp, d.hd0p), wys=z(d.NYlp if d.conv else d.NYl, d.hdp), wyTs=z(d.hdp, d.NYlp),
             sums=z(_lib.STAT_CHUNKS, 3, max(d.n_stat, 1), dt=torch.float64), norm=z(2, max(d.n_stat, 1), dt=f32),
             xn=z(Bp, d.Xep), xnT=z(d.Xep, Bp), xt=z(Bp, d.D, dt=f32), m8=z(Bp, d.D, dt=torch.uint8),
-            slab=z(max(S_e, S_d), Bp, max(d.hep, d.hdp), dt=f32),
+            slab=z(max(S_e, S_d), Bp, max(d.hep, d.hdp, d.hd0p), dt=f32),
             t=z(Bp, d.hep), tT=z(d.hep, Bp), mu=z(Bp, d.L, dt=f32), lv=z(Bp, d.L, dt=f32), z=z(Bp, d.L, dt=f32),
             zb=z(Bp, d.Lp), zbT=z(d.Lp, Bp), u=z(Bp, d.hdp), uT=z(d.hdp, Bp), dy=z(Bp, d.NYp), dyT=z(d.NY, Bp),
             log_p_x=z(Bp, d.D, dt=f32), log_p_x_missing=z(Bp, d.D, dt=f32), rowpart=z(NT, Bp, dt=f32), hgpart=z(Bp // 64, NT * 16, self._head_acc(), dt=f32),
             nll=z(Bp, dt=f32), scal=z(8, dt=torch.float64), klpart=z(max(Bp // 4, 1), dt=torch.float64),
             eps=z(Bp, d.L, dt=f32), rng=z(2, dt=torch.int64), pfull=z(Bp, d.Theta, dt=f32), xhat=z(Bp, d.D, dt=f32),
             metpart=z(16, 6, d.D, dt=f32),
-            du=z(Bp, d.hdp), duT=z(d.hdp, Bp), dz=z(Bp, d.Lp, dt=f32), dml=z(Bp, 2 * d.Lp), dmlT=z(2 * d.Lp, Bp),
+            du=z(Bp, d.hd0p), duT=z(d.hd0p, Bp), dz=z(Bp, d.Lp, dt=f32), dml=z(Bp, 2 * d.Lp), dmlT=z(2 * d.Lp, Bp),
             dt=z(Bp, d.hep), dtT=z(d.hep, Bp))
         if d.conv:          # convolutional front / back end (csrc/conv.hip)
             t.update(w1Ts=z(d.Xep, d.hep), cpack=z(_lib.CONV_PACK_ELEMS), img=z(Bp, d.D, dt=f32), yc=z(Bp, d.NYlp),
                      a2=z(Bp, 18 * 18 * 16), yv=z(Bp, d.NY, dt=f32), da2=z(Bp, 18 * 18 * 16), dyc=z(Bp, d.NYlp),
                      dycT=z(d.NYl, Bp), dfeat=z(Bp, d.Xep, dt=f32), dimg=z(Bp, d.D, dt=f32), cvpart=z(_lib.CONV_PART_ROWS, d.cv_n, dt=f32))
+        # deeper trunks: shadows, activations and pre-activation gradients of the extra hidden layers (both layouts)
+        if d.n_xe:
+            t.update(w1Ts=z(d.K1p, d.hep))
+        if d.n_xd:
+            t.update(u0=z(Bp, d.hd0p), u0T=z(d.hd0p, Bp))
+        for tag, arr, n in (("xe", d.xe, d.n_xe), ("xd", d.xd, d.n_xd)):
+            for i in range(n):
+                l = arr[i]
+                last_dec = tag == "xd" and i == n - 1                   # y_layer's input: the buffers the head kernel reads
+                t.update({f"{tag}{i}_w": z(l.n_out_p, l.n_in_p), f"{tag}{i}_wT": z(l.n_in_p, l.n_out_p),
+                          f"{tag}{i}_a": t["u"] if last_dec else z(Bp, l.n_out_p), f"{tag}{i}_aT": t["uT"] if last_dec else z(l.n_out_p, Bp),
+                          f"{tag}{i}_d": z(Bp, l.n_out_p), f"{tag}{i}_dT": z(l.n_out_p, Bp)})
         t["P"] = self._arena
         t["rng"][0] = int(torch.randint(0, 2 ** 62, (1,)).item())          # Philox seed from torch's global RNG
         ws = _lib.HlvaeWs()
         ws.Bp_max, ws.splitk_enc, ws.splitk_dec = Bp, S_e, S_d
         for name in _lib.WS_POINTERS:
             setattr(ws, name, t[name].data_ptr() if name in t else None)
+        ws.u0, ws.u0T = t.get("u0", t["u"]).data_ptr(), t.get("u0T", t["uT"]).data_ptr()
+        for tag, arr, n in (("xe", ws.xe, d.n_xe), ("xd", ws.xd, d.n_xd)):
+            for i in range(n):
+                for f in ("w", "wT", "a", "aT", "d", "dT"):
+                    setattr(arr[i], f, t[f"{tag}{i}_{f}"].data_ptr())
         # second set of the input-stage buffers (statistics + packed batch): the next batch can be normalised and packed
         # on a side stream while this one trains (ELBOTrainer.step(prefetch=...)); everything else is shared
         self._input_stage = _INPUT_STAGE + (("img",) if d.conv else ())

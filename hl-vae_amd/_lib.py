@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HLVAE_LIB_PATH", os.path.join(_HERE, "libhlvae_hip.so"))      # (override: diagnostic builds)
-ABI_VERSION = 26
+ABI_VERSION = 27
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -22,12 +22,25 @@ class HlvaeVar(C.Structure):
                                             "b2_off", "pad")]
 
 
+MAX_EXTRA = 3
+
+
+class HlvaeLayer(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_in", "n_out", "n_in_p", "n_out_p")] + [("o_w", C.c_int64), ("o_b", C.c_int64)]
+
+
+class HlvaeLayerWs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w", "wT", "a", "aT", "d", "dT")]
+
+
 class HlvaeDims(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("D", "X", "y_dim", "h_e", "h_d", "L", "n_real", "n_pos", "conv", "Theta",
                                             "Xp", "hep", "hdp", "Lp", "NY", "NYp", "n_stat", "Xe", "Xep", "NYl", "NYlp")]
                 + [(n, C.c_int64) for n in ("o_w1", "o_b1", "o_wmu", "o_bmu", "o_wlv", "o_blv", "o_wd", "o_bd",
                                             "o_wy", "o_by", "o_c1w", "o_c1b", "o_c2w", "o_c2b", "o_t1w", "o_t1b", "o_t2w", "o_t2b",
-                                            "o_cv_lo", "cv_n", "arena_size", "atomic_region", "frozen_lo", "frozen_hi")])
+                                            "o_cv_lo", "cv_n", "arena_size", "atomic_region", "frozen_lo", "frozen_hi")]
+                + [(n, C.c_int32) for n in ("n_xe", "n_xd", "h_d0", "K1", "K1p", "hd0p")]
+                + [("xe", HlvaeLayer * MAX_EXTRA), ("xd", HlvaeLayer * MAX_EXTRA), ("o_xw", C.c_int64)])
 
 
 WS_POINTERS = ("P", "G", "w1s", "wmls", "wmlTs", "wds", "wdTs", "wys", "wyTs", "sums", "norm", "xn", "xnT", "xt", "m8",
@@ -40,7 +53,8 @@ CONV_FEATURES = 32 * 9 * 9
 
 
 class HlvaeWs(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ("Bp_max", "splitk_enc", "splitk_dec")] + [(n, _vp) for n in WS_POINTERS])
+    _fields_ = ([(n, C.c_int32) for n in ("Bp_max", "splitk_enc", "splitk_dec")] + [(n, _vp) for n in WS_POINTERS]
+                + [("u0", _vp), ("u0T", _vp), ("xe", HlvaeLayerWs * MAX_EXTRA), ("xd", HlvaeLayerWs * MAX_EXTRA)])
 
 
 GP_MAX_TERMS, GP_MAX_FACTORS = 8, 4

@@ -121,6 +121,16 @@ void hlvae_dims_fill(hlvae_dims* d) {
     d->Xep = ru(d->Xe, 64);
     d->NYl = d->conv ? 32 * 9 * 9 : d->NY;            // HLVAE.py:246
     d->NYlp = ru(d->NYl, 64);
+    // deeper trunks: the fused kernels' "first encoder Linear" is the LAST one of the stack, their decoder trunk the FIRST
+    if (d->n_xe < 0 || d->n_xe > HLVAE_MAX_EXTRA) d->n_xe = 0;      // (rejected by plan_create; keep the loops below in range)
+    if (d->n_xd < 0 || d->n_xd > HLVAE_MAX_EXTRA) d->n_xd = 0;
+    for (int i = 0; i < d->n_xe; ++i) { d->xe[i].n_in_p = ru(d->xe[i].n_in, 64); d->xe[i].n_out_p = ru(d->xe[i].n_out, 64); }
+    for (int i = 0; i < d->n_xd; ++i) { d->xd[i].n_in_p = ru(d->xd[i].n_in, 64); d->xd[i].n_out_p = ru(d->xd[i].n_out, 64); }
+    d->K1 = d->n_xe > 0 ? d->xe[d->n_xe - 1].n_out : d->Xe;
+    d->K1p = ru(d->K1, 64);
+    if (d->h_d0 <= 0 || d->n_xd == 0) d->h_d0 = d->h_d;
+    d->hd0p = ru(d->h_d0, 64);
+    if (d->n_xe == 0 && d->n_xd == 0) d->o_xw = d->o_wy;
 }
 
 int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var* vars, const int32_t* var_order) {
@@ -132,6 +142,23 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     HL_REQUIRE(!d.conv || d.y_dim == 5, HLVAE_EINVAL, "plan_create: the convolutional decoder has y_dim = 5 output channels");
     HL_REQUIRE(d.Lp <= 64, HLVAE_EINVAL, "plan_create: latent_dim=%d > 64 unsupported", d.L);
     HL_REQUIRE(d.arena_size % 4 == 0, HLVAE_EINVAL, "plan_create: arena_size must be a multiple of 4 floats");
+    HL_REQUIRE(dims->n_xe >= 0 && dims->n_xe <= HLVAE_MAX_EXTRA && dims->n_xd >= 0 && dims->n_xd <= HLVAE_MAX_EXTRA, HLVAE_EINVAL,
+               "plan_create: at most %d extra hidden layers per side (got %d / %d)", HLVAE_MAX_EXTRA, dims->n_xe, dims->n_xd);
+    HL_REQUIRE(!d.conv || (d.n_xe == 0 && d.n_xd == 0), HLVAE_EINVAL, "plan_create: the convolutional model has one hidden layer per side");
+    for (int i = 0; i < d.n_xe + d.n_xd; ++i) {     // chains: X -> xe[0] -> .. -> K1 (-> h_e);  h_d0 -> xd[0] -> .. -> h_d
+        const bool enc = i < d.n_xe;
+        const int k = enc ? i : i - d.n_xe;
+        const hlvae_layer& l = enc ? d.xe[k] : d.xd[k];
+        const int want_in = k > 0 ? (enc ? d.xe[k - 1].n_out : d.xd[k - 1].n_out) : (enc ? d.Xe : d.h_d0);
+        HL_REQUIRE(l.n_in == want_in && l.n_out > 0, HLVAE_EINVAL, "plan_create: extra %s layer %d is %d -> %d, its input has %d",
+                   enc ? "encoder" : "decoder", k, l.n_in, l.n_out, want_in);
+        HL_REQUIRE(l.o_w % 4 == 0 && l.o_w >= d.o_xw && l.o_w + (int64_t)l.n_in * l.n_out <= d.o_wy && l.o_b >= 0 &&
+                       l.o_b + l.n_out <= d.atomic_region, HLVAE_EINVAL,
+                   "plan_create: extra %s layer %d: weight must lie in [o_xw, o_wy) at a multiple of 4 floats, bias in the atomic region",
+                   enc ? "encoder" : "decoder", k);
+    }
+    HL_REQUIRE(d.n_xd == 0 || d.xd[d.n_xd - 1].n_out == d.h_d, HLVAE_EINVAL, "plan_create: the last decoder layer must have h_d = %d outputs", d.h_d);
+    HL_REQUIRE(d.o_xw > d.o_w1 && d.o_xw <= d.o_wy, HLVAE_EINVAL, "plan_create: o_xw outside (o_w1, o_wy]");
     HL_REQUIRE(!d.conv || d.D == 36 * 36, HLVAE_EINVAL, "plan_create: the convolutional model needs 36 x 36 = 1296 variables "
                "(HLVAE.py:305), got %d", d.D);
     if (d.conv) {
@@ -334,15 +361,53 @@ int hlvae_feed_prefetch(const hlvae_plan* p, const hlvae_ws* ws_next, const floa
     return 0;
 }
 
+// ---- deeper trunks (dims[1] / dims[3] with several entries, HLVAE.py:125-137, 232-242): the layers around the fused middle run
+// as plain GEMM + ReLU launches with both bf16 layouts of every activation kept for the backward pass -------------------------
+static int hl_check_extra(const hlvae_dims& d, const hlvae_ws* ws) {
+    for (int i = 0; i < d.n_xe; ++i)
+        HL_REQUIRE(ws->xe[i].w && ws->xe[i].wT && ws->xe[i].a && ws->xe[i].aT && ws->xe[i].d && ws->xe[i].dT, HLVAE_EINVAL,
+                   "extra encoder layer %d: workspace buffers missing", i);
+    for (int i = 0; i < d.n_xd; ++i)
+        HL_REQUIRE(ws->xd[i].w && ws->xd[i].wT && ws->xd[i].a && ws->xd[i].aT && ws->xd[i].d && ws->xd[i].dT, HLVAE_EINVAL,
+                   "extra decoder layer %d: workspace buffers missing", i);
+    HL_REQUIRE(ws->u0 && ws->u0T, HLVAE_EINVAL, "ws->u0 / u0T missing (== u / uT for one decoder layer)");
+    HL_REQUIRE(d.n_xd == 0 || (ws->xd[d.n_xd - 1].a == ws->u && ws->xd[d.n_xd - 1].aT == ws->uT), HLVAE_EINVAL,
+               "the last decoder layer must write ws->u / ws->uT (y_layer's input)");
+    HL_REQUIRE(d.n_xe == 0 || (ws->w1Ts && ws->dt), HLVAE_EINVAL, "extra encoder layers need ws->w1Ts and ws->dt");
+    return 0;
+}
+
+// u0 -> .. -> u  (HLVAE.py:336: self.hidden(z), all but its first Linear + ReLU)
+static int hl_extra_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, int B, int Bp, hipStream_t st) {
+    const hlvae_dims& d = p->d;
+    const bf16_t* in = ws->u0;
+    for (int j = 0; j < d.n_xd; ++j) {
+        const hlvae_layer& l = d.xd[j];
+        if (int rc = hl_launch_gemm_act(0, in, l.n_in_p, ws->xd[j].w, l.n_in_p, Bp, l.n_out_p, l.n_in_p, ws->P + l.o_b, l.n_out, nullptr,
+                                        ws->xd[j].a, l.n_out_p, ws->xd[j].aT, Bp, B, nullptr, "dec_hidden_relu", st)) return rc;
+        in = ws->xd[j].a;
+    }
+    return 0;
+}
+
 int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int sample, uint64_t rng_host_offset,
                       int B, hlvae_stream s) {
     CHECK_B();
     int rc;
     HL_REQUIRE(ws->splitk_enc >= 1, HLVAE_EINVAL, "splitk_enc");
+    if ((rc = hl_check_extra(d, ws))) return rc;
+    const bf16_t* in = ws->xn;                     // input of the last encoder Linear: Xn, or the output of the layers before it
+    for (int i = 0; i < d.n_xe; ++i) {              // HLVAE.py:316-317: VAE_encoder_common_layers, all but its last Linear + ReLU
+        const hlvae_layer& l = d.xe[i];
+        if ((rc = hl_launch_gemm_act(0, in, l.n_in_p, ws->xe[i].w, l.n_in_p, Bp, l.n_out_p, l.n_in_p, ws->P + l.o_b, l.n_out, nullptr,
+                                     ws->xe[i].a, l.n_out_p, ws->xe[i].aT, Bp, B, nullptr, "enc_hidden_relu", st))) return rc;
+        in = ws->xe[i].a;
+    }
     // trunk product Xn W1^T as split-K slabs (HLVAE.py:316-317, evaluated once) ...
-    if ((rc = hl_launch_gemm_splitk(ws->xn, d.Xep, ws->w1s, d.Xep, ws->slab, d.hep, Bp, d.hep, d.Xep, ws->splitk_enc, "enc1_splitk", st))) return rc;
+    if ((rc = hl_launch_gemm_splitk(in, d.K1p, ws->w1s, d.K1p, ws->slab, d.hep, Bp, d.hep, d.K1p, ws->splitk_enc, "enc1_splitk", st))) return rc;
     // ... then bias + ReLU, mean / log-var heads, clamp, reparameterisation AND the decoder trunk in one fused kernel
-    return hl_launch_mid_fwd_fused(p, ws, eps, sample, rng_host_offset, B, Bp, st);
+    if ((rc = hl_launch_mid_fwd_fused(p, ws, eps, sample, rng_host_offset, B, Bp, st))) return rc;
+    return hl_extra_decoder_fwd(p, ws, B, Bp, st);
 }
 
 int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, float g_scale, int want_grad,
@@ -351,8 +416,10 @@ int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_lo
     int rc;
     if (trunk) {   // U = relu(z Wd^T + bd) from ws->zb (HLVAE.py:336): only when z was set by the caller (decode(z));
                    // after hlvae_encoder_fwd the trunk is already in ws->u
-        if ((rc = hl_launch_gemm_act(0, ws->zb, d.Lp, ws->wds, d.Lp, Bp, d.hdp, d.Lp, ws->P + d.o_bd, d.h_d, nullptr, ws->u,
-                                     d.hdp, ws->uT, Bp, B, nullptr, "dec1_relu", st))) return rc;
+        if ((rc = hl_check_extra(d, ws))) return rc;
+        if ((rc = hl_launch_gemm_act(0, ws->zb, d.Lp, ws->wds, d.Lp, Bp, d.hd0p, d.Lp, ws->P + d.o_bd, d.h_d0, nullptr, ws->u0,
+                                     d.hd0p, ws->u0T, Bp, B, nullptr, "dec1_relu", st))) return rc;
+        if ((rc = hl_extra_decoder_fwd(p, ws, B, Bp, st))) return rc;
     }
     if (d.conv) {   // y_layer as a plain Linear, then the two transposed convolutions (HLVAE.py:337-341)
         if ((rc = hl_launch_gemm_act(2, ws->u, d.hdp, ws->wys, d.hdp, Bp, d.NYlp, d.hdp, ws->P + d.o_by, d.NYl, nullptr, ws->yc,
@@ -484,24 +551,64 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     const bf16_t* dylT = d.conv ? ws->dycT : ws->dyT;
     HL_CHECK(hipEventRecord(p->ev[0], st));        // dY is final
     // d U slabs = dY Wy (split-K), then the fused middle: dU -> dz -> d(mu, lv) -> dT, bias gradients
-    if ((rc = hl_launch_gemm_splitk(dyl, d.NYlp, ws->wyTs, d.NYlp, ws->slab, d.hdp, Bp, d.hdp, d.NYlp, ws->splitk_dec, "dU_splitk", st))) return rc;
-    HL_CHECK(hipEventRecord(p->ev[2], st));        // the last reader of y_layer's weight shadows is done
+    if (d.n_xd == 0) {
+        if ((rc = hl_launch_gemm_splitk(dyl, d.NYlp, ws->wyTs, d.NYlp, ws->slab, d.hdp, Bp, d.hdp, d.NYlp, ws->splitk_dec, "dU_splitk", st))) return rc;
+        HL_CHECK(hipEventRecord(p->ev[2], st));        // the last reader of y_layer's weight shadows is done
+    } else {
+        // deeper decoder: layer by layer down to the first one, whose pre-activation gradient the fused middle consumes.
+        //   d_last = (dY Wy) .* (u > 0), bias gradient = its column sums
+        if ((rc = hl_check_extra(d, ws))) return rc;
+        const int jl = d.n_xd - 1;
+        if ((rc = hl_launch_gemm_act(1, dyl, d.NYlp, ws->wyTs, d.NYlp, Bp, d.hdp, d.NYlp, nullptr, d.h_d, ws->xd[jl].a, ws->xd[jl].d, d.hdp,
+                                     ws->xd[jl].dT, Bp, B, ws->G + d.xd[jl].o_b, "dU_hidden", st))) return rc;
+        HL_CHECK(hipEventRecord(p->ev[2], st));
+        for (int j = jl; j >= 0; --j) {
+            const hlvae_layer& l = d.xd[j];
+            //   d W_j = d_j^T a_(j-1)   [n_out][n_in]
+            if ((rc = hl_launch_gemm_f32(ws->xd[j].dT, Bp, j > 0 ? ws->xd[j - 1].aT : ws->u0T, Bp, ws->G + l.o_w, l.n_in, l.n_out, l.n_in, Bp,
+                                         0, 0, nullptr, "dW_dec_hidden", st))) return rc;
+            if (j > 0) {    //   d_(j-1) = (d_j W_j) .* (a_(j-1) > 0)
+                if ((rc = hl_launch_gemm_act(1, ws->xd[j].d, l.n_out_p, ws->xd[j].wT, l.n_out_p, Bp, l.n_in_p, l.n_out_p, nullptr, l.n_in,
+                                             ws->xd[j - 1].a, ws->xd[j - 1].d, l.n_in_p, ws->xd[j - 1].dT, Bp, B, ws->G + d.xd[j - 1].o_b,
+                                             "dU_hidden", st))) return rc;
+            } else {        //   the first layer's dU as ONE fp32 slab for k_mid_bwd_fused
+                if ((rc = hl_launch_gemm_splitk(ws->xd[0].d, l.n_out_p, ws->xd[0].wT, l.n_out_p, ws->slab, d.hd0p, Bp, d.hd0p, l.n_out_p, 1,
+                                                "dU0", st))) return rc;
+            }
+        }
+    }
     if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st))) return rc;
+    // d W1 below is the LAST encoder Linear's gradient; its input is Xn or the output of the layers before it
+    const bf16_t* w1_inT = d.n_xe > 0 ? ws->xe[d.n_xe - 1].aT : ws->xnT;
     // d W1 = dT^T Xn [h_e][X] (no input gradient for layer 1);  d Wd = dU^T z [h_d][L];  d [Wmu; Wlv] = dml^T T 2 x [L][h_e]
     GemmGroup g{};
     g.n = 3;
     g.K = Bp;
-    g.p[0] = GemmProb{ws->dtT, ws->xnT, ws->G + d.o_w1, nullptr, Bp, Bp, d.Xe, d.h_e, d.Xe, 0, 0};
-    g.p[1] = GemmProb{ws->duT, ws->zbT, ws->G + d.o_wd, nullptr, Bp, Bp, d.L, d.h_d, d.L, 0, 0};
+    g.p[0] = GemmProb{ws->dtT, w1_inT, ws->G + d.o_w1, nullptr, Bp, Bp, d.K1, d.h_e, d.K1, 0, 0};
+    g.p[1] = GemmProb{ws->duT, ws->zbT, ws->G + d.o_wd, nullptr, Bp, Bp, d.L, d.h_d0, d.L, 0, 0};
     g.p[2] = GemmProb{ws->dmlT, ws->tT, ws->G + d.o_wmu, ws->G + d.o_wlv, Bp, Bp, d.h_e, 2 * d.Lp, d.h_e, d.Lp, d.L};
     // few output tiles and a long batch axis (a 64-feature model at 4096 rows: 24 tiles x 64 k-steps): split-K with fp32 atomics
     // into the (cleared) gradient slices -- they are neighbours in the arena: [Wd | Wmu | Wlv | W1]
-    g.ksplit = hl_wgrad_ksplit((long)((d.h_e + 63) / 64) * ((d.Xe + 63) / 64), Bp);
-    if (g.ksplit > 1) HL_CHECK(hipMemsetAsync(ws->G + d.o_wd, 0, sizeof(float) * (size_t)(d.o_wy - d.o_wd), st));
+    g.ksplit = hl_wgrad_ksplit((long)((d.h_e + 63) / 64) * ((d.K1 + 63) / 64), Bp);
+    if (g.ksplit > 1) HL_CHECK(hipMemsetAsync(ws->G + d.o_wd, 0, sizeof(float) * (size_t)(d.o_xw - d.o_wd), st));
     if ((rc = hl_launch_gemm_f32_group(g, "dW1_dWd_dWmu", st))) return rc;
+    if (d.n_xe > 0) {   // deeper encoder: d a = (dT W1) .* (a > 0) for the layer below the last, and so on down to the inputs
+        const int il = d.n_xe - 1;
+        if ((rc = hl_launch_gemm_act(1, ws->dt, d.hep, ws->w1Ts, d.hep, Bp, d.K1p, d.hep, nullptr, d.K1, ws->xe[il].a, ws->xe[il].d, d.K1p,
+                                     ws->xe[il].dT, Bp, B, ws->G + d.xe[il].o_b, "dT_hidden", st))) return rc;
+        for (int i = il; i >= 0; --i) {
+            const hlvae_layer& l = d.xe[i];
+            if ((rc = hl_launch_gemm_f32(ws->xe[i].dT, Bp, i > 0 ? ws->xe[i - 1].aT : ws->xnT, Bp, ws->G + l.o_w, l.n_in, l.n_out, l.n_in, Bp,
+                                         0, 0, nullptr, "dW_enc_hidden", st))) return rc;
+            if (i > 0)
+                if ((rc = hl_launch_gemm_act(1, ws->xe[i].d, l.n_out_p, ws->xe[i].wT, l.n_out_p, Bp, l.n_in_p, l.n_out_p, nullptr, l.n_in,
+                                             ws->xe[i - 1].a, ws->xe[i - 1].d, l.n_in_p, ws->xe[i - 1].dT, Bp, B, ws->G + d.xe[i - 1].o_b,
+                                             "dT_hidden", st))) return rc;
+        }
+    }
     const bool conv_opt = d.conv && opt != nullptr && !skip_wy;
     if (d.conv) {   // the convolutional features receive a gradient: d feat = dT W1, then conv2 / conv1 / representation layer
-        if ((rc = hl_launch_gemm_f32(ws->dt, d.hep, ws->w1Ts, d.hep, ws->dfeat, d.Xep, Bp, d.Xe, d.hep, 0, 0, nullptr, "dfeat", st))) return rc;
+        if ((rc = hl_launch_gemm_f32(ws->dt, d.hep, ws->w1Ts, d.hep, ws->dfeat, d.Xep, Bp, d.Xe, d.hep, 0, 0, nullptr, "dfeat", st))) return rc;   // (conv: K1 = Xe)
         if (conv_opt) HL_CHECK(hipEventRecord(p->ev[1], st));      // dense gradients final, W1's transposed shadow read
         if ((rc = hl_launch_conv_enc_bwd(p, ws, B, st))) return rc;
     }
@@ -589,7 +696,7 @@ int hlvae_adam_small(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* 
 int hlvae_shadows_from_bf16(const hlvae_plan* p, const hlvae_ws* ws, const uint16_t* pb16, int64_t base, unsigned which,
                             hlvae_stream s) {
     HL_REQUIRE(p && ws && pb16, HLVAE_EINVAL, "shadows_from_bf16: null argument");
-    HL_REQUIRE(which != 0 && (which & ~0x1fu) == 0 && base % 4 == 0, HLVAE_EINVAL, "shadows_from_bf16: which=0x%x base=%ld", which,
+    HL_REQUIRE(which != 0 && (which & ~0x7ffu) == 0 && base % 4 == 0, HLVAE_EINVAL, "shadows_from_bf16: which=0x%x base=%ld", which,
                (long)base);
     return hl_shadows_from_bf16(p, ws, pb16 - base, which, which == 0x01 ? "shadows_wy" : "shadows_rest", (hipStream_t)s);
 }

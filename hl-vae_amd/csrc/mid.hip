@@ -414,8 +414,8 @@ static size_t mid_bwd_smem(int Lp, int hdp) {
 int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int sample, uint64_t rng_off, int B,
                             int Bp, hipStream_t s) {
     const hlvae_dims& d = p->d;
-    HL_REQUIRE(Bp % MID_ROWS == 0 && d.hep % 64 == 0 && d.hdp % 64 == 0, HLVAE_ESHAPE, "mid_fwd_fused shapes");
-    const size_t smem = mid_fwd_smem(d.Lp, d.hep, d.hdp);
+    HL_REQUIRE(Bp % MID_ROWS == 0 && d.hep % 64 == 0 && d.hd0p % 64 == 0, HLVAE_ESHAPE, "mid_fwd_fused shapes");
+    const size_t smem = mid_fwd_smem(d.Lp, d.hep, d.hd0p);           // (decoder side: the FIRST decoder layer, width h_d0)
     HL_REQUIRE(smem <= 150 * 1024, HLVAE_EINVAL, "hidden width too large for the fused middle kernel (%zu B of LDS)", smem);
     HL_PROF("mid_fwd_fused", s);
 #define HL_MF(LPv, MRv)                                                                                                \
@@ -429,7 +429,7 @@ int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
         k_mid_fwd_fused<LPv, MRv><<<Bp / MRv, MID_THREADS, smem, s>>>(                                                    \
             ws->slab, ws->splitk_enc, Bp, d.hep, d.h_e, ws->P + d.o_b1, ws->t, ws->tT, ws->wmls, ws->P + d.o_bmu,       \
             ws->P + d.o_blv, sample ? eps : nullptr, ws->eps, sample ? ws->rng : nullptr, rng_off, ws->mu, ws->lv,     \
-            ws->z, ws->zb, ws->zbT, d.L, ws->klpart, ws->wds, d.hdp, d.h_d, ws->P + d.o_bd, ws->u, ws->uT, B);          \
+            ws->z, ws->zb, ws->zbT, d.L, ws->klpart, ws->wds, d.hd0p, d.h_d0, ws->P + d.o_bd, ws->u0, ws->u0T, B);      \
     }
     // fewer than 128 sixteen-row workgroups (batches below 2048 rows) leave most CUs idle: eight rows per workgroup then
     // (four rows measured too: 0.1585 vs 0.1567 ms/step at 512 rows)
@@ -445,8 +445,9 @@ int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
 int hl_launch_mid_bwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_w,
                             int B, int Bp, hipStream_t s) {
     const hlvae_dims& d = p->d;
-    HL_REQUIRE(Bp % MID_ROWS == 0 && d.hep % 64 == 0 && d.hdp % 64 == 0, HLVAE_ESHAPE, "mid_bwd_fused shapes");
-    const size_t smem = mid_bwd_smem(d.Lp, d.hdp);
+    HL_REQUIRE(Bp % MID_ROWS == 0 && d.hep % 64 == 0 && d.hd0p % 64 == 0, HLVAE_ESHAPE, "mid_bwd_fused shapes");
+    const size_t smem = mid_bwd_smem(d.Lp, d.hd0p);
+    const int S = d.n_xd > 0 ? 1 : ws->splitk_dec;                    // deeper decoder: dU of the first layer arrives as one slab
     HL_REQUIRE(smem <= 150 * 1024, HLVAE_EINVAL, "hidden width too large for the fused middle kernel (%zu B of LDS)", smem);
     HL_PROF("mid_bwd_fused", s);
 #define HL_MB(LPv, MRv)                                                                                                \
@@ -458,9 +459,9 @@ int hl_launch_mid_bwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
             attr_max = smem;                                                                                           \
         }                                                                                                              \
         k_mid_bwd_fused<LPv, MRv><<<Bp / MRv, MID_THREADS, smem, s>>>(                                                    \
-            ws->slab, ws->splitk_dec, Bp, d.hdp, d.h_d, ws->u, ws->duT, ws->G + d.o_bd, ws->wdTs, ws->eps, ws->lv,     \
+            ws->slab, S, Bp, d.hd0p, d.h_d0, ws->u0, ws->duT, ws->G + d.o_bd, ws->wdTs, ws->eps, ws->lv,             \
             ws->mu, g_mu, g_lv, kl_w, d.L, ws->dmlT, ws->G + d.o_bmu, ws->G + d.o_blv, ws->wmlTs, d.hep, d.h_e, ws->t, \
-            ws->dtT, ws->G + d.o_b1, B, d.conv ? ws->dt : nullptr);                                                    \
+            ws->dtT, ws->G + d.o_b1, B, (d.conv || d.n_xe > 0) ? ws->dt : nullptr);                                                    \
     }
     const int mr = Bp / MID_ROWS < 128 ? 8 : 16;
     if (d.Lp == 32) { if (mr == 8) HL_MB(32, 8) else HL_MB(32, 16) }

@@ -25,8 +25,9 @@ struct ShadowMat {
     int tiles_c, tile0;   // tiles per row of tiles, first block index (a multiple of 8)
     int npad, remap;      // workgroups owned (tiles rounded up to a multiple of 8); XCD-contiguous tile order
 };
+constexpr int SHADOW_MAX = 5 + 2 * HLVAE_MAX_EXTRA;     // Wy, W1, Wd, Wmu, Wlv + the extra hidden layers of deeper trunks
 struct ShadowSet {
-    ShadowMat m[5];
+    ShadowMat m[SHADOW_MAX];
     int n, total_tiles;
 };
 
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
     }
     int mi = 0;
 #pragma unroll
-    for (int k = 1; k < 5; ++k)
+    for (int k = 1; k < SHADOW_MAX; ++k)
         if (k < set.n && (int)blockIdx.x >= set.m[k].tile0) mi = k;
     const ShadowMat mt = set.m[mi];
     // Neighbouring column tiles of a row band share their boundary cache lines whenever the row stride is not a multiple of
@@ -194,7 +195,16 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
     }
 }
 
-static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws, unsigned which = 0x1f) {
+// bit i of `which` selects matrix i: 0 Wy, 1 W1, 2 Wd, 3 Wmu, 4 Wlv, 5 + i extra encoder layer i, 5 + HLVAE_MAX_EXTRA + j extra decoder layer j
+static unsigned all_matrices(const hlvae_dims& d) {
+    unsigned m = 0x1f;
+    for (int i = 0; i < d.n_xe; ++i) m |= 1u << (5 + i);
+    for (int j = 0; j < d.n_xd; ++j) m |= 1u << (5 + HLVAE_MAX_EXTRA + j);
+    return m;
+}
+unsigned hl_all_matrices(const hlvae_plan* p) { return all_matrices(p->d); }
+
+static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws, unsigned which) {
     const hlvae_dims& d = p->d;
     ShadowSet s;
     auto put = [&](int i, long off, int R, int C, bf16_t* dst, int ldd, int row_off, bf16_t* dstT, int ldT, int Rc, int Cc) {
@@ -210,12 +220,20 @@ static ShadowSet make_set(const hlvae_plan* p, const hlvae_ws* ws, unsigned whic
     //  features receive a gradient, the raw inputs of the MLP path do not)
     put(0, d.o_wy, d.NYl, d.h_d, ws->wys, d.hdp, 0, ws->wyTs, d.NYlp, d.NYl, d.hdp);
     s.m[0].rowsrc = d.conv ? nullptr : p->wy_rowsrc_dev;
-    put(1, d.o_w1, d.h_e, d.Xe, ws->w1s, d.Xep, 0, d.conv ? ws->w1Ts : nullptr, d.hep, d.hep, d.Xep);
-    put(2, d.o_wd, d.h_d, d.L, ws->wds, d.Lp, 0, ws->wdTs, d.hdp, d.hdp, d.Lp);
+    // (deeper trunks: W1 is the last encoder Linear [h_e][K1], Wd the first decoder Linear [h_d0][L])
+    put(1, d.o_w1, d.h_e, d.K1, ws->w1s, d.K1p, 0, (d.conv || d.n_xe > 0) ? ws->w1Ts : nullptr, d.hep, d.hep, d.K1p);
+    put(2, d.o_wd, d.h_d0, d.L, ws->wds, d.Lp, 0, ws->wdTs, d.hd0p, d.hd0p, d.Lp);
     put(3, d.o_wmu, d.L, d.h_e, ws->wmls, d.hep, 0, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep);
     put(4, d.o_wlv, d.L, d.h_e, ws->wmls, d.hep, d.Lp, ws->wmlTs, 2 * d.Lp, d.Lp, d.hep);
+    for (int i = 0; i < HLVAE_MAX_EXTRA; ++i) {
+        if (i < d.n_xe) put(5 + i, d.xe[i].o_w, d.xe[i].n_out, d.xe[i].n_in, ws->xe[i].w, d.xe[i].n_in_p, 0, ws->xe[i].wT, d.xe[i].n_out_p,
+                            d.xe[i].n_out_p, d.xe[i].n_in_p);
+        if (i < d.n_xd) put(5 + HLVAE_MAX_EXTRA + i, d.xd[i].o_w, d.xd[i].n_out, d.xd[i].n_in, ws->xd[i].w, d.xd[i].n_in_p, 0, ws->xd[i].wT,
+                            d.xd[i].n_out_p, d.xd[i].n_out_p, d.xd[i].n_in_p);
+    }
+    which &= all_matrices(d);
     int n = 0;                                   // keep the selected matrices (bit i of `which`), compacted
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < SHADOW_MAX; ++i)
         if (which & (1u << i)) s.m[n++] = s.m[i];
     s.n = n;
     int t = 0;
@@ -244,7 +262,7 @@ static int check_set(const ShadowSet& s) {
 int hl_conv_pack_weights(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s);
 
 int hl_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s) {
-    const ShadowSet set = make_set(p, ws);
+    const ShadowSet set = make_set(p, ws, all_matrices(p->d));
     if (int rc = check_set(set)) return rc;
     {
         HL_PROF("shadow_cast", s);
@@ -292,7 +310,7 @@ int hl_adam_part(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, 
 // the whole step in ONE launch: weight tiles plus the workgroups of the small flat region (disjoint parts of the arena)
 int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
             float b2, float eps, float gscale, hipStream_t s, int skip_wy) {
-    const unsigned which = skip_wy ? 0x1e : 0x1f;
+    const unsigned which = all_matrices(p->d) & (skip_wy ? ~0x01u : ~0u);
     return hl_adam_part(p, ws, m1, m2, step_count, lr, b1, b2, eps, gscale, which, 1, (unsigned)hl_adam_grid(p, ws, which, 1),
                         skip_wy ? "adam_weights_shadows" : "adam_all_in_one", s);
 }

@@ -64,14 +64,17 @@ class ShardedAdam:
         # slices in the order their gradients become final.  MLP: y_layer's weight (the last tensor of the arena) first --
         # its reduce-scatter overlaps the rest of the backward pass; the convolutional model's y_layer gradient is final only
         # after the transposed convolutions' backward, so its (smaller) dense region is one slice
-        ranges = [(a0, end, 0x1f)] if model.conv else [(o_wy, end, 0x01), (a0, o_wy, 0x1e)]
+        rest = 0x1e | sum(1 << (5 + i) for i in range(int(d.n_xe))) | sum(1 << (5 + _lib.MAX_EXTRA + j) for j in range(int(d.n_xd)))
+        ranges = [(a0, end, 0x1f)] if model.conv else [(o_wy, end, 0x01), (a0, o_wy, rest)]
         self.plan = ShardPlan(ranges, dp.world, dp.rank)
         if self.plan.pad > GRAD_SLACK:
             raise ValueError(f"world size {dp.world}: slice padding {self.plan.pad} exceeds the gradient arena's slack")
         # The gathered bf16 copy of the first encoder Linear [h_e][X] IS its row-major shadow when X needs no column padding
         # (D4: 5184 = 81 x 64): the MFMA kernels then read it where the all-gather puts it, and only the small matrices of that
         # slice are rebuilt.  The padding rows h_e .. hep-1 fall into the (zero) slack behind the copy.
-        self._w1_alias = (not model.conv) and int(d.Xe) == int(d.Xep)
+        # (not with extra encoder layers: their backward pass also reads the TRANSPOSED shadow of that Linear, which is rebuilt
+        # together with the row-major one)
+        self._w1_alias = (not model.conv) and int(d.n_xe) == 0 and int(d.Xe) == int(d.Xep)
         slack = (int(d.hep) - int(d.h_e)) * int(d.Xep) + 64 if self._w1_alias else 0
         self.state = ShardedState(dp, self.plan, dev, slack=slack)
         if self._w1_alias:

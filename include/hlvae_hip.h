@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 26
+#define HLVAE_ABI_VERSION 27
 #define HLVAE_STAT_CHUNKS 16
 /* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
 #define HLVAE_HEAD_ACC 95
@@ -55,9 +55,19 @@ typedef struct {
     int32_t pad;
 } hlvae_var;
 
+/* one extra hidden Linear + ReLU of a deeper trunk (dims[1] / dims[3] with more than one entry, HLVAE.py:125-137, 232-242) */
+#define HLVAE_MAX_EXTRA 3
+typedef struct {
+    int32_t n_in, n_out;         /* nn.Linear(n_in, n_out): weight [n_out][n_in]                                        */
+    int32_t n_in_p, n_out_p;     /* derived: padded to multiples of 64                                                  */
+    int64_t o_w, o_b;            /* arena offsets: the weight in the dense region [o_xw, o_wy), the bias in the atomic one */
+} hlvae_layer;
+
 /* model geometry.  Padded sizes are derived by hlvae_dims_fill(). */
 typedef struct {
-    int32_t D, X, y_dim, h_e, h_d, L;          /* reference dims = [X, [h_e], L, [h_d], y_dim], D = n_variables */
+    int32_t D, X, y_dim, h_e, h_d, L;          /* reference dims = [X, [.., h_e], L, reversed [h_d0, .., h_d], y_dim], D = n_variables:
+                                                  h_e = width of the LAST encoder layer (it feeds mean_layer / log_var_layer),
+                                                  h_d = width of the LAST decoder layer (y_layer's input) */
     int32_t n_real, n_pos;
     int32_t conv;                              /* 1 = convolutional front / back end (HLVAE.py:139-152, 253-259): D must be 36 * 36 */
     int32_t Theta;                             /* columns of the likelihood-parameter matrix: X, or X + n_real + n_pos under logvar_network */
@@ -83,9 +93,25 @@ typedef struct {
     int64_t frozen_lo, frozen_hi; /* arena range inside [0, atomic_region) that the optimiser leaves alone (vy_fixed = True:
                                     _log_vy_real / _log_vy_pos without requires_grad, HLVAE.py:209-216; torch.optim.Adam skips
                                     parameters without a gradient); frozen_lo == frozen_hi: none */
+    /* deeper trunks.  The fused kernels keep their single-hidden-layer shape: "W1" (o_w1) is the LAST encoder layer, with
+     * input width K1 (X for one layer), "Wd" (o_wd) the FIRST decoder layer [h_d0][L]; the layers in between run as plain
+     * GEMM + ReLU launches.  n_xe = n_xd = 0 and h_d0 = 0 describe the reference configuration ([500] / [500]). */
+    int32_t n_xe, n_xd;          /* encoder layers before the last one, decoder layers after the first one (<= HLVAE_MAX_EXTRA) */
+    int32_t h_d0;                /* width of the first decoder layer; 0 = h_d                                            */
+    int32_t K1, K1p, hd0p;       /* derived: input width of the last encoder layer (Xe, or xe[n_xe-1].n_out); padded sizes */
+    hlvae_layer xe[HLVAE_MAX_EXTRA];   /* VAE_encoder_common_layers.{0, 2, ..}: X -> .. (all but the last Linear)         */
+    hlvae_layer xd[HLVAE_MAX_EXTRA];   /* d_layers.{2, 4, ..}: h_d0 -> .. -> h_d                                          */
+    int64_t o_xw;                /* start of the extra layers' weights in the arena (they sit between W1 and Wy); o_wy when none */
 } hlvae_dims;
 
 void hlvae_dims_fill(hlvae_dims* d);   /* fills the derived fields from D,X,y_dim,h_e,h_d,L,n_real,n_pos */
+
+/* buffers of one extra hidden layer */
+typedef struct {
+    uint16_t* w;  uint16_t* wT;      /* bf16 shadows of the weight [n_out_p][n_in_p] and its transpose [n_in_p][n_out_p]   */
+    uint16_t* a;  uint16_t* aT;      /* ReLU output [Bp][n_out_p], [n_out_p][Bp]                                           */
+    uint16_t* d;  uint16_t* dT;      /* gradient with respect to the pre-activation, same shapes                           */
+} hlvae_layer_ws;
 
 /* Workspace: every device buffer one training / inference step touches.  Allocated by the caller
  * (hl-vae_amd/HLVAE.py) for a maximum padded batch Bp_max (multiple of 128).  Padding rows/columns
@@ -136,7 +162,7 @@ typedef struct {
     uint16_t* dml; uint16_t* dmlT;   /* [Bp][2Lp], [2Lp][Bp]                                */
     uint16_t* dt; uint16_t* dtT;     /* [Bp][hep], [hep][Bp]                                */
     /* convolutional front / back end (NULL otherwise) */
-    uint16_t* w1Ts;      /* bf16 shadow [Xep][hep] of W1^T (input gradient of the first encoder Linear) */
+    uint16_t* w1Ts;      /* bf16 shadow [K1p][hep] of W1^T (input gradient of that Linear: conv, or n_xe > 0) */
     uint16_t* cpack;     /* packed bf16 convolution weights (csrc/conv.hip, CP_TOTAL elements)          */
     float* img;          /* [Bp][1296] the one-number-per-variable image the encoder convolves          */
     uint16_t* yc;        /* [Bp][NYlp] y_layer output (bf16), viewed as [32][9][9]                      */
@@ -148,6 +174,10 @@ typedef struct {
     float* dimg;         /* [Bp][1296] gradient of img                                                  */
     float* cvpart;       /* [512][cv_n] per-workgroup partial gradients of the arena range above; padding entries must be
                             zero at allocation (the kernels write every real entry each step, never the padding) */
+    /* deeper trunks (NULL for one hidden layer per side, except u0 / u0T) */
+    uint16_t* u0; uint16_t* u0T;     /* output of the FIRST decoder layer [Bp][hd0p], [hd0p][Bp]; == u, uT when n_xd == 0  */
+    hlvae_layer_ws xe[HLVAE_MAX_EXTRA];
+    hlvae_layer_ws xd[HLVAE_MAX_EXTRA];   /* xd[n_xd-1].a / .aT must be u / uT (y_layer's input)                          */
 } hlvae_ws;
 
 typedef struct hlvae_plan hlvae_plan;

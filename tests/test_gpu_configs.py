@@ -61,9 +61,11 @@ def _adam_reference(st):
     return names, [st[k] for k in names]
 
 
-@pytest.mark.parametrize("B", [1024, 4096])
-def test_d4_large_batch_against_oracle(B):
-    """BASELINE configs[2] (global batch 4096) and configs[4] (batch 1024) on the D4 layout, MLP [5184,[500],32,[500],5]."""
+@pytest.mark.parametrize("B,hid_e,hid_d", [(1024, [500], [500]), (4096, [500], [500]), (1024, [500, 260], [132, 260, 500])])
+def test_d4_large_batch_against_oracle(B, hid_e, hid_d):
+    """BASELINE configs[2] (global batch 4096) and configs[4] (batch 1024) on the D4 layout, MLP [5184,[500],32,[500],5]; and the
+    same layout with deeper trunks at model scale (two encoder layers, three decoder layers, widths that need padding:
+    HLVAE.py:113, 125-137, 232-242), every layer's gradient and the fused optimiser step included."""
     import hlvae_oracle as orc
     from hlvae_amd.HLVAE import HLVAE
     from hlvae_amd.training import ELBOTrainer
@@ -75,7 +77,7 @@ def test_d4_large_batch_against_oracle(B):
     P_batch = int(np.unique(src.labels[rows, 2]).size)
     P_total = 4 * n_subj
     scale = P_total / P_batch
-    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    dims = [src.cov_dim_ext, hid_e, 32, hid_d, 5]
     torch.manual_seed(1234 + B)
     model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=B, materialize_samples=False).to(dev)
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -97,7 +99,7 @@ def test_d4_large_batch_against_oracle(B):
     ref_loss.backward()
     elbo, elbo_ref = float(lpx.double().sum()), float(ref["log_p_x"].sum())
     rel = abs(elbo - elbo_ref) / abs(elbo_ref)
-    key = f"d4_b{B}"
+    key = f"d4_b{B}" + ("" if len(hid_e) + len(hid_d) == 2 else "_deep")
     _report(key, elbo_rel=rel, loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
             mu=max_abs_err(mu.cpu(), ref["mu"].detach()), lv=max_abs_err(lv.cpu(), ref["log_var"].detach()),
             lpx_max=max_abs_err(lpx.cpu(), ref["log_p_x"].detach()))
@@ -108,16 +110,21 @@ def test_d4_large_batch_against_oracle(B):
     e = np.abs(out[4].detach().double().cpu().numpy() - ref["log_p_x_missing"].detach().numpy())
     assert np.all(e <= 3e-2 + 2e-2 * np.abs(ref["log_p_x_missing"].detach().numpy()))
     sd = dict(model.named_parameters())
-    n_checked = 0
+    n_checked, errs, deep = 0, {}, len(hid_e) + len(hid_d) > 2
     for k, p in sd.items():
         if p.grad is None or st[k].grad is None:
             assert k == "_disp_param" or p.numel() == 0, k
             continue
         err = rel_err(p.grad.double().cpu().numpy(), st[k].grad.numpy())
         _report(key + "_grads", **{k: err})
-        assert err < GRAD_RTOL, (k, err)
+        errs[k] = err
         n_checked += 1
-    assert n_checked >= 12
+    for k, err in errs.items():
+        # the first decoder Linear [h_d0][32]: its pre-activations are the smallest of the model (32 inputs), so bf16 rounding
+        # flips the most ReLU gates there, each a whole term of the 1024-row sum (1.5e-2 with one hidden layer, 3.5e-2 below
+        # two more bf16 layers)
+        assert err < (5e-2 if deep and k == "d_layers.0.weight" else GRAD_RTOL), (k, err)
+    assert n_checked >= 12 + 2 * (len(hid_e) + len(hid_d) - 2)
     # ---- the fused training step (no autograd) from the compact feed: same weights, same noise
     model2 = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=B, materialize_samples=False)
     model2.load_state_dict(state)
@@ -356,7 +363,8 @@ def test_conv_backward_against_oracle(B):
         assert e < tol, (k, e)
 
 
-def test_sharded_optimizer_path_matches_fused_path():
+@pytest.mark.parametrize("hid_e,hid_d", [([500], [500]), ([500, 132], [260, 500])])
+def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d):
     """The data-parallel optimiser path at world size 1 (flat Adam on the whole dense region -> bf16 copy -> shadows rebuilt
     from it; hl-vae_amd/parallel.py with the collectives skipped) against the fused tile Adam of the single-process step: D4,
     512 rows, three steps with the same noise -- same arithmetic, so the parameters agree to fp32 atomics' reordering and the
@@ -367,7 +375,7 @@ def test_sharded_optimizer_path_matches_fused_path():
     from hlvae_amd.datafeed import CompactDataset
     dev = _dev()
     src = synthetic.make_d4(n_subjects=30, T=20, seed=11)
-    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    dims = [src.cov_dim_ext, hid_e, 32, hid_d, 5]
     ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
     rows = [torch.tensor(np.arange(i * 40, i * 40 + 512).astype(np.int32), device=dev) for i in range(2)]
     eps = [torch.randn(512, 32, generator=torch.Generator().manual_seed(40 + i)).to(dev) for i in range(3)]
@@ -384,7 +392,8 @@ def test_sharded_optimizer_path_matches_fused_path():
         model.state_dict()              # (data-parallel path: finishes y_layer's all-gather + shadow rebuild left running)
         torch.cuda.synchronize()
         assert int(tr.opt.step_count[0]) == 3
-        res.append((nll, model._arena.clone(), {k: model._ws_t[k].clone() for k in ("wys", "wyTs", "w1s", "wds", "wdTs", "wmls", "wmlTs")}))
+        res.append((nll, model._arena.clone(), {k: model._ws_t[k].clone() for k in model._ws_t
+                                                if k in ("wys", "wyTs", "w1s", "w1Ts", "wds", "wdTs", "wmls", "wmlTs") or k.endswith(("_w", "_wT"))}))
     (nll_a, P_a, sh_a), (nll_b, P_b, sh_b) = res
     assert rel_err(np.array(nll_b), np.array(nll_a)) < 1e-6, (nll_a, nll_b)
     assert rel_err(P_b, P_a) < 1e-6
