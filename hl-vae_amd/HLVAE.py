@@ -471,6 +471,10 @@ class HLVAE(nn.Module):
             t.update(w1Ts=z(d.Xep, d.hep), cpack=z(_lib.CONV_PACK_ELEMS), img=z(Bp, d.D, dt=f32), yc=z(Bp, d.NYlp),
                      a2=z(Bp, 18 * 18 * 16), yv=z(Bp, d.NY, dt=f32), da2=z(Bp, 18 * 18 * 16), dyc=z(Bp, d.NYlp),
                      dycT=z(d.NYl, Bp), dfeat=z(Bp, d.Xep, dt=f32), dimg=z(Bp, d.D, dt=f32), cvpart=z(_lib.CONV_PART_ROWS, d.cv_n, dt=f32))
+        # second pair of y_layer shadows: a chain of captured training steps lets the optimiser write the updated shadows
+        # beside the ones this step still reads (ELBOTrainer, include/hlvae_hip.h: wys_next)
+        if not d.conv:
+            t.update(wys_b=torch.zeros_like(t["wys"]), wyTs_b=torch.zeros_like(t["wyTs"]))
         # deeper trunks: shadows, activations and pre-activation gradients of the extra hidden layers (both layouts)
         if d.n_xe:
             t.update(w1Ts=z(d.K1p, d.hep))
@@ -507,6 +511,21 @@ class HLVAE(nn.Module):
         self._ws, self._ws_t = ws, t
         self._grad_arena = t["G"]
         self._shadow_versions = None
+
+    def _set_wy_double_buffer(self, on: bool):
+        """on: the next fused training step writes y_layer's updated shadows into the spare pair (ws->wys_next); off: in place"""
+        t = self._ws_t
+        for w in (self._ws, self._ws_alt):
+            w.wys_next = t["wys_b"].data_ptr() if on else None
+            w.wyTs_next = t["wyTs_b"].data_ptr() if on else None
+
+    def _flip_wy_shadows(self):
+        """after such a step: the spare pair holds the current shadows"""
+        t = self._ws_t
+        t["wys"], t["wys_b"] = t["wys_b"], t["wys"]
+        t["wyTs"], t["wyTs_b"] = t["wyTs_b"], t["wyTs"]
+        for w in (self._ws, self._ws_alt):
+            w.wys, w.wyTs = t["wys"].data_ptr(), t["wyTs"].data_ptr()
 
     def _swap_input_buffers(self):
         """exchange the two sets of input-stage buffers (host-side pointer swap)"""

@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HLVAE_LIB_PATH", os.path.join(_HERE, "libhlvae_hip.so"))      # (override: diagnostic builds)
-ABI_VERSION = 27
+ABI_VERSION = 28
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -54,7 +54,8 @@ CONV_FEATURES = 32 * 9 * 9
 
 class HlvaeWs(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("Bp_max", "splitk_enc", "splitk_dec")] + [(n, _vp) for n in WS_POINTERS]
-                + [("u0", _vp), ("u0T", _vp), ("xe", HlvaeLayerWs * MAX_EXTRA), ("xd", HlvaeLayerWs * MAX_EXTRA)])
+                + [("u0", _vp), ("u0T", _vp), ("xe", HlvaeLayerWs * MAX_EXTRA), ("xd", HlvaeLayerWs * MAX_EXTRA),
+                   ("wys_next", _vp), ("wyTs_next", _vp)])
 
 
 GP_MAX_TERMS, GP_MAX_FACTORS = 8, 4
@@ -100,6 +101,7 @@ _SIGS = {
                                   C.c_float, _vp]),
     "hlvae_backward_adam": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_float, C.c_int, _vp, _vp, _vp, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.c_float, _vp]),
+    "hlvae_backward_adam_fused": (C.c_int, [_vp, C.c_int]),
     "hlvae_adam_shard": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_float, _vp]),
     "hlvae_adam_small": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

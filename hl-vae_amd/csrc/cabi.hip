@@ -31,6 +31,9 @@ int hl_launch_conv_dec_fwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t)
 int hl_launch_conv_dec_bwd(const hlvae_plan*, const hlvae_ws*, int, int, hipStream_t);
 int hl_launch_conv_enc_bwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
 int hl_launch_gemm_f32_group(GemmGroup, const char*, hipStream_t);
+bool hl_gemm_adam_ok(int, int, int, bool);
+int hl_gemm_adam_grid(const AdamGemmGroup&);
+int hl_launch_gemm_adam(AdamGemmGroup, float*, float*, float*, int64_t*, float, float, float, float, float, unsigned, const char*, hipStream_t);
 int hl_wgrad_ksplit(long, int);
 int hl_launch_transpose_bf16(const bf16_t*, int, bf16_t*, int, int, int, const char*, hipStream_t);
 int hl_adam_grid(const hlvae_plan*, const hlvae_ws*, unsigned, int);
@@ -511,6 +514,17 @@ int hlvae_backward_wy(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stre
     return hl_launch_gemm_f32(ws->dyT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NY, d.h_d, Bp, 0, 0, nullptr, "dWy", st, p->wy_rowsrc_dev);
 }
 
+// does hlvae_backward_adam apply the optimiser step in the epilogue of the weight-gradient GEMMs for this model and batch?
+static bool hl_fused_optimiser(const hlvae_dims& d, int Bp) {
+    return !d.conv && d.n_xe == 0 && d.n_xd == 0 && getenv("HL_NO_FUSED_ADAM") == nullptr && hl_gemm_adam_ok(d.NYl, d.h_d, Bp, false) &&
+           hl_gemm_adam_ok(d.h_e, d.K1, Bp, false) && hl_gemm_adam_ok(d.h_d0, d.L, Bp, true) && hl_gemm_adam_ok(2 * d.Lp, d.h_e, Bp, true);
+}
+
+int hlvae_backward_adam_fused(const hlvae_plan* p, int B) {
+    if (!p || B < 1) return 0;
+    return hl_fused_optimiser(p->d, padded_batch(B)) ? 1 : 0;
+}
+
 struct HlAdamArgs {
     float *m1, *m2;
     int64_t* step_count;
@@ -578,6 +592,51 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         }
     }
     if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st))) return rc;
+    // ---- single-process training step, MLP with one hidden layer per side: optimiser step in the weight gradients' epilogue ----
+    //   caller:  dU -> fused middle -> {dW1, dWd, d[Wmu; Wlv]} + Adam + shadows (ONE launch) -> [join] -> next step
+    //   side 0:  dWy + Adam + shadows (one launch; into the second shadow pair when the caller provides one, else behind dU_splitk,
+    //            this step's last reader of y_layer's shadows) -> head-gradient fold -> Adam of the small region
+    //   side 1:  deferred ELBO scalars / metrics / next batch's input stage
+    // The three optimiser launches share one completion ticket (whichever workgroup finishes last commits the step number).
+    // Before: gradients through HBM, then two HBM-bound k_adam_tiled launches that must not overlap (71 us each together, 28 +
+    // 22 us apart), y_layer's on side 0 and the rest behind a cross-queue join: 44 us of optimiser on the critical path of a
+    // 145 us step (rocprofv3 trace of the replayed graph: profiles/r2_*_step_timeline.txt).
+    const bool fused_opt = opt != nullptr && !skip_wy && hl_fused_optimiser(d, Bp);
+    if (fused_opt) {
+        AdamGemmGroup g{};
+        g.n = 3;
+        g.K = Bp;
+        g.p[0] = AdamGemmProb{ws->dtT, ws->xnT, nullptr, ws->w1s, nullptr, (long)d.o_w1, 0, Bp, Bp, d.h_e, d.K1, 0, 0, d.K1p, 0, 0, 0, 0};
+        g.p[1] = AdamGemmProb{ws->duT, ws->zbT, nullptr, ws->wds, ws->wdTs, (long)d.o_wd, 0, Bp, Bp, d.h_d0, d.L, 0, 0, d.Lp, d.hd0p, 0, 0, 0};
+        g.p[2] = AdamGemmProb{ws->dmlT, ws->tT, nullptr, ws->wmls, ws->wmlTs, (long)d.o_wmu, (long)d.o_wlv, Bp, Bp, 2 * d.Lp, d.h_e, d.Lp,
+                              d.L, d.hep, 2 * d.Lp, 0, 0, 0};
+        bf16_t* wys_out = ws->wys_next != nullptr ? ws->wys_next : ws->wys;
+        bf16_t* wyTs_out = ws->wyTs_next != nullptr ? ws->wyTs_next : ws->wyTs;
+        HL_REQUIRE((ws->wys_next == nullptr) == (ws->wyTs_next == nullptr), HLVAE_EINVAL, "ws->wys_next / wyTs_next: both or none");
+        AdamGemmGroup gy{};
+        gy.n = 1;
+        gy.K = Bp;
+        gy.p[0] = AdamGemmProb{dylT, ws->uT, p->wy_rowsrc_dev, wys_out, wyTs_out, (long)d.o_wy, 0, Bp, Bp, d.NYl, d.h_d, 0, 0, d.hdp, d.NYlp,
+                               0, 0, 0};
+        const unsigned tickets = (unsigned)(hl_gemm_adam_grid(g) + hl_gemm_adam_grid(gy) + hl_adam_grid(p, ws, 0u, 1));
+        if ((rc = hl_launch_gemm_adam(g, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, tickets,
+                                      "dW1_dWd_dWmu_adam", st))) return rc;
+        HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
+        if (wys_out == ws->wys) HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
+        if ((rc = hl_launch_gemm_adam(gy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, tickets,
+                                      "dWy_adam", s0))) return rc;
+        if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s0))) return rc;
+        if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tickets,
+                               "adam_small", s0))) return rc;
+        HL_CHECK(hipEventRecord(p->ev[3], s0));
+        if (p->pend_flags & HL_PEND_DEFERRED) {
+            HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));   // forked at the head kernel like side 0: with the fork behind
+            // dU_splitk the graph executor put both side chains on ONE hardware queue, y_layer's launch last (0.166 vs 0.144 ms/step)
+            if ((rc = hl_flush_deferred(p, s1, true))) return rc;
+        }
+        HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
+        return hlvae_join(p, s);
+    }
     // d W1 below is the LAST encoder Linear's gradient; its input is Xn or the output of the layers before it
     const bf16_t* w1_inT = d.n_xe > 0 ? ws->xe[d.n_xe - 1].aT : ws->xnT;
     // d W1 = dT^T Xn [h_e][X] (no input gradient for layer 1);  d Wd = dU^T z [h_d][L];  d [Wmu; Wlv] = dml^T T 2 x [L][h_e]
@@ -621,6 +680,8 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0,
                                      d.conv ? nullptr : p->wy_rowsrc_dev))) return rc;
         if (opt != nullptr) {       // takes no completion ticket: the final launch below is ordered behind it by the join
+            HL_REQUIRE(ws->wys_next == nullptr, HLVAE_EINVAL, "backward_adam: ws->wys_next is honoured by the fused-optimiser step only "
+                       "(hlvae_backward_adam_fused() says when)");
             HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
             if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0x01, 0,
                                    0u, "adam_wy_early", s0))) return rc;

@@ -60,6 +60,24 @@ struct GemmGroup {
     int ksplit, kper, tiles_total;      // split-K over the whole group (launcher fills kper / tiles_total)
 };
 
+// weight-gradient products whose epilogue applies the optimiser step (dense.hip: k_gemm_adam): g = A B^T [M][N] stays in LDS.
+// Tile row gr belongs to master row rowmap[gr] (or gr) of the fp32 matrix at arena offset `off`; band > 0: rows [0, band_rows)
+// -> matrix at `off`, rows [band, band + band_rows) -> matrix at `off2`, others dropped (stacked [mu; log_var] operand).
+// The bf16 shadows take the NEW values at the tile's own row index: sh [..][ldd] row-major, shT [..][ldT] transposed (or nullptr).
+struct AdamGemmProb {
+    const bf16_t* A;
+    const bf16_t* B;
+    const int32_t* rowmap;
+    bf16_t* sh;
+    bf16_t* shT;
+    long off, off2;
+    int lda, ldb, M, N, band, band_rows, ldd, ldT, tiles_m, tiles_n, tile0;
+};
+struct AdamGemmGroup {
+    AdamGemmProb p[3];
+    int n, K, tiles_total;
+};
+
 enum { HL_PEND_METRICS = 1, HL_PEND_FINALIZE = 2, HL_PEND_RUNNING = 4, HL_PEND_FEED = 8,
        HL_PEND_DEFERRED = HL_PEND_METRICS | HL_PEND_FINALIZE | HL_PEND_FEED };
 

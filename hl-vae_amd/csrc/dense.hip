@@ -1,6 +1,7 @@
 // Dense-layer kernels of the HL-VAE step (SURVEY.md section 8(a) rows B, C, D and their backward):
 // every product is the NT main loop of gemm_nt.h with a different LDS-staged epilogue.
 #include "gemm_nt.h"
+#include "adam.h"
 
 // ------------------------------------------------------------------------------------------------
 // tile helpers: the fp32 tile sits in LDS as Cs[BM][CLD]
@@ -76,6 +77,106 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32(const bf16_t* __restric
         } else {   // rows [0,band_rows) -> C, rows [band, band+band_rows) -> C2, others dropped
             if (gr < band_rows) C[(size_t)gr * ldc + gc] = Cs[r * G::CLD + c];
             else if (gr >= band && gr < band + band_rows) C2[(size_t)(gr - band) * ldc + gc] = Cs[r * G::CLD + c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient AND optimiser step in one kernel (single-process training step):
+//     g = A B^T (tile in LDS)  ->  Adam on the master / m / v cells the tile owns  ->  both bf16 shadows of the new values.
+// As separate launches (k_gemm_f32*, k_adam_tiled) the gradient makes a round trip through HBM (8 of 36 B per parameter), the
+// optimiser is two more dependent launches on the critical path of the replayed step, and the two HBM-bound optimiser launches
+// must be kept apart.  Up to three products per launch (the ones that become computable together).  64 x 64 tiles: three
+// workgroups per CU, and every lane requests its 12 float4 of optimiser state BEFORE the product, so the streaming part is
+// in flight under the MFMA loop (round 1 applied Adam in the epilogue of the 128-row-tile gradient kernel, loads after the
+// product: 1-2 workgroups per CU could not keep enough bytes in flight, 0.190 vs 0.166 ms/step).
+// Completion tickets as in k_adam_tiled: the launches of one step may run concurrently; the last workgroup commits t.
+// ------------------------------------------------------------------------------------------------
+template <int BK>
+__global__ __launch_bounds__(HL_THREADS) void k_gemm_adam(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
+                                                          float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
+                                                          float b1, float b2, float eps, float gscale, unsigned ticket_total) {
+    using G = GemmNT<64, 64, BK, 2, 2>;
+    constexpr int CLD = G::CLD;
+    __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k)
+        if (k < g.n && (int)blockIdx.x >= g.p[k].tile0) pi = k;
+    const AdamGemmProb& q = g.p[pi];
+    // problem 0 starts at workgroup 0: its XCD-contiguous order is exact (consecutive ids share the row panel of A)
+    const int lid = pi == 0 ? xcd_remap(blockIdx.x, q.tiles_m * q.tiles_n) : (int)blockIdx.x - q.tile0;
+    const int m0 = (lid / q.tiles_n) * 64, n0 = (lid % q.tiles_n) * 64;
+    const int M = q.M, N = q.N;
+    const int c4 = (threadIdx.x & 15) * 4, rq = threadIdx.x >> 4;         // 16 float4 per tile row, 16 rows per pass
+    float4 p[4], m[4], v[4];
+    long o[4];
+    bool in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gr = m0 + rq + 16 * i;
+        long base = -1;
+        if (n0 + c4 < N) {
+            if (q.band <= 0) {
+                if (gr < M) base = q.off + (long)(q.rowmap != nullptr ? q.rowmap[gr] : gr) * N;
+            } else if (gr < q.band_rows) {
+                base = q.off + (long)gr * N;
+            } else if (gr >= q.band && gr < q.band + q.band_rows) {
+                base = q.off2 + (long)(gr - q.band) * N;
+            }
+        }
+        in[i] = base >= 0;
+        o[i] = in[i] ? base + n0 + c4 : q.off;
+        p[i] = *reinterpret_cast<const float4*>(P + o[i]);
+        m[i] = *reinterpret_cast<const float4*>(M1 + o[i]);
+        v[i] = *reinterpret_cast<const float4*>(M2 + o[i]);
+    }
+    typename G::Acc acc;
+    G::zero(acc);
+    G::run(q.A, q.lda, q.B, q.ldb, m0, n0, M, N, 0, g.K, smem, acc);
+    G::to_lds(acc, smem);
+    float* Cs = reinterpret_cast<float*>(smem);
+    const AdamScalars a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = rq + 16 * i;
+        const float4 gr4 = *reinterpret_cast<const float4*>(Cs + r * CLD + c4);
+        p[i].x = adam_one(p[i].x, gr4.x, m[i].x, v[i].x, a);
+        p[i].y = adam_one(p[i].y, gr4.y, m[i].y, v[i].y, a);
+        p[i].z = adam_one(p[i].z, gr4.z, m[i].z, v[i].z, a);
+        p[i].w = adam_one(p[i].w, gr4.w, m[i].w, v[i].w, a);
+        if (in[i]) {
+            *reinterpret_cast<float4*>(P + o[i]) = p[i];
+            *reinterpret_cast<float4*>(M1 + o[i]) = m[i];
+            *reinterpret_cast<float4*>(M2 + o[i]) = v[i];
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(p[i].x) | ((uint32_t)f2bf(p[i].y) << 16);
+            pk.y = (uint32_t)f2bf(p[i].z) | ((uint32_t)f2bf(p[i].w) << 16);
+            *reinterpret_cast<uint2*>(q.sh + (size_t)(m0 + r) * q.ldd + n0 + c4) = pk;
+        }
+        // (each lane rewrites only the four cells it has just read: no barrier needed before the write)
+        *reinterpret_cast<float4*>(Cs + r * CLD + c4) = in[i] ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (q.shT != nullptr) {                // block-uniform
+        __syncthreads();
+        // transposed shadow: lane -> (column, 4 consecutive rows), one 8-byte store (rows outside the matrix: zeros = padding)
+        const int r4 = (threadIdx.x & 15) * 4, cq = threadIdx.x >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cq + 16 * i;
+            if (m0 + r4 < M && n0 + c < N) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(Cs[(r4 + 0) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 1) * CLD + c]) << 16);
+                pk.y = (uint32_t)f2bf(Cs[(r4 + 2) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 3) * CLD + c]) << 16);
+                *reinterpret_cast<uint2*>(q.shT + (size_t)(n0 + c) * q.ldT + m0 + r4) = pk;
+            }
+        }
+    }
+    if (ticket_total != 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
+            if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
         }
     }
 }
@@ -249,6 +350,41 @@ int hl_launch_gemm_f32(const bf16_t* A, int lda, const bf16_t* B, int ldb, float
         if (K % 64 == 0) HL_GO(128, 64, 64, 2, 2) else HL_GO(128, 64, 32, 2, 2)
     }
 #undef HL_GO
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+// can a weight gradient [M][N] over K batch rows take its optimiser step in the epilogue (k_gemm_adam)?  16-byte rows, whole
+// 4-row groups for the transposed shadow, and enough tiles that the batch axis is not sliced (split-K adds with atomics)
+bool hl_gemm_adam_ok(int M, int N, int K, bool may_be_small) {
+    return N % 4 == 0 && M % 4 == 0 && K % 32 == 0 &&
+           (may_be_small || hl_wgrad_ksplit((long)((M + 63) / 64) * ((N + 63) / 64), K) == 1);
+}
+
+int hl_gemm_adam_grid(const AdamGemmGroup& g) {
+    int t = 0;
+    for (int i = 0; i < g.n; ++i) t += ((g.p[i].M + 63) / 64) * ((g.p[i].N + 63) / 64);
+    return t;
+}
+
+int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t* step_count, float lr, float b1, float b2, float eps,
+                        float gscale, unsigned ticket_total, const char* label, hipStream_t s) {
+    HL_REQUIRE(g.n >= 1 && g.n <= 3 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm_adam: n=%d K=%d", g.n, g.K);
+    int t = 0;
+    for (int i = 0; i < g.n; ++i) {
+        AdamGemmProb& q = g.p[i];
+        HL_REQUIRE(q.N % 4 == 0 && q.M % 4 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldd % 4 == 0 && q.off % 4 == 0 && q.off2 % 4 == 0 &&
+                       (q.shT == nullptr || q.ldT % 4 == 0), HLVAE_ESHAPE, "gemm_adam problem %d: M=%d N=%d lda=%d ldb=%d", i, q.M, q.N,
+                   q.lda, q.ldb);
+        q.tiles_m = (q.M + 63) / 64;
+        q.tiles_n = (q.N + 63) / 64;
+        q.tile0 = t;
+        t += q.tiles_m * q.tiles_n;
+    }
+    g.tiles_total = t;
+    HL_PROF(label, s);
+    if (g.K % 64 == 0) k_gemm_adam<64><<<t, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total);
+    else k_gemm_adam<32><<<t, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -174,6 +174,7 @@ class ELBOTrainer:
         self.opt = FusedAdam(model, lr=lr) if dp is None else ShardedAdam(model, dp, lr=lr)
         dev, L = model.device, model.z_dim
         self._graphs = {}
+        self._wy_dbuf = False        # y_layer shadows double-buffered (only inside an even chain of captured steps)
         if dp is not None and dp.world > 1:
             # every rank draws its own reparameterisation noise: the in-kernel Philox stream is indexed by the LOCAL row, so
             # the seed carries the rank (the reference's single process draws one randn_like for the whole batch, HLVAE.py:361)
@@ -314,9 +315,16 @@ class ELBOTrainer:
         if fused_opt:
             # backward and optimiser in one call: y_layer's Adam update runs under the rest of the backward pass
             o = self.opt
+            dbuf = self._wy_dbuf and not m.conv and bool(lib.hlvae_backward_adam_fused(m._plan_handle, B))
+            if dbuf:
+                m._set_wy_double_buffer(True)
+                ws = C.byref(m._ws)
             _lib.check(lib.hlvae_backward_adam(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), B, _lib.ptr(o.m1),
                                                _lib.ptr(o.m2), _lib.ptr(o.step_count), C.c_float(o.lr), C.c_float(o.betas[0]),
                                                C.c_float(o.betas[1]), C.c_float(o.eps), C.c_float(1.0), s), "backward_adam")
+            if dbuf:
+                m._set_wy_double_buffer(False)
+                m._flip_wy_shadows()
             m.mark_shadows_fresh()
         else:
             # data parallel (hlvae_amd.parallel): reduce-scatter of the dense gradient slices -> Adam on this rank's slices ->
@@ -421,11 +429,18 @@ class ELBOTrainer:
                 self.prime_rows(ds, chain[0][0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.cuda.graph(g):
-            for (r, pb), nr, gr in zip(chain, nxt, grp):
-                self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None, groups=gr)
-            if self.dp is not None:
-                self.opt.finish_pending()          # nothing may stay in flight across the end of a graph
+        # y_layer's shadows alternate between two buffer pairs inside a chain with an even number of steps (the graph ends where
+        # it began): the optimiser launch of a step need not wait for the step's last reader of the shadows.  Never in eager
+        # steps: a graph captured earlier has the buffer it starts from baked in.
+        self._wy_dbuf = len(chain) % 2 == 0
+        try:
+            with torch.cuda.graph(g):
+                for (r, pb), nr, gr in zip(chain, nxt, grp):
+                    self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None, groups=gr)
+                if self.dp is not None:
+                    self.opt.finish_pending()          # nothing may stay in flight across the end of a graph
+        finally:
+            self._wy_dbuf = False
         self._graphs[key] = g
         return g
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 27
+#define HLVAE_ABI_VERSION 28
 #define HLVAE_STAT_CHUNKS 16
 /* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
 #define HLVAE_HEAD_ACC 95
@@ -178,6 +178,10 @@ typedef struct {
     uint16_t* u0; uint16_t* u0T;     /* output of the FIRST decoder layer [Bp][hd0p], [hd0p][Bp]; == u, uT when n_xd == 0  */
     hlvae_layer_ws xe[HLVAE_MAX_EXTRA];
     hlvae_layer_ws xd[HLVAE_MAX_EXTRA];   /* xd[n_xd-1].a / .aT must be u / uT (y_layer's input)                          */
+    /* optional second pair of y_layer shadows: hlvae_backward_adam writes the UPDATED shadows there instead of in place, so
+     * that its y_layer launch need not wait for this step's last reader of wys / wyTs; the caller then passes them as wys /
+     * wyTs of the next step (and these two as that step's *_next).  NULL: in place. */
+    uint16_t* wys_next; uint16_t* wyTs_next;
 } hlvae_ws;
 
 typedef struct hlvae_plan hlvae_plan;
@@ -285,10 +289,17 @@ int hlvae_adam_step(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m
 
 /* hlvae_backward + hlvae_adam_step as ONE call (single-process training): identical result, but the Adam update of
  * y_layer's weight (the largest slice of the HBM-bound optimiser) is queued on the side stream as soon as its gradient and
- * its last reader of the step are done, so it runs under the latency-bound remainder of the backward pass. */
+ * its last reader of the step are done, so it runs under the latency-bound remainder of the backward pass.
+ * MLP model with one hidden layer per side, widths that are multiples of 4 and enough output tiles that the batch axis of the
+ * weight gradients is not sliced: the optimiser step is applied in the EPILOGUE of the weight-gradient GEMMs (csrc/dense.hip:
+ * k_gemm_adam) -- the gradients of the dense matrices never reach ws->G, and the step is three launches ({W1, Wd, Wmu, Wlv} on
+ * the caller's stream; y_layer, then the small region on a side stream) that share one completion ticket.  Same arithmetic
+ * as hlvae_backward + hlvae_adam_step (tests/test_gpu_configs.py: test_fused_optimiser_epilogue_matches_separate_launches). */
 int hlvae_backward_adam(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,
                         int B, float* m1, float* m2, int64_t* step_count, float lr, float beta1, float beta2, float eps,
                         float grad_scale, hlvae_stream s);
+/* 1 when hlvae_backward_adam takes that fused form for this plan and batch size (ws->wys_next may then be set), else 0 */
+int hlvae_backward_adam_fused(const hlvae_plan* p, int B);
 
 /* ---- sharded optimiser step (data parallel: hl-vae_amd/parallel.py; the reference has no distributed code, the semantics
  * to keep are ONE optimiser step on the sum of the ranks' gradients, training.py:121-128) ------------------------------------

@@ -582,3 +582,64 @@ def _flatten(x):
             yield from _flatten(y)
     else:
         yield x
+
+
+@pytest.mark.gpu
+def test_fused_optimiser_epilogue_matches_separate_launches():
+    """hlvae_backward_adam applies the optimiser step in the epilogue of the weight-gradient GEMMs (csrc/dense.hip: k_gemm_adam; D4,
+    512 rows).  Three ways through six identical steps must leave the same parameters, optimiser state and shadows:
+    (a) eager steps, fused epilogue, shadows updated in place;  (b) eager steps with the separate gradient + k_adam_tiled launches
+    (HL_NO_FUSED_ADAM);  (c) a captured chain of two pipelined steps replayed twice, y_layer's shadows double-buffered."""
+    import os
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    from hlvae_amd.datafeed import CompactDataset
+    from hlvae_amd import _lib
+    dev = _dev()
+    src = synthetic.make_d4(n_subjects=30, T=20, seed=11)
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    R = [torch.tensor(np.arange(i * 40, i * 40 + 512).astype(np.int32), device=dev) for i in range(2)]
+
+    def run(mode):
+        torch.manual_seed(5)
+        model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=512, materialize_samples=False).to(dev)
+        tr = ELBOTrainer(model, P_total=30, kl="normal", max_batch=512, metrics=True)
+        model._ensure_device_state(512)
+        assert _lib.load().hlvae_backward_adam_fused(model._plan_handle, 512) == (0 if mode == "separate" else 1)
+        if mode == "graph":
+            tr.capture_rows("c", ds, R, [26, 26], next_rows=[R[1], R[0]])       # (runs two warm-up steps on R[0] first)
+            tr.prime_rows(ds, R[0])
+            for _ in range(2):
+                tr.replay("c")
+        else:
+            for r in (R[0], R[0], R[0], R[1], R[0], R[1]):
+                tr.step_rows(ds, r, 26)
+        torch.cuda.synchronize()
+        assert int(tr.opt.step_count[0]) == 6 and int(tr.opt.step_count[1]) == 0
+        t = model._ws_t
+        rows = torch.as_tensor(model.kernel_wy_rows(), device=dev)
+        wy = model.y_layer[0].weight.detach()[rows].to(torch.bfloat16)
+        assert torch.equal(t["wys"][:wy.shape[0], :wy.shape[1]], wy), mode                 # shadows = bf16 of the masters,
+        assert torch.equal(t["wyTs"][:wy.shape[1], :wy.shape[0]], wy.t()), mode             # in the kernel's row order
+        w1 = model.VAE_encoder_common_layers[0].weight.detach().to(torch.bfloat16)
+        assert torch.equal(t["w1s"][:w1.shape[0], :w1.shape[1]], w1), mode
+        wm = model.mean_layer[0].weight.detach().to(torch.bfloat16)
+        assert torch.equal(t["wmls"][:wm.shape[0], :wm.shape[1]], wm) and torch.equal(t["wmlTs"][:wm.shape[1], :wm.shape[0]], wm.t()), mode
+        out = (model._arena.clone(), tr.opt.m1.clone(), tr.opt.m2.clone(), float(tr.scalars()["nll_sum"]))
+        model._release_device_state()
+        return out
+
+    a = run("fused")
+    os.environ["HL_NO_FUSED_ADAM"] = "1"
+    try:
+        b = run("separate")
+    finally:
+        del os.environ["HL_NO_FUSED_ADAM"]
+    c = run("graph")
+    for name, other in (("separate launches", b), ("captured chain", c)):
+        assert abs(a[3] - other[3]) <= 1e-6 * abs(a[3]), name
+        # same arithmetic per element; the first moments follow the gradients linearly and so carry the fp32 reordering of the
+        # head gradients' atomics and of the two GEMM tile shapes (measured 9e-6), the parameters move by ~lr per step either way
+        for x, y, what, tol in zip(a[:3], other[:3], ("parameters", "m", "v"), (1e-6, 5e-5, 5e-5)):
+            assert rel_err(x, y) < tol, (name, what, rel_err(x, y))
