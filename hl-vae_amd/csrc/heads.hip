@@ -484,11 +484,23 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     constexpr int POST_BYTES = BM * CLD * 4 + NACC * RST * 4;
     constexpr int SMEM_TOTAL = Gm::SMEM_BYTES + SCR_BYTES > POST_BYTES ? Gm::SMEM_BYTES + SCR_BYTES : POST_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SMEM_TOTAL];
-    // 1-D grid, XCD-aware: the tiles_m row-blocks that share one 16-variable panel of Wy get consecutive
-    // logical ids and therefore one XCD's L2
+    // 1-D grid, XCD-aware.  Up to 8 row blocks (512 rows): the row blocks that share one 16-variable panel of Wy get
+    // consecutive logical ids and therefore one XCD's L2; U (<= 0.5 MB) stays in every L2.  Larger batches: U no longer fits
+    // beside the streams of a 4 MB L2 and was re-read for every panel an XCD owns (PMC at 4096 rows: 630 MB fetched + written
+    // for 207 MB of algorithmic traffic, the kernel ran AT the HBM rate).  There every XCD owns tiles_m / 8 row blocks -- its
+    // slice of U stays resident -- and walks all the panels, the row blocks of one panel side by side: Wy streams once per XCD.
     const int tiles_m = Bp / BM;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = lid / tiles_m, m0 = (lid % tiles_m) * BM, n0 = tn * BN;
+    int tn, m0;
+    if (tiles_m >= 16 && (tiles_m & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, rbx = tiles_m >> 3;       // hardware XCD, index inside it
+        tn = j / rbx;
+        m0 = (xcd * rbx + j % rbx) * BM;
+    } else {
+        const int lid = xcd_remap(blockIdx.x, gridDim.x);
+        tn = lid / tiles_m;
+        m0 = (lid % tiles_m) * BM;
+    }
+    const int n0 = tn * BN;
     const int NY = D * YD;
     float* Cs = reinterpret_cast<float*>(smem);
     const bool conv = ysrc != nullptr;
