@@ -16,7 +16,7 @@ int hl_launch_y_heads(const hlvae_plan*, const hlvae_ws*, const float*, float, i
 int hl_launch_elbo_finalize(const hlvae_plan*, const hlvae_ws*, int, int, hipStream_t);
 int hl_launch_head_grad_reduce(const hlvae_plan*, const hlvae_ws*, int, hipStream_t);
 int hl_launch_scale_dy(const hlvae_plan*, const hlvae_ws*, const float*, int, int, hipStream_t);
-int hl_launch_step_metrics(const hlvae_plan*, const hlvae_ws*, int, float*, hipStream_t);
+int hl_launch_step_metrics(const hlvae_plan*, const hlvae_ws*, int, float*, hipStream_t, const hlvae_ws* fin_ws = nullptr, int fin_B = 0);
 int hl_launch_stats(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, hipStream_t);
 int hl_launch_pack(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, int, hipStream_t);
 int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
@@ -471,12 +471,14 @@ int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* er
 static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered) {
     if (!(p->pend_flags & HL_PEND_DEFERRED)) return 0;
     if (!side_is_ordered) HL_CHECK(hipStreamWaitEvent(side, p->ev[5], 0));
-    if (p->pend_flags & HL_PEND_FINALIZE) {
+    const bool both = (p->pend_flags & HL_PEND_FINALIZE) && (p->pend_flags & HL_PEND_METRICS);
+    if ((p->pend_flags & HL_PEND_FINALIZE) && !both) {
         const int B = p->pend_fin_B;
         if (int rc = hl_launch_elbo_finalize(p, &p->pend_fin_ws, B, (B + 127) / 128 * 128, side)) return rc;
     }
-    if (p->pend_flags & HL_PEND_METRICS)
-        if (int rc = hl_launch_step_metrics(p, &p->pend_ws, p->pend_B, p->pend_err, side)) return rc;
+    if (p->pend_flags & HL_PEND_METRICS)       // (both pending: the ELBO bookkeeping rides in the metrics launch -- one link less)
+        if (int rc = hl_launch_step_metrics(p, &p->pend_ws, p->pend_B, p->pend_err, side, both ? &p->pend_fin_ws : nullptr, p->pend_fin_B))
+            return rc;
     if (p->pend_flags & HL_PEND_FEED) {       // input stage of the NEXT batch into the other buffer set (data only, no weights)
         const int B = p->pend_feed_B;
         if (p->d.n_stat > 0)

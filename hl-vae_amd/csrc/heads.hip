@@ -766,13 +766,23 @@ int hl_launch_head_grad_reduce(const hlvae_plan* p, const hlvae_ws* ws, int Bp, 
 //   scal[0] = sum_b nll[b]                                     (training.py:104)
 //   scal[1] = sum of the per-block KL(q || N(0,I)) partials    (extension)
 //   rng[1] += 1: advances the Philox offset of the reparameterisation noise for the next step
-__global__ __launch_bounds__(1024) void k_elbo_finalize(const float* __restrict__ rowpart, int NT, int Bp, int B,
-                                                        float* __restrict__ nll, double* __restrict__ scal,
-                                                        const double* __restrict__ klpart, int nkl,
-                                                        uint64_t* __restrict__ rng) {
+struct ElboFinArgs {
+    const float* rowpart;
+    float* nll;
+    double* scal;
+    const double* klpart;
+    uint64_t* rng;
+    int NT, Bp, B, nkl;
+};
+
+// one workgroup of `nthr` threads (a multiple of 64, <= 1024)
+__device__ __forceinline__ void elbo_finalize_body(const ElboFinArgs& f, int tid, int nthr) {
     __shared__ double red[16];
+    __shared__ double redk[16];
+    const float* __restrict__ rowpart = f.rowpart;
+    const int NT = f.NT, Bp = f.Bp, B = f.B;
     double tot = 0.0;
-    for (int b = threadIdx.x; b < Bp; b += blockDim.x) {
+    for (int b = tid; b < Bp; b += nthr) {
         float s = 0.f;
         if (b < B) {                                    // 27 loads in flight per lane (one workgroup: pure latency; 9 took 8 us)
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -787,26 +797,27 @@ __global__ __launch_bounds__(1024) void k_elbo_finalize(const float* __restrict_
             for (; t < NT; ++t) s0 += rowpart[(size_t)t * Bp + b];
             s = (s0 + s1) + s2;
         }
-        nll[b] = -s;
+        f.nll[b] = -s;
         tot += (double)(-s);
     }
     // the KL partials (one per 4 rows) in parallel too: a serial loop of one thread over them is a chain of global loads
     double kl = 0.0;
-    if (klpart != nullptr)
-        for (int i = threadIdx.x; i < nkl; i += blockDim.x) kl += klpart[i];
+    if (f.klpart != nullptr)
+        for (int i = tid; i < f.nkl; i += nthr) kl += f.klpart[i];
     tot = wave_sum_d(tot);
     kl = wave_sum_d(kl);
-    __shared__ double redk[16];
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = tot; redk[threadIdx.x >> 6] = kl; }
+    if ((tid & 63) == 0) { red[tid >> 6] = tot; redk[tid >> 6] = kl; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         double t = 0.0, k = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { t += red[w]; k += redk[w]; }
-        scal[0] = t;
-        scal[1] = k;
-        if (rng != nullptr) rng[1] += 1;
+        for (int w = 0; w < (nthr >> 6); ++w) { t += red[w]; k += redk[w]; }
+        f.scal[0] = t;
+        f.scal[1] = k;
+        if (f.rng != nullptr) f.rng[1] += 1;
     }
 }
+
+__global__ __launch_bounds__(1024) void k_elbo_finalize(ElboFinArgs f) { elbo_finalize_body(f, threadIdx.x, blockDim.x); }
 
 // Row M: per-variable reconstruction errors of the imputed values (reference read_functions.py:342-412 with
 // true_miss_mask = 1, conv False): categorical 0/1 mismatch, ordinal |x - x_hat| / K, continuous (x_hat - x)^2 / range^2
@@ -817,7 +828,15 @@ __global__ __launch_bounds__(1024) void k_elbo_finalize(const float* __restrict_
 #define HL_MET_CHUNKS 16
 __global__ __launch_bounds__(1024) void k_metrics_partial(const float* __restrict__ xt, const uint8_t* __restrict__ m8,
                                                          const float* __restrict__ xhat, const hlvae_var* __restrict__ vars,
-                                                         int B, int D, float* __restrict__ part, int conv) {
+                                                         int B, int D, float* __restrict__ part, int conv, ElboFinArgs fin,
+                                                         int with_fin) {
+    // with_fin: the grid has one more column of workgroups; its first one does the ELBO bookkeeping of the step (k_elbo_finalize's
+    // work: both are deferred side work of a training step, and as launches of their own each is a dependent ~7-10 us link of the
+    // side chain that the end of the step waits for)
+    if (with_fin && blockIdx.x == gridDim.x - 1) {
+        if (blockIdx.y == 0) elbo_finalize_body(fin, threadIdx.y * 64 + threadIdx.x, blockDim.x * blockDim.y);
+        return;
+    }
     // conv (types_info['conv'], read_functions.py:366-369): continuous data are divided by 255 (x_hat too for pos / count)
     // and the range normalisation is dropped
     __shared__ float red[6][16][64];                            // blockDim = (64 variables, RL row lanes), RL = 4 or 16
@@ -909,14 +928,21 @@ __global__ void k_metrics_finish(const float* __restrict__ part, const hlvae_var
     err[2 * D + d] = ea;
 }
 
-int hl_launch_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* err, hipStream_t s) {
+static ElboFinArgs fin_args(const hlvae_plan* p, const hlvae_ws* ws, int B, int Bp) {
+    return ElboFinArgs{ws->rowpart, ws->nll, ws->scal, ws->klpart, ws->rng, (p->d.D + 15) / 16, Bp, B, Bp / 4};   // one KL partial per 4 rows (k_mid_fwd_fused)
+}
+
+// fin_ws != nullptr: the ELBO bookkeeping of that workspace's step rides in the first launch
+int hl_launch_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* err, hipStream_t s, const hlvae_ws* fin_ws, int fin_B) {
     const hlvae_dims& d = p->d;
     HL_REQUIRE(ws->xhat != nullptr && err != nullptr && ws->metpart != nullptr, HLVAE_EINVAL,
                "step_metrics: needs ws->xhat (decoder_fwd with want_params), ws->metpart and err");
     {
         HL_PROF("metrics_partial", s);
-        k_metrics_partial<<<dim3((d.D + 63) / 64, HL_MET_CHUNKS), dim3(64, B >= 2048 ? 16 : 4), 0, s>>>(ws->xt, ws->m8, ws->xhat, p->vars_dev, B,
-                                                                                      d.D, ws->metpart, d.conv);
+        const int with_fin = fin_ws != nullptr;
+        const ElboFinArgs fa = with_fin ? fin_args(p, fin_ws, fin_B, (fin_B + 127) / 128 * 128) : ElboFinArgs{};
+        k_metrics_partial<<<dim3((d.D + 63) / 64 + with_fin, HL_MET_CHUNKS), dim3(64, B >= 2048 ? 16 : 4), 0, s>>>(
+            ws->xt, ws->m8, ws->xhat, p->vars_dev, B, d.D, ws->metpart, d.conv, fa, with_fin);
     }
     HL_LAUNCH_CHECK();
     HL_PROF("metrics_finish", s);
@@ -1002,7 +1028,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
 int hl_launch_elbo_finalize(const hlvae_plan* p, const hlvae_ws* ws, int B, int Bp, hipStream_t s) {
     const int NT = (p->d.D + 15) / 16;
     HL_PROF("elbo_finalize", s);
-    k_elbo_finalize<<<1, 1024, 0, s>>>(ws->rowpart, NT, Bp, B, ws->nll, ws->scal, ws->klpart, Bp / 4, ws->rng);        // one partial per 4 rows (k_mid_fwd_fused)
+    k_elbo_finalize<<<1, 1024, 0, s>>>(fin_args(p, ws, B, Bp));
     HL_LAUNCH_CHECK();
     return 0;
 }
