@@ -899,19 +899,24 @@ __global__ __launch_bounds__(256) void k_gp_rsym(const double* __restrict__ u, c
 }
 
 // out[l][m] = sum_b A[l][b][m] x[l][b]: the two matrix^T-vector products of the bound (Kxz^T v, V^T mu).  As batched GEMMs with
-// one column the library reads the 15.7 MB operand at 0.5 TB/s (32 us each); here one workgroup per latent streams its slab:
-// thread = (column m, one of 1024 / 128 row groups), partials folded through LDS -- no atomics, nothing to zero.
+// one column the library reads the 15.7 MB operand at 0.5 TB/s (32 us each).  One workgroup per (latent, row chunk) streams its
+// part of the slab: thread = (column m, one of 1024 / 128 row groups), partials folded through LDS.  With ONE workgroup per
+// latent (round 1) 32 CUs pulled the whole operand: 65 us for 31 MB at 1024 rows, on the longest chain of the GP step.  Several
+// chunks per latent add their rows with fp64 atomics into an output the launcher has cleared.  (A last-chunk-reduces ticket
+// needs a device-scope fence per workgroup: the L2 write-backs made the kernel 226 us and slowed everything beside it.)
+#define GP_GEMV_CHUNKS_MAX 16
 template <typename XT>
 __global__ __launch_bounds__(1024) void k_gp_gemv_t(const double* __restrict__ A, const XT* __restrict__ x, long xs_l, long xs_b,
                                                     double* __restrict__ out, int Bn, int M) {
     __shared__ double red[8][GP_MMAX];
-    const int l = blockIdx.x, m = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const int l = blockIdx.x, nc = gridDim.y, c = blockIdx.y, m = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const int per = ((Bn + nc - 1) / nc + 7) & ~7, b_lo = c * per, b_hi = min(Bn, b_lo + per);
     const double* Al = A + (size_t)l * Bn * M;
     const XT* xl = x + (size_t)l * xs_l;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     if (m < M) {
-        int b = g;
-        for (; b + 8 * 15 < Bn; b += 8 * 16) {                       // 16 loads of the slab in flight per lane (32 KB per wave)
+        int b = b_lo + g;
+        for (; b + 8 * 15 < b_hi; b += 8 * 16) {                     // 16 loads of the slab in flight per lane (32 KB per wave)
             double t[16], xv[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(1024) void k_gp_gemv_t(const double* __restrict__ A
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k & 3] += t[k] * xv[k];
         }
-        for (; b < Bn; b += 8) acc[0] += Al[(size_t)b * M + m] * (double)xl[(size_t)b * xs_b];
+        for (; b < b_hi; b += 8) acc[0] += Al[(size_t)b * M + m] * (double)xl[(size_t)b * xs_b];
     }
     red[g][m] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
@@ -929,8 +934,16 @@ __global__ __launch_bounds__(1024) void k_gp_gemv_t(const double* __restrict__ A
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += red[k][m];
-        out[(size_t)l * M + m] = s;
+        if (nc == 1) out[(size_t)l * M + m] = s;
+        else atomicAdd(out + (size_t)l * M + m, s);
     }
+}
+
+static int gemv_chunks(int L, int B) {      // about one workgroup per CU, at least 128 rows each
+    int c = 256 / (L > 0 ? L : 1);
+    if (c > GP_GEMV_CHUNKS_MAX) c = GP_GEMV_CHUNKS_MAX;
+    while (c > 1 && B / c < 128) --c;
+    return c < 1 ? 1 : c;
 }
 
 // G[l][b][m] = c (v[l][b] w[l][m] - Y[l][b][m]): the gradient w.r.t. K0xz from its two pieces in one pass (as baddbmm: a
@@ -1130,8 +1143,10 @@ int hlvae_gp_bmm(const double* A, const double* B, const double* D, double* C, i
 int hlvae_gp_gemv_t(const double* A, const double* x, long x_stride_l, long x_stride_b, double* out, int L, int B, int M,
                     hlvae_stream s) {
     HL_REQUIRE(A && x && out && L >= 1 && B >= 1 && M >= 1 && M <= GP_MMAX, HLVAE_EINVAL, "gp_gemv_t: L=%d B=%d M=%d", L, B, M);
+    const int nc = gemv_chunks(L, B);
+    if (nc > 1) HL_CHECK(hipMemsetAsync(out, 0, sizeof(double) * (size_t)L * M, (hipStream_t)s));
     HL_PROF("gp_gemv_t", (hipStream_t)s);
-    k_gp_gemv_t<double><<<L, 1024, 0, (hipStream_t)s>>>(A, x, x_stride_l, x_stride_b, out, B, M);
+    k_gp_gemv_t<double><<<dim3(L, nc), 1024, 0, (hipStream_t)s>>>(A, x, x_stride_l, x_stride_b, out, B, M);
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -1226,8 +1241,10 @@ int hlvae_gp_resid(const double* Kxz, const double* w, const float* mu, int L, i
 int hlvae_gp_gemv_t_f32(const double* A, const float* x, long x_stride_l, long x_stride_b, double* out, int L, int B, int M,
                         hlvae_stream s) {
     HL_REQUIRE(A && x && out && L >= 1 && B >= 1 && M >= 1 && M <= GP_MMAX, HLVAE_EINVAL, "gp_gemv_t_f32: L=%d B=%d M=%d", L, B, M);
+    const int nc = gemv_chunks(L, B);
+    if (nc > 1) HL_CHECK(hipMemsetAsync(out, 0, sizeof(double) * (size_t)L * M, (hipStream_t)s));
     HL_PROF("gp_gemv_t", (hipStream_t)s);
-    k_gp_gemv_t<float><<<L, 1024, 0, (hipStream_t)s>>>(A, x, x_stride_l, x_stride_b, out, B, M);
+    k_gp_gemv_t<float><<<dim3(L, nc), 1024, 0, (hipStream_t)s>>>(A, x, x_stride_l, x_stride_b, out, B, M);
     HL_LAUNCH_CHECK();
     return 0;
 }
