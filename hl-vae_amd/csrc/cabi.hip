@@ -20,8 +20,11 @@ int hl_launch_step_metrics(const hlvae_plan*, const hlvae_ws*, int, float*, hipS
 int hl_launch_stats(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, hipStream_t);
 int hl_launch_pack(const hlvae_plan*, const hlvae_ws*, const double*, const double*, int, int, hipStream_t);
 int hl_refresh_shadows(const hlvae_plan*, const hlvae_ws*, hipStream_t);
-int hl_launch_mid_fwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, int, uint64_t, int, int, hipStream_t);
-int hl_launch_mid_bwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, const float*, float, int, int, hipStream_t);
+int hl_launch_mid_fwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, int, uint64_t, int, int, hipStream_t, const bf16_t* xin = nullptr);
+bool hl_mid_direct_fwd(const hlvae_dims&);
+bool hl_mid_direct_bwd(const hlvae_dims&);
+int hl_launch_mid_bwd_fused(const hlvae_plan*, const hlvae_ws*, const float*, const float*, float, int, int, hipStream_t, const bf16_t* dyin = nullptr,
+                            float* zero_ptr = nullptr, long zero_n = 0);
 int hl_adam(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, hipStream_t, int);
 int hl_launch_conv_enc_fwd(const hlvae_plan*, const hlvae_ws*, const double*, const double*, const float*, const uint8_t*,
                            const int32_t*, int, int, hipStream_t);
@@ -406,6 +409,10 @@ int hlvae_encoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* eps,
                                      ws->xe[i].a, l.n_out_p, ws->xe[i].aT, Bp, B, nullptr, "enc_hidden_relu", st))) return rc;
         in = ws->xe[i].a;
     }
+    if (hl_mid_direct_fwd(d)) {     // narrow input: the fused middle computes Xn W1^T itself
+        if ((rc = hl_launch_mid_fwd_fused(p, ws, eps, sample, rng_host_offset, B, Bp, st, in))) return rc;
+        return hl_extra_decoder_fwd(p, ws, B, Bp, st);
+    }
     // trunk product Xn W1^T as split-K slabs (HLVAE.py:316-317, evaluated once) ...
     if ((rc = hl_launch_gemm_splitk(in, d.K1p, ws->w1s, d.K1p, ws->slab, d.hep, Bp, d.hep, d.K1p, ws->splitk_enc, "enc1_splitk", st))) return rc;
     // ... then bias + ReLU, mean / log-var heads, clamp, reparameterisation AND the decoder trunk in one fused kernel
@@ -448,7 +455,7 @@ int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx
     return hl_launch_scale_dy(p, ws, g_logpx, B, Bp, st);
 }
 
-static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered);
+static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered, int mask = HL_PEND_DEFERRED, bool second = false);
 
 int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* err, hlvae_stream s) {
     CHECK_B();
@@ -468,36 +475,39 @@ int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* er
 
 // queues the deferred launches on `side`.  side_is_ordered: the caller has just made `side` wait for a LATER point of
 // its stream than ev[5] (one fork point for all the side work of the backward pass)
-static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered) {
-    if (!(p->pend_flags & HL_PEND_DEFERRED)) return 0;
+// mask: which of the pending pieces to queue now (the others stay pending).  second: this chain's end is ev[1] / HL_PEND_RUNNING2
+// instead of ev[5] / HL_PEND_RUNNING -- two chains on two side streams (ELBO scalars + metrics on one, the next batch's input
+// stage on the other) that hlvae_join waits for separately.
+static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered, int mask, bool second) {
+    const int todo = p->pend_flags & mask & HL_PEND_DEFERRED;
+    if (!todo) return 0;
     if (!side_is_ordered) HL_CHECK(hipStreamWaitEvent(side, p->ev[5], 0));
-    const bool both = (p->pend_flags & HL_PEND_FINALIZE) && (p->pend_flags & HL_PEND_METRICS);
-    if ((p->pend_flags & HL_PEND_FINALIZE) && !both) {
+    const bool both = (todo & HL_PEND_FINALIZE) && (todo & HL_PEND_METRICS);
+    if ((todo & HL_PEND_FINALIZE) && !both) {
         const int B = p->pend_fin_B;
         if (int rc = hl_launch_elbo_finalize(p, &p->pend_fin_ws, B, (B + 127) / 128 * 128, side)) return rc;
     }
-    if (p->pend_flags & HL_PEND_METRICS)       // (both pending: the ELBO bookkeeping rides in the metrics launch -- one link less)
+    if (todo & HL_PEND_METRICS)       // (both pending: the ELBO bookkeeping rides in the metrics launch -- one link less)
         if (int rc = hl_launch_step_metrics(p, &p->pend_ws, p->pend_B, p->pend_err, side, both ? &p->pend_fin_ws : nullptr, p->pend_fin_B))
             return rc;
-    if (p->pend_flags & HL_PEND_FEED) {       // input stage of the NEXT batch into the other buffer set (data only, no weights)
+    if (todo & HL_PEND_FEED) {       // input stage of the NEXT batch into the other buffer set (data only, no weights)
         const int B = p->pend_feed_B;
         if (p->d.n_stat > 0)
             if (int rc = hl_launch_stats_compact(p, &p->pend_feed_ws, p->pend_feed_vals, p->pend_feed_mask, p->pend_feed_rows, B, side)) return rc;
         if (int rc = hl_launch_pack_compact(p, &p->pend_feed_ws, p->pend_feed_vals, p->pend_feed_mask, p->pend_feed_rows, B,
                                             (B + 127) / 128 * 128, side)) return rc;
     }
-    HL_CHECK(hipEventRecord(p->ev[5], side));
-    p->pend_flags = HL_PEND_RUNNING;
+    HL_CHECK(hipEventRecord(p->ev[second ? 1 : 5], side));
+    p->pend_flags = (p->pend_flags & ~todo) | (second ? HL_PEND_RUNNING2 : HL_PEND_RUNNING);
     return 0;
 }
 
 int hlvae_join(const hlvae_plan* p, hlvae_stream s) {
     HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
     if (int rc = hl_flush_deferred(p, g_prof_on ? (hipStream_t)s : p->side[1], false)) return rc;
-    if (p->pend_flags & HL_PEND_RUNNING) {
-        HL_CHECK(hipStreamWaitEvent((hipStream_t)s, p->ev[5], 0));
-        p->pend_flags = 0;
-    }
+    if (p->pend_flags & HL_PEND_RUNNING) HL_CHECK(hipStreamWaitEvent((hipStream_t)s, p->ev[5], 0));
+    if (p->pend_flags & HL_PEND_RUNNING2) HL_CHECK(hipStreamWaitEvent((hipStream_t)s, p->ev[1], 0));
+    p->pend_flags &= ~(HL_PEND_RUNNING | HL_PEND_RUNNING2);
     return 0;
 }
 
@@ -566,8 +576,31 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     const bf16_t* dyl = d.conv ? ws->dyc : ws->dy;          // gradient of y_layer's output, both layouts
     const bf16_t* dylT = d.conv ? ws->dycT : ws->dyT;
     HL_CHECK(hipEventRecord(p->ev[0], st));        // dY is final
+    const bool fused_opt = opt != nullptr && !skip_wy && hl_fused_optimiser(d, Bp);
+    AdamGemmGroup g_rest{}, g_wy{};
+    unsigned tickets = 0;
+    if (fused_opt) {
+        g_rest.n = 3;
+        g_rest.K = Bp;
+        g_rest.p[0] = AdamGemmProb{ws->dtT, ws->xnT, nullptr, ws->w1s, nullptr, (long)d.o_w1, 0, Bp, Bp, d.h_e, d.K1, 0, 0, d.K1p, 0, 0, 0, 0};
+        g_rest.p[1] = AdamGemmProb{ws->duT, ws->zbT, nullptr, ws->wds, ws->wdTs, (long)d.o_wd, 0, Bp, Bp, d.h_d0, d.L, 0, 0, d.Lp, d.hd0p, 0, 0, 0};
+        g_rest.p[2] = AdamGemmProb{ws->dmlT, ws->tT, nullptr, ws->wmls, ws->wmlTs, (long)d.o_wmu, (long)d.o_wlv, Bp, Bp, 2 * d.Lp, d.h_e, d.Lp,
+                                   d.L, d.hep, 2 * d.Lp, 0, 0, 0};
+        HL_REQUIRE((ws->wys_next == nullptr) == (ws->wyTs_next == nullptr), HLVAE_EINVAL, "ws->wys_next / wyTs_next: both or none");
+        bf16_t* wys_out = ws->wys_next != nullptr ? ws->wys_next : ws->wys;
+        bf16_t* wyTs_out = ws->wyTs_next != nullptr ? ws->wyTs_next : ws->wyTs;
+        g_wy.n = 1;
+        g_wy.K = Bp;
+        g_wy.p[0] = AdamGemmProb{dylT, ws->uT, p->wy_rowsrc_dev, wys_out, wyTs_out, (long)d.o_wy, 0, Bp, Bp, d.NYl, d.h_d, 0, 0, d.hdp,
+                                 d.NYlp, 0, 0, 0};
+        tickets = (unsigned)(hl_gemm_adam_grid(g_rest) + hl_gemm_adam_grid(g_wy) + hl_adam_grid(p, ws, 0u, 1));
+        // (y_layer's launch created BEFORE dU_splitk -- the head kernel's first child starts at once, the caller's chain pays the
+        // cross-queue start instead: dU_splitk 21 us late and 25 us long beside it, 0.142 vs 0.137 ms/step)
+    }
     // d U slabs = dY Wy (split-K), then the fused middle: dU -> dz -> d(mu, lv) -> dT, bias gradients
-    if (d.n_xd == 0) {
+    const bool direct_bwd = hl_mid_direct_bwd(d);      // narrow y_layer: the fused middle computes dY Wy itself (and is then the last
+    if (direct_bwd) {                                  // reader of y_layer's shadows)
+    } else if (d.n_xd == 0) {
         if ((rc = hl_launch_gemm_splitk(dyl, d.NYlp, ws->wyTs, d.NYlp, ws->slab, d.hdp, Bp, d.hdp, d.NYlp, ws->splitk_dec, "dU_splitk", st))) return rc;
         HL_CHECK(hipEventRecord(p->ev[2], st));        // the last reader of y_layer's weight shadows is done
     } else {
@@ -593,7 +626,20 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
             }
         }
     }
-    if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st))) return rc;
+    // split-K slices of the grouped weight-gradient launch add with atomics into [Wd | Wmu | Wlv | W1]'s gradients: cleared by the
+    // fused middle (no memset node on the critical path)
+    const bool fused_opt_ = opt != nullptr && !skip_wy && hl_fused_optimiser(d, Bp);
+    const int wg_ksplit = fused_opt_ ? 1 : hl_wgrad_ksplit((long)((d.h_e + 63) / 64) * ((d.K1 + 63) / 64), Bp);
+    // a small y_layer (64-feature models: 0.16 M parameters) and no extra layers: its weight gradient rides in the grouped launch
+    // (a fourth problem) and ONE optimiser launch follows -- there is nothing to keep apart, and the side chain dWy -> Adam ->
+    // gradient fold (dWy 37 us beside the fused middle) was what the final launch waited for
+    const bool wy_in_group = opt != nullptr && !fused_opt_ && !d.conv && !skip_wy && d.n_xe == 0 && d.n_xd == 0 &&
+                             (long)d.NYl * d.h_d <= 512l * 1024;
+    const long clear_n = wy_in_group ? (long)(d.arena_size - d.o_wd) : (long)(d.o_xw - d.o_wd);
+    const bool clear_in_mid = wg_ksplit > 1 && d.o_wd % 4 == 0 && clear_n % 4 == 0;
+    if ((rc = hl_launch_mid_bwd_fused(p, ws, g_mu, g_lv, kl_std_weight, B, Bp, st, direct_bwd ? dyl : nullptr,
+                                      clear_in_mid ? ws->G + d.o_wd : nullptr, clear_in_mid ? clear_n : 0))) return rc;
+    if (direct_bwd) HL_CHECK(hipEventRecord(p->ev[2], st));
     // ---- single-process training step, MLP with one hidden layer per side: optimiser step in the weight gradients' epilogue ----
     //   caller:  dU -> fused middle -> {dW1, dWd, d[Wmu; Wlv]} + Adam + shadows (ONE launch) -> [join] -> next step
     //   side 0:  dWy + Adam + shadows (one launch; into the second shadow pair when the caller provides one, else behind dU_splitk,
@@ -603,30 +649,13 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     // Before: gradients through HBM, then two HBM-bound k_adam_tiled launches that must not overlap (71 us each together, 28 +
     // 22 us apart), y_layer's on side 0 and the rest behind a cross-queue join: 44 us of optimiser on the critical path of a
     // 145 us step (rocprofv3 trace of the replayed graph: profiles/r2_*_step_timeline.txt).
-    const bool fused_opt = opt != nullptr && !skip_wy && hl_fused_optimiser(d, Bp);
     if (fused_opt) {
-        AdamGemmGroup g{};
-        g.n = 3;
-        g.K = Bp;
-        g.p[0] = AdamGemmProb{ws->dtT, ws->xnT, nullptr, ws->w1s, nullptr, (long)d.o_w1, 0, Bp, Bp, d.h_e, d.K1, 0, 0, d.K1p, 0, 0, 0, 0};
-        g.p[1] = AdamGemmProb{ws->duT, ws->zbT, nullptr, ws->wds, ws->wdTs, (long)d.o_wd, 0, Bp, Bp, d.h_d0, d.L, 0, 0, d.Lp, d.hd0p, 0, 0, 0};
-        g.p[2] = AdamGemmProb{ws->dmlT, ws->tT, nullptr, ws->wmls, ws->wmlTs, (long)d.o_wmu, (long)d.o_wlv, Bp, Bp, 2 * d.Lp, d.h_e, d.Lp,
-                              d.L, d.hep, 2 * d.Lp, 0, 0, 0};
-        bf16_t* wys_out = ws->wys_next != nullptr ? ws->wys_next : ws->wys;
-        bf16_t* wyTs_out = ws->wyTs_next != nullptr ? ws->wyTs_next : ws->wyTs;
-        HL_REQUIRE((ws->wys_next == nullptr) == (ws->wyTs_next == nullptr), HLVAE_EINVAL, "ws->wys_next / wyTs_next: both or none");
-        AdamGemmGroup gy{};
-        gy.n = 1;
-        gy.K = Bp;
-        gy.p[0] = AdamGemmProb{dylT, ws->uT, p->wy_rowsrc_dev, wys_out, wyTs_out, (long)d.o_wy, 0, Bp, Bp, d.NYl, d.h_d, 0, 0, d.hdp, d.NYlp,
-                               0, 0, 0};
-        const unsigned tickets = (unsigned)(hl_gemm_adam_grid(g) + hl_gemm_adam_grid(gy) + hl_adam_grid(p, ws, 0u, 1));
-        if ((rc = hl_launch_gemm_adam(g, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, tickets,
-                                      "dW1_dWd_dWmu_adam", st))) return rc;
+        if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
+                                      tickets, "dW1_dWd_dWmu_adam", st))) return rc;
         HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
-        if (wys_out == ws->wys) HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
-        if ((rc = hl_launch_gemm_adam(gy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, tickets,
-                                      "dWy_adam", s0))) return rc;
+        if (g_wy.p[0].sh == ws->wys) HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
+        if ((rc = hl_launch_gemm_adam(g_wy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
+                                      tickets, "dWy_adam", s0))) return rc;
         if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s0))) return rc;
         if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tickets,
                                "adam_small", s0))) return rc;
@@ -650,8 +679,13 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     g.p[2] = GemmProb{ws->dmlT, ws->tT, ws->G + d.o_wmu, ws->G + d.o_wlv, Bp, Bp, d.h_e, 2 * d.Lp, d.h_e, d.Lp, d.L};
     // few output tiles and a long batch axis (a 64-feature model at 4096 rows: 24 tiles x 64 k-steps): split-K with fp32 atomics
     // into the (cleared) gradient slices -- they are neighbours in the arena: [Wd | Wmu | Wlv | W1]
-    g.ksplit = hl_wgrad_ksplit((long)((d.h_e + 63) / 64) * ((d.K1 + 63) / 64), Bp);
-    if (g.ksplit > 1) HL_CHECK(hipMemsetAsync(ws->G + d.o_wd, 0, sizeof(float) * (size_t)(d.o_xw - d.o_wd), st));
+    if (wy_in_group) {      // (rows of dY^T are in the head kernel's variable order: stored through the row map)
+        g.n = 4;
+        g.p[3] = GemmProb{dylT, ws->uT, ws->G + d.o_wy, nullptr, Bp, Bp, d.h_d, d.NYl, d.h_d, 0, 0};
+        g.p[3].rowmap = p->wy_rowsrc_dev;
+    }
+    g.ksplit = wg_ksplit;
+    if (g.ksplit > 1 && !clear_in_mid) HL_CHECK(hipMemsetAsync(ws->G + d.o_wd, 0, sizeof(float) * (size_t)clear_n, st));
     if ((rc = hl_launch_gemm_f32_group(g, "dW1_dWd_dWmu", st))) return rc;
     if (d.n_xe > 0) {   // deeper encoder: d a = (dT W1) .* (a > 0) for the layer below the last, and so on down to the inputs
         const int il = d.n_xe - 1;
@@ -668,6 +702,9 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         }
     }
     const bool conv_opt = d.conv && opt != nullptr && !skip_wy;
+    // a small y_layer (64-feature models: 0.16 M parameters): ONE optimiser launch at the end instead of y_layer's own on side 0 --
+    // nothing to keep apart, and the side chain (dWy -> Adam -> gradient fold) was what the final launch waited for
+    const bool small_wy = opt != nullptr && !d.conv && !skip_wy && (long)d.NYl * d.h_d <= 512l * 1024;
     if (d.conv) {   // the convolutional features receive a gradient: d feat = dT W1, then conv2 / conv1 / representation layer
         if ((rc = hl_launch_gemm_f32(ws->dt, d.hep, ws->w1Ts, d.hep, ws->dfeat, d.Xep, Bp, d.Xe, d.hep, 0, 0, nullptr, "dfeat", st))) return rc;   // (conv: K1 = Xe)
         if (conv_opt) HL_CHECK(hipEventRecord(p->ev[1], st));      // dense gradients final, W1's transposed shadow read
@@ -679,9 +716,10 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
             if ((rc = hl_launch_transpose_bf16(ws->dyc, d.NYlp, ws->dycT, Bp, Bp, d.NYl, "dyc_transpose", s0))) return rc;
         // d Wy = dY^T U  [NYl][h_d]
         // (rows of dY^T are in the head kernel's variable order: the store maps them back to the master's rows)
-        if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0,
-                                     d.conv ? nullptr : p->wy_rowsrc_dev))) return rc;
-        if (opt != nullptr) {       // takes no completion ticket: the final launch below is ordered behind it by the join
+        if (!wy_in_group)
+            if ((rc = hl_launch_gemm_f32(dylT, Bp, ws->uT, Bp, ws->G + d.o_wy, d.h_d, d.NYl, d.h_d, Bp, 0, 0, nullptr, "dWy", s0,
+                                         d.conv ? nullptr : p->wy_rowsrc_dev))) return rc;
+        if (opt != nullptr && !small_wy) {       // takes no completion ticket: the final launch below is ordered behind it by the join
             HL_REQUIRE(ws->wys_next == nullptr, HLVAE_EINVAL, "backward_adam: ws->wys_next is honoured by the fused-optimiser step only "
                        "(hlvae_backward_adam_fused() says when)");
             HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
@@ -698,9 +736,13 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         // 4 us kernel started 40 us late in the replayed graph and took dWy and y_layer's Adam launch with it (rocprofv3 trace).
         if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s0))) return rc;
         HL_CHECK(hipEventRecord(p->ev[3], s0));
+        if (wy_in_group)        // side 0 is otherwise idle here: the ELBO scalars + metrics behind the fold, so that the next batch's
+            // input stage -- what the end of the step waits for -- has side 1 to itself (colstats + pack ended 6 us after the
+            // final optimiser launch, 132 -> 122 us traced)
+            if ((rc = hl_flush_deferred(p, s0, true, HL_PEND_FINALIZE | HL_PEND_METRICS, true))) return rc;
     }
     if (p->pend_flags & HL_PEND_DEFERRED) {
-        HL_CHECK(hipStreamWaitEvent(s1, p->ev[2], 0));
+        HL_CHECK(hipStreamWaitEvent(s1, p->ev[direct_bwd ? 0 : 2], 0));     // (narrow y_layer: ev[2] is behind the fused middle)
         if ((rc = hl_flush_deferred(p, s1, true))) return rc;
     }
     if (!skip_wy) HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
@@ -710,7 +752,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         if ((rc = conv_opt ? hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1,
                                           (unsigned)hl_adam_grid(p, ws, 0u, 1), "adam_small", st)
                            : hl_adam(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, st,
-                                     skip_wy ? 0 : 1)))
+                                     (skip_wy || small_wy) ? 0 : 1)))
             return rc;
     return hlvae_join(p, s);
 }

@@ -53,9 +53,10 @@ struct GemmProb {
     float* C;
     float* C2;
     int lda, ldb, ldc, M, N, band, band_rows, tiles_m, tiles_n, n_fast, tile0;
+    const int32_t* rowmap;      // band <= 0 only: output row gr is stored at row rowmap[gr] of C (nullptr: gr)
 };
 struct GemmGroup {
-    GemmProb p[3];
+    GemmProb p[4];
     int n, K;
     int ksplit, kper, tiles_total;      // split-K over the whole group (launcher fills kper / tiles_total)
 };
@@ -78,7 +79,7 @@ struct AdamGemmGroup {
     int n, K, tiles_total;
 };
 
-enum { HL_PEND_METRICS = 1, HL_PEND_FINALIZE = 2, HL_PEND_RUNNING = 4, HL_PEND_FEED = 8,
+enum { HL_PEND_METRICS = 1, HL_PEND_FINALIZE = 2, HL_PEND_RUNNING = 4, HL_PEND_FEED = 8, HL_PEND_RUNNING2 = 16,
        HL_PEND_DEFERRED = HL_PEND_METRICS | HL_PEND_FINALIZE | HL_PEND_FEED };
 
 // a + (the value of the lane 16 / 32 positions away, lane ^ 16 / lane ^ 32): the cross-row steps of a wave reduction on the

@@ -90,10 +90,14 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32(const bf16_t* __restric
 // workgroups per CU, and every lane requests its 12 float4 of optimiser state BEFORE the product, so the streaming part is
 // in flight under the MFMA loop (round 1 applied Adam in the epilogue of the 128-row-tile gradient kernel, loads after the
 // product: 1-2 workgroups per CU could not keep enough bytes in flight, 0.190 vs 0.166 ms/step).
+// Registers decide the rest: with all 12 float4 prefetched the kernel needed 184 VGPRs = two workgroups per CU, 512 slots for
+// the 816 tiles of y_layer's gradient, i.e. two rounds (34 us).  Only the masters are requested before the product; m and v
+// follow once the product's registers are free: 124 VGPRs, four workgroups per CU (LDS 36.9 KB each), every tile resident at
+// once: 34.1 -> 28.6 us (y_layer), 28.9 -> 24.8 us (the other three), step 0.1437 -> 0.136 ms.
 // Completion tickets as in k_adam_tiled: the launches of one step may run concurrently; the last workgroup commits t.
 // ------------------------------------------------------------------------------------------------
 template <int BK>
-__global__ __launch_bounds__(HL_THREADS) void k_gemm_adam(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
+__global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
                                                           float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
                                                           float b1, float b2, float eps, float gscale, unsigned ticket_total) {
     using G = GemmNT<64, 64, BK, 2, 2>;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_adam(AdamGemmGroup g, float
     const int M = q.M, N = q.N;
     const int c4 = (threadIdx.x & 15) * 4, rq = threadIdx.x >> 4;         // 16 float4 per tile row, 16 rows per pass
     float4 p[4], m[4], v[4];
-    long o[4];
+    int o[4];                                                     // (arena offsets fit 31 bits: checked by the launcher)
     bool in[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -126,16 +130,19 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_adam(AdamGemmGroup g, float
             }
         }
         in[i] = base >= 0;
-        o[i] = in[i] ? base + n0 + c4 : q.off;
+        o[i] = (int)(in[i] ? base + n0 + c4 : q.off);
         p[i] = *reinterpret_cast<const float4*>(P + o[i]);
-        m[i] = *reinterpret_cast<const float4*>(M1 + o[i]);
-        v[i] = *reinterpret_cast<const float4*>(M2 + o[i]);
     }
     typename G::Acc acc;
     G::zero(acc);
     G::run(q.A, q.lda, q.B, q.ldb, m0, n0, M, N, 0, g.K, smem, acc);
     G::to_lds(acc, smem);
     float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                                      // (the product's registers are free again)
+        m[i] = *reinterpret_cast<const float4*>(M1 + o[i]);
+        v[i] = *reinterpret_cast<const float4*>(M2 + o[i]);
+    }
     const AdamScalars a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -195,9 +202,10 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32_group(GemmGroup g) {
     const int bid = (int)blockIdx.x % g.tiles_total, ks = (int)blockIdx.x / g.tiles_total;
     int pi = 0;
 #pragma unroll
-    for (int k = 1; k < 3; ++k)
+    for (int k = 1; k < 4; ++k)
         if (k < g.n && bid >= g.p[k].tile0) pi = k;
     const GemmProb& q = g.p[pi];
+    const int32_t* __restrict__ rowmap = q.rowmap;
     // problem 0 starts at workgroup 0, so its XCD-contiguous remap is exact; the small problems do not care
     const int lid = pi == 0 ? xcd_remap(bid, q.tiles_m * q.tiles_n) : bid - q.tile0;
     const int tm = q.n_fast ? lid / q.tiles_n : lid % q.tiles_m, tn = q.n_fast ? lid % q.tiles_n : lid / q.tiles_m;
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32_group(GemmGroup g) {
             const int gr = m0 + r, gc = n0 + c;
             if (gr >= M || gc >= N) continue;
             float* dst = nullptr;
-            if (band <= 0) dst = C + (size_t)gr * ldc + gc;
+            if (band <= 0) dst = C + (size_t)(rowmap != nullptr ? rowmap[gr] : gr) * ldc + gc;
             else if (gr < band_rows) dst = C + (size_t)gr * ldc + gc;
             else if (gr >= band && gr < band + band_rows) dst = C2 + (size_t)(gr - band) * ldc + gc;
             if (dst != nullptr) atomicAdd(dst, Cs[r * G::CLD + c]);
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32_group(GemmGroup g) {
         const int gr = m0 + r, gc = n0 + c;
         if (gr >= M || gc >= N) continue;
         if (band <= 0) {
-            C[(size_t)gr * ldc + gc] = Cs[r * G::CLD + c];
+            C[(size_t)(rowmap != nullptr ? rowmap[gr] : gr) * ldc + gc] = Cs[r * G::CLD + c];
         } else {
             if (gr < band_rows) C[(size_t)gr * ldc + gc] = Cs[r * G::CLD + c];
             else if (gr >= band && gr < band + band_rows) C2[(size_t)(gr - band) * ldc + gc] = Cs[r * G::CLD + c];
@@ -376,6 +384,8 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
         HL_REQUIRE(q.N % 4 == 0 && q.M % 4 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldd % 4 == 0 && q.off % 4 == 0 && q.off2 % 4 == 0 &&
                        (q.shT == nullptr || q.ldT % 4 == 0), HLVAE_ESHAPE, "gemm_adam problem %d: M=%d N=%d lda=%d ldb=%d", i, q.M, q.N,
                    q.lda, q.ldb);
+        HL_REQUIRE(q.off + (long)q.M * q.N < (1l << 31) && q.off2 + (long)q.M * q.N < (1l << 31), HLVAE_ESHAPE,
+                   "gemm_adam problem %d: arena offsets beyond 2^31 elements", i);          // the kernel keeps them in 32 bits
         q.tiles_m = (q.M + 63) / 64;
         q.tiles_n = (q.N + 63) / 64;
         q.tile0 = t;
@@ -391,7 +401,7 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
 
 // grouped launch: every problem uses the tile shape chosen for problem 0 (the large one)
 int hl_launch_gemm_f32_group(GemmGroup g, const char* label, hipStream_t s) {
-    HL_REQUIRE(g.n >= 1 && g.n <= 3 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm group: n=%d K=%d", g.n, g.K);
+    HL_REQUIRE(g.n >= 1 && g.n <= 4 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm group: n=%d K=%d", g.n, g.K);
     // g.ksplit (set by the caller, who clears the outputs when it is > 1) slices K for every problem of the group
     if (g.ksplit < 1) g.ksplit = 1;
     g.kper = g.ksplit > 1 ? ru((g.K + g.ksplit - 1) / g.ksplit, 64) : g.K;

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     float* __restrict__ mu, float* __restrict__ lv, float* __restrict__ z, bf16_t* __restrict__ zb,
     bf16_t* __restrict__ zbT, int L, double* __restrict__ klpart,
     const bf16_t* __restrict__ wd, int hdp, int h_d, const float* __restrict__ bd, bf16_t* __restrict__ u_out,
-    bf16_t* __restrict__ uT_out, int B) {
+    bf16_t* __restrict__ uT_out, int B, const bf16_t* __restrict__ xin, int K1p, const bf16_t* __restrict__ w1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lda = hep + 8;                                     // bf16 elements
     bf16_t* Ta = reinterpret_cast<bf16_t*>(smem);                // [16][hep+8]
@@ -77,6 +77,37 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * MR;
 
+    // ---- stage 1 (narrow input, xin != nullptr): T tile = relu(Xn W1^T + b1) computed HERE -- the input tile [16][K1p] goes to
+    // LDS, W1's shadow is read as MFMA B fragments from L2 like the other small weights.  For a 64-feature model (K1p = 128) the
+    // separate split-K GEMM was a 10 us launch of two k-steps plus a slab round trip through HBM.
+    if (xin != nullptr) {
+        bf16_t* Xa = reinterpret_cast<bf16_t*>(Cp);                  // [16][K1p+8], in the stage-2 partials' place (used after)
+        const int ldx = K1p + 8;
+        for (int idx = tid; idx < MID_ROWS * (K1p / 8); idx += MID_THREADS) {
+            const int r = idx / (K1p / 8), c8 = (idx % (K1p / 8)) * 8;
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (r < MR && m0 + r < B) q = *reinterpret_cast<const uint4*>(xin + (size_t)(m0 + r) * K1p + c8);
+            *reinterpret_cast<uint4*>(Xa + r * ldx + c8) = q;
+        }
+        __syncthreads();
+        for (int nt = wave; nt < hep / 16; nt += MID_THREADS / 64) {
+            const f32x4_t acc = mfma_lds_x_global(Xa, ldx, w1, K1p, nt * 16, 0, K1p, lane);
+            const int col = nt * 16 + (lane & 15);
+            const float bias = col < h_e ? b1[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (lane >> 4) * 4 + r;
+                float x = acc[r] + bias;
+                x = (x > 0.f && col < h_e && row < MR && m0 + row < B) ? x : 0.f;
+                Ta[row * lda + col] = f2bf(x);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < MR * (hep / 4); idx += MID_THREADS) {
+            const int r = idx / (hep / 4), c4 = (idx % (hep / 4)) * 4;
+            *reinterpret_cast<uint2*>(t_out + (size_t)(m0 + r) * hep + c4) = *reinterpret_cast<const uint2*>(Ta + r * lda + c4);
+        }
+    } else
     // ---- stage 1: T tile = relu(sum_s slab + b1), rows >= B and columns >= h_e are zero
     // (two elements per pass: the slab loads of both -- 2 x S float4 -- are requested before the first is consumed)
     for (int idx0 = tid; idx0 < MID_ROWS * (hep / 4); idx0 += 2 * MID_THREADS) {
@@ -232,8 +263,13 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     const float* __restrict__ mu, const float* __restrict__ g_mu, const float* __restrict__ g_lv, float kl_w, int L,
     bf16_t* __restrict__ dmlT_out, float* __restrict__ gbmu, float* __restrict__ gblv,
     const bf16_t* __restrict__ wmlT, int hep, int h_e, const bf16_t* __restrict__ t, bf16_t* __restrict__ dtT_out,
-    float* __restrict__ gb1, int B, bf16_t* __restrict__ dt_out) {
+    float* __restrict__ gb1, int B, bf16_t* __restrict__ dt_out, const bf16_t* __restrict__ dyin, int NYp,
+    const bf16_t* __restrict__ wyT, float* __restrict__ zero_ptr, long zero_n4) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (the weight-gradient GEMMs that follow on this stream add split-K slices with atomics: their output region is cleared
+    //  here instead of by a memset node on the critical path, 5.7 us in the replayed graph)
+    for (long i = (long)blockIdx.x * MID_THREADS + threadIdx.x; i < zero_n4; i += (long)gridDim.x * MID_THREADS)
+        reinterpret_cast<float4*>(zero_ptr)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int lda = hdp + 8;
     bf16_t* Ua = reinterpret_cast<bf16_t*>(smem);                            // dU tile bf16 [16][hdp+8]
     constexpr int NTZ = LP / 16, KSZ = (MID_THREADS / 64) / NTZ;            // dz: n-tiles x k-slices over the 16 waves
@@ -243,6 +279,36 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * MR;
 
+    // ---- stage 1 (narrow y_layer, dyin != nullptr): dU tile = (dY Wy) * relu'(U) computed HERE from the dY tile [16][NYp] in LDS
+    // and y_layer's transposed shadow as B fragments from L2 (a 64-feature model: NYp = 320, five k-steps; the separate split-K
+    // GEMM was a 12 us launch plus a slab round trip)
+    if (dyin != nullptr) {
+        bf16_t* Ya = reinterpret_cast<bf16_t*>(Cz);                  // [16][NYp+8], in the dz partials' place (used after)
+        const int ldy = NYp + 8;
+        for (int idx = tid; idx < MID_ROWS * (NYp / 8); idx += MID_THREADS) {
+            const int r = idx / (NYp / 8), c8 = (idx % (NYp / 8)) * 8;
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (r < MR && m0 + r < B) q = *reinterpret_cast<const uint4*>(dyin + (size_t)(m0 + r) * NYp + c8);
+            *reinterpret_cast<uint4*>(Ya + r * ldy + c8) = q;
+        }
+        __syncthreads();
+        for (int nt = wave; nt < hdp / 16; nt += MID_THREADS / 64) {
+            const int col = nt * 16 + (lane & 15);
+            bf16_t gate[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (lane >> 4) * 4 + r;
+                gate[r] = (row < MR && m0 + row < B) ? u[(size_t)(m0 + row) * hdp + col] : (bf16_t)0;
+            }
+            const f32x4_t acc = mfma_lds_x_global(Ya, ldy, wyT, NYp, nt * 16, 0, NYp, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (lane >> 4) * 4 + r;
+                const float x = (col < h_d && bf2f(gate[r]) > 0.f) ? acc[r] : 0.f;
+                Ua[row * lda + col] = f2bf(x);
+            }
+        }
+    } else
     // ---- stage 1: dU tile = sum_s slab * relu'(U); d bd column sums
     // (two elements per pass: the slab loads of both -- 2 x S float4 -- are requested before the first is consumed)
     for (int idx0 = tid; idx0 < MID_ROWS * (hdp / 4); idx0 += 2 * MID_THREADS) {
@@ -411,8 +477,12 @@ static size_t mid_bwd_smem(int Lp, int hdp) {
            (size_t)MID_ROWS * 2 * Lp * 4;
 }
 
+// narrow first encoder Linear / narrow y_layer: the fused middle computes that product itself (no split-K launch, no slabs)
+bool hl_mid_direct_fwd(const hlvae_dims& d) { return !d.conv && d.K1p <= 256 && getenv("HL_NO_MID_DIRECT") == nullptr; }
+bool hl_mid_direct_bwd(const hlvae_dims& d) { return !d.conv && d.n_xd == 0 && d.NYlp <= 512 && getenv("HL_NO_MID_DIRECT") == nullptr; }
+
 int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float* eps, int sample, uint64_t rng_off, int B,
-                            int Bp, hipStream_t s) {
+                            int Bp, hipStream_t s, const bf16_t* xin) {
     const hlvae_dims& d = p->d;
     HL_REQUIRE(Bp % MID_ROWS == 0 && d.hep % 64 == 0 && d.hd0p % 64 == 0, HLVAE_ESHAPE, "mid_fwd_fused shapes");
     const size_t smem = mid_fwd_smem(d.Lp, d.hep, d.hd0p);           // (decoder side: the FIRST decoder layer, width h_d0)
@@ -429,7 +499,8 @@ int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
         k_mid_fwd_fused<LPv, MRv><<<Bp / MRv, MID_THREADS, smem, s>>>(                                                    \
             ws->slab, ws->splitk_enc, Bp, d.hep, d.h_e, ws->P + d.o_b1, ws->t, ws->tT, ws->wmls, ws->P + d.o_bmu,       \
             ws->P + d.o_blv, sample ? eps : nullptr, ws->eps, sample ? ws->rng : nullptr, rng_off, ws->mu, ws->lv,     \
-            ws->z, ws->zb, ws->zbT, d.L, ws->klpart, ws->wds, d.hd0p, d.h_d0, ws->P + d.o_bd, ws->u0, ws->u0T, B);      \
+            ws->z, ws->zb, ws->zbT, d.L, ws->klpart, ws->wds, d.hd0p, d.h_d0, ws->P + d.o_bd, ws->u0, ws->u0T, B,       \
+            xin, d.K1p, ws->w1s);                                                                                      \
     }
     // fewer than 128 sixteen-row workgroups (batches below 2048 rows) leave most CUs idle: eight rows per workgroup then
     // (four rows measured too: 0.1585 vs 0.1567 ms/step at 512 rows)
@@ -443,7 +514,8 @@ int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
 }
 
 int hl_launch_mid_bwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_w,
-                            int B, int Bp, hipStream_t s) {
+                            int B, int Bp, hipStream_t s, const bf16_t* dyin, float* zero_ptr, long zero_n) {
+    HL_REQUIRE(zero_n % 4 == 0 && (zero_n == 0 || ((uintptr_t)zero_ptr & 15) == 0), HLVAE_ESHAPE, "mid_bwd: the region to clear must be 16-byte aligned");
     const hlvae_dims& d = p->d;
     HL_REQUIRE(Bp % MID_ROWS == 0 && d.hep % 64 == 0 && d.hd0p % 64 == 0, HLVAE_ESHAPE, "mid_bwd_fused shapes");
     const size_t smem = mid_bwd_smem(d.Lp, d.hd0p);
@@ -461,7 +533,7 @@ int hl_launch_mid_bwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
         k_mid_bwd_fused<LPv, MRv><<<Bp / MRv, MID_THREADS, smem, s>>>(                                                    \
             ws->slab, S, Bp, d.hd0p, d.h_d0, ws->u0, ws->duT, ws->G + d.o_bd, ws->wdTs, ws->eps, ws->lv,             \
             ws->mu, g_mu, g_lv, kl_w, d.L, ws->dmlT, ws->G + d.o_bmu, ws->G + d.o_blv, ws->wmlTs, d.hep, d.h_e, ws->t, \
-            ws->dtT, ws->G + d.o_b1, B, (d.conv || d.n_xe > 0) ? ws->dt : nullptr);                                                    \
+            ws->dtT, ws->G + d.o_b1, B, (d.conv || d.n_xe > 0) ? ws->dt : nullptr, dyin, d.NYlp, ws->wyTs, zero_ptr, zero_n / 4); \
     }
     const int mr = Bp / MID_ROWS < 128 ? 8 : 16;
     if (d.Lp == 32) { if (mr == 8) HL_MB(32, 8) else HL_MB(32, 16) }

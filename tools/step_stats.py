@@ -1,4 +1,4 @@
-"""Per-step statistics from a rocprofv3 --kernel-trace CSV of bench.py: step period (start of one enc1_splitk to the next),
+"""Per-step statistics from a rocprofv3 --kernel-trace CSV of bench.py: step period (start of one k_mid_fwd_fused to the next),
 and for every kernel of a step its start offset / duration, averaged over the steady-state steps (median).
 usage: python tools/step_stats.py <kernel_trace.csv> [n_kernels_first_steps_to_skip]"""
 import csv
@@ -7,9 +7,8 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a step starts at every second k_gemm_splitk (enc1, then dU); enc1 = the one followed by k_mid_fwd_fused
-starts = [i for i, r in enumerate(rows) if "k_gemm_splitk" in r["Kernel_Name"] and i + 1 < len(rows)
-          and any("k_mid_fwd_fused" in rows[j]["Kernel_Name"] for j in range(i + 1, min(i + 4, len(rows))))]
+# step marker: the fused middle of the forward pass (one launch per step in every configuration); offsets are relative to it
+starts = [i for i, r in enumerate(rows) if "k_mid_fwd_fused" in r["Kernel_Name"]]
 starts = starts[len(starts) // 3:]                      # steady state (graph replays)
 per = [(int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e3 for a, b in zip(starts[:-1], starts[1:])]
 print(f"steps {len(per)}  period us: median {st.median(per):.1f}  mean {st.mean(per):.1f}  p10 {sorted(per)[len(per) // 10]:.1f}  p90 {sorted(per)[9 * len(per) // 10]:.1f}")
