@@ -660,6 +660,8 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tickets,
                                "adam_small", s0))) return rc;
         HL_CHECK(hipEventRecord(p->ev[3], s0));
+        // (large batches, metrics behind side 0's chain and the input stage alone on side 1: its 16-workgroup statistics kernel
+        //  starves beside the streaming launches -- 110 us instead of 12 -- and the step does not move, 0.490 vs 0.483 ms)
         if (p->pend_flags & HL_PEND_DEFERRED) {
             HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));   // forked at the head kernel like side 0: with the fork behind
             // dU_splitk the graph executor put both side chains on ONE hardware queue, y_layer's launch last (0.166 vs 0.144 ms/step)
