@@ -59,6 +59,9 @@ def algorithmic_work(model, B, trainer_world=1):
     w["enc1_splitk"] = ((B * Xep + hep * Xep) * 2 + S_e * B * hep * 4, 2 * B * Xe * he)
     w["mid_fwd_fused"] = (S_e * B * hep * 4 + 2 * B * hep * 2 + 2 * Lp * hep * 2 + B * L * 16 + hdp * Lp * 2 + 2 * B * hdp * 2,
                           2 * B * he * 2 * L + 2 * B * L * hd)
+    if not d.conv and d.K1p <= 256:      # narrow input: the fused middle computes Xn W1^T itself (csrc/mid.hip), no split-K slabs
+        w["mid_fwd_fused"] = ((B * d.K1p + hep * d.K1p) * 2 + 2 * B * hep * 2 + 2 * Lp * hep * 2 + B * L * 16 + hdp * Lp * 2 + 2 * B * hdp * 2,
+                              2 * B * d.K1 * he + 2 * B * he * 2 * L + 2 * B * L * hd)
     w["dec1_relu"] = ((B * Lp + hdp * Lp) * 2 + 2 * B * hdp * 2, 2 * B * L * hd)
     # U + Wy panels in, targets + mask in (5 B / entry), dY out in both layouts, log_p_x + log_p_x_missing + x_hat out
     w["y_heads_loglik"] = ((B * hdp + NY * hdp) * 2 + B * D * 5 + 2 * B * NY * 2 + 3 * B * D * 4, 2 * B * NY * hd + 150 * B * D)
@@ -69,6 +72,9 @@ def algorithmic_work(model, B, trainer_world=1):
     w["dU_splitk"] = ((B * NYlp + hdp * NYlp) * 2 + S_d * B * hdp * 4, 2 * B * NYl * hd)
     w["mid_bwd_fused"] = (S_d * B * hdp * 4 + 2 * B * hdp * 2 + B * L * 16 + 2 * B * 2 * Lp * 2 + 2 * B * hep * 2,
                           2 * B * hd * L + 2 * B * 2 * L * he)
+    if not d.conv and d.n_xd == 0 and NYlp <= 512:      # narrow y_layer: dY Wy inside the fused middle
+        w["mid_bwd_fused"] = ((B * NYlp + hdp * NYlp) * 2 + 2 * B * hdp * 2 + B * L * 16 + 2 * B * 2 * Lp * 2 + 2 * B * hep * 2,
+                              2 * B * NYl * hd + 2 * B * hd * L + 2 * B * 2 * L * he)
     w["dWd"] = ((hdp * Bp + Lp * Bp) * 2 + hd * L * 4, 2 * B * hd * L)
     w["dWmu_dWlv"] = ((2 * Lp * Bp + hep * Bp) * 2 + 2 * L * he * 4, 2 * B * 2 * L * he)
     w["dW1"] = ((hep * Bp + Xep * Bp) * 2 + he * Xe * 4, 2 * B * Xe * he)
