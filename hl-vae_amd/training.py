@@ -139,8 +139,11 @@ class ShardedAdam:
         if self._pending is not None:
             h, k = self._pending
             self._pending = None
-            h.wait()
-            self.rebuild_shadows(k)
+            if isinstance(h, torch.cuda.Stream):     # gather + rebuild already queued on that stream: wait for it
+                torch.cuda.current_stream(self.model.device).wait_stream(h)
+            else:
+                h.wait()
+                self.rebuild_shadows(k)
 
     def sync_masters(self):
         """collective: brings the fp32 masters of the other ranks' slices up to date (state_dict, checkpoints)"""
@@ -180,6 +183,7 @@ class ELBOTrainer:
             # the seed carries the rank (the reference's single process draws one randn_like for the whole batch, HLVAE.py:361)
             model._ws_t["rng"][0] = (int(model._ws_t["rng"][0].item()) + (dp.rank + 1) * 0x9E3779B97F4A7C15) % (2 ** 62)
         self._pf_stream = torch.cuda.Stream(device=dev)      # input stage of the NEXT batch (prefetch)
+        self._wy_stream = torch.cuda.Stream(device=dev)      # data parallel: y_layer's weight gradient + the start of its reduce-scatter
         self.err = torch.zeros(3, model.plan.D, dtype=torch.float32, device=dev)     # error_observed / missing / all
 
     # -- the step, eager ------------------------------------------------------------------------
@@ -337,10 +341,15 @@ class ELBOTrainer:
             else:
                 # y_layer's gradient (the largest slice) is final first: its reduce-scatter runs on RCCL's stream while the
                 # rest of the backward pass is still computing
-                _lib.check(lib.hlvae_backward_wy(m._plan_handle, ws, B, s), "backward_wy")
-                pend = [o.reduce_scatter(0, async_op=True)]
+                # (dWy itself runs on a stream of its own beside dU / the fused middle: on the caller's stream it was 21 us in front of them)
+                main = torch.cuda.current_stream(m.device)
+                self._wy_stream.wait_stream(main)
+                with torch.cuda.stream(self._wy_stream):
+                    _lib.check(lib.hlvae_backward_wy(m._plan_handle, ws, B, m._stream()), "backward_wy")
+                    pend = [o.reduce_scatter(0, async_op=True)]
                 _lib.check(lib.hlvae_backward(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), 1, B, s), "backward")
                 pend.append(o.reduce_scatter(1, async_op=True))
+                main.wait_stream(self._wy_stream)
             small = self.dp.allreduce_async(G[:int(d.atomic_region)])
             for k, h in enumerate(pend):        # slice k: wait for its sums, Adam on the owned part
                 h.wait()
@@ -354,10 +363,19 @@ class ELBOTrainer:
             gath = [(k, o.gather(k, async_op=True)) for k in order]
             for k, h in gath:
                 if k == 0 and len(pend) > 1:
-                    o._pending = (h, k)
+                    # the shadow rebuild too goes on the side stream (8 us in front of the next head kernel when the caller's
+                    # stream did it in finish_pending)
+                    side = self._wy_stream
+                    side.wait_stream(torch.cuda.current_stream(m.device))
+                    with torch.cuda.stream(side):
+                        h.wait()
+                        o.rebuild_shadows(k)
+                    o._pending = (side, k)
                 else:
                     h.wait()
                     o.rebuild_shadows(k)
+            if not m.conv:      # hlvae_backward(skip_wy = 1) left the deferred side chain (metrics, next batch's input stage) running
+                _lib.check(lib.hlvae_join(m._plan_handle, s), "join")
         m._fwd_token += 1
         m._grad_region_clean = True
         if self.kl == "gp":
@@ -449,5 +467,16 @@ class ELBOTrainer:
 
     # -- device-resident scalars (the reference's .item() values, training.py:139-143) ----------
     def scalars(self):
+        """device-resident scalars of the last step (no host sync: ``.item()`` them where the reference logs, training.py:139-143).
+        With the GP prior, ``gp_not_spd`` is the device flag of its SPD inversions (non-zero: a covariance stopped being positive
+        definite, where the reference's torch.cholesky raises at once); ``check()`` turns it into an exception."""
         sc = self.model._ws_t["scal"]
-        return {"nll_sum": sc[0], "kl": sc[1]}
+        out = {"nll_sum": sc[0], "kl": sc[1]}
+        if self.gp is not None and hasattr(self.gp, "fail"):
+            out["gp_not_spd"] = self.gp.fail
+        return out
+
+    def check(self):
+        """host-side check at a logging / epoch boundary (one device read): raises if the GP prior met a non-positive pivot"""
+        if self.gp is not None and hasattr(self.gp, "check"):
+            self.gp.check()

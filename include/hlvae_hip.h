@@ -272,7 +272,10 @@ int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx
 /* backward of rows B-D: all dense-layer gradients into ws->G (reads the noise from ws->eps).
  * g_mu, g_lv: upstream gradients of mu / log_var from the KL term ([B][L] fp32, may be NULL);
  * kl_std_weight != 0 adds the gradient of kl_std_weight * KL(q(z|x) || N(0,I)) in the same kernel
- * (closed form; NOT in the reference). */
+ * (closed form; NOT in the reference).
+ * skip_wy = 1 (data-parallel host): d Wy is not computed (hlvae_backward_wy did) and the call returns WITHOUT joining the deferred
+ * side work (metrics, next batch's input stage): the host's collectives and optimiser calls that follow do not depend on it;
+ * call hlvae_join at the end of the step. */
 int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv,
                    float kl_std_weight, int skip_wy, int B, hlvae_stream s);
 /* only d Wy = dY^T U, on the given stream.  Data-parallel hosts call this first, start the all-reduce of that arena
