@@ -412,7 +412,7 @@ class ELBOTrainer:
         if prefetch is not None:
             self.prime(data, mask)
             torch.cuda.synchronize()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, **self._capture_kw()):
             self.step(data, mask, P_batch, train_x=train_x, prefetch=prefetch, prepacked=(prefetch is not None) or None)
             if self.dp is not None:
                 self.opt.finish_pending()
@@ -452,7 +452,7 @@ class ELBOTrainer:
         # steps: a graph captured earlier has the buffer it starts from baked in.
         self._wy_dbuf = len(chain) % 2 == 0
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **self._capture_kw()):
                 for (r, pb), nr, gr in zip(chain, nxt, grp):
                     self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None, groups=gr)
                 if self.dp is not None:
@@ -461,6 +461,11 @@ class ELBOTrainer:
             self._wy_dbuf = False
         self._graphs[key] = g
         return g
+
+    def _capture_kw(self):
+        """several ranks: the process group's watchdog thread queries events while this thread captures -- only THIS thread's
+        calls may be checked against the capture (torch's default mode would invalidate it)"""
+        return {"capture_error_mode": "thread_local"} if (self.dp is not None and self.dp.world > 1) else {}
 
     def replay(self, key):
         self._graphs[key].replay()
