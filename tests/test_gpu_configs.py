@@ -689,3 +689,50 @@ def test_gp_captured_chain_matches_eager_steps():
     # fp32 / fp64 atomics (head gradients, the prior's per-subject sums) reorder between runs, and Adam turns a sign flip of a tiny
     # gradient into a +-lr step: measured kld 7e-6, parameters 2.7e-4 of the largest one, m 3e-6, H 5e-8, hyper-parameters 1e-9
     assert errs["kld"] < 1e-4 and errs["arena"] < 2e-3 and errs["theta"] < 1e-6 and errs["m"] < 1e-4 and errs["H"] < 1e-5, errs
+
+
+@pytest.mark.gpu
+def test_narrow_model_paths_match_the_general_ones():
+    """64-feature model (X = 104, D y = 320), 1024 rows: the narrow-model forms of round 2 -- first encoder Linear and dY Wy inside
+    the fused middle kernels, y_layer's gradient in the grouped launch, one optimiser launch, gradients cleared by the middle
+    kernel -- against the general launch sequence (HL_NO_MID_DIRECT: separate split-K GEMMs): forward outputs of one step and the
+    parameters after four steps."""
+    import os
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    from hlvae_amd.datafeed import CompactDataset
+    dev = _dev()
+    src = synthetic.make_tabular(n_rows=2048, T=16, seed=9)
+    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    R = [torch.tensor(np.arange(i * 512, i * 512 + 1024).astype(np.int32), device=dev) for i in range(2)]
+    eps = [torch.randn(1024, 32, generator=torch.Generator().manual_seed(70 + i)).to(dev) for i in range(4)]
+
+    def run():
+        torch.manual_seed(5)
+        model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=1024, materialize_samples=False).to(dev)
+        tr = ELBOTrainer(model, P_total=128, kl="normal", max_batch=1024, metrics=True)
+        tr.step_rows(ds, R[0], 64, eps=eps[0])
+        torch.cuda.synchronize()
+        t = model._ws_t
+        first = dict(mu=t["mu"][:1024].clone(), lpx=t["log_p_x"][:1024].clone(), nll=float(tr.scalars()["nll_sum"]))
+        for i in range(1, 4):
+            tr.step_rows(ds, R[i % 2], 64, eps=eps[i])
+        torch.cuda.synchronize()
+        out = (first, model._arena.clone(), tr.opt.m1.clone(), tr.err.clone())
+        model._release_device_state()
+        return out
+
+    a = run()
+    os.environ["HL_NO_MID_DIRECT"] = "1"
+    try:
+        b = run()
+    finally:
+        del os.environ["HL_NO_MID_DIRECT"]
+    # the same products with another split of the K axis (fp32 slabs summed vs one MFMA chain): last-bit differences before the bf16
+    # rounding of T and dU, which a few of their elements turn into one bf16 ulp
+    assert rel_err(a[0]["mu"], b[0]["mu"]) < 2e-3
+    assert rel_err(a[0]["lpx"], b[0]["lpx"]) < 2e-3
+    assert abs(a[0]["nll"] - b[0]["nll"]) <= 1e-5 * abs(b[0]["nll"])
+    assert rel_err(a[1], b[1]) < 2e-3, rel_err(a[1], b[1])         # parameters after four steps (Adam: +-lr per sign flip of a tiny gradient)
+    assert torch.isfinite(a[3]).all()
