@@ -284,11 +284,22 @@ def main():
             Gr = [b["groups_dev"] for b in ring]
             nx = [R[(i + 1) % len(ring)] for i in range(len(ring))]
             try:
-                for i in range(len(ring)):
-                    trainer.capture_rows(i, dsd, R[i], PB[i], next_rows=nx[i] if feed_pf else None, groups=Gr[i])
-                if a.graph_chain:      # the ring, `reps` times over, as ONE graph: a replay = a.chain consecutive steps
+                # Chains of consecutive steps as ONE graph each, for every ring position a region may start at and for the lengths
+                # a.chain, 4, 2: a timed region of any length is then whole chains plus at most one single step (an even chain
+                # double-buffers y_layer's shadows and has no executor join between its steps; a short driver run of 20 steps
+                # that fell back to single-step graphs at its ragged ends measured 0.145 instead of 0.137 ms/step).
+                # Capture order keeps the two input-buffer sets in phase: position o starts on set o % 2, an even chain ends on
+                # the set it began on, the single-step graph of position o moves on to the next.
+                chain_lens = sorted({l for l in (a.chain, 16, 8, 4, 2) if l <= a.chain and l % 2 == 0 and l >= 2}, reverse=True) if (a.graph_chain and feed_pf) else []
+                for o in range(len(ring)):
+                    for l in chain_lens:
+                        idx = [(o + j) % len(ring) for j in range(l)]
+                        trainer.capture_rows(("chain", o, l), dsd, [R[k] for k in idx], [PB[k] for k in idx],
+                                             next_rows=[nx[k] for k in idx], groups=[Gr[k] for k in idx])
+                    trainer.capture_rows(o, dsd, R[o], PB[o], next_rows=nx[o] if feed_pf else None, groups=Gr[o])
+                if a.graph_chain and not feed_pf:      # (no pipelined input stage: one chain from position 0, as before)
                     reps = max(1, a.chain // len(ring))
-                    trainer.capture_rows("ring", dsd, R * reps, PB * reps, next_rows=(nx * reps) if feed_pf else None, groups=Gr * reps)
+                    trainer.capture_rows("ring", dsd, R * reps, PB * reps, next_rows=None, groups=Gr * reps)
                 ok = 1
             except Exception as e:     # noqa: BLE001 -- a failed capture must not cost the whole measurement
                 ok, graph_note = 0, f"capture failed: {type(e).__name__}: {e}"
@@ -317,12 +328,19 @@ def main():
     it = [0]                                   # the batch chain continues across warm-up and the timed region
     chain = use_graph and compact and a.graph_chain
     n_chain = len(ring) * max(1, a.chain // len(ring))
+    chain_lens = sorted({l for l in (a.chain, 16, 8, 4, 2) if l <= a.chain and l % 2 == 0 and l >= 2}, reverse=True) if (chain and feed_pf) else []
 
     def run(n):
         left = n
         while left > 0:
             i = it[0]
-            if chain and i % len(ring) == 0 and left >= n_chain:        # n_chain steps per launch; the ragged ends one by one
+            l = next((l for l in chain_lens if left >= l), 0)
+            if l:                                                       # the longest chain that fits, from this ring position
+                trainer.replay(("chain", i % len(ring), l))
+                it[0] += l
+                left -= l
+                continue
+            if chain and not feed_pf and i % len(ring) == 0 and left >= n_chain:
                 trainer.replay("ring")
                 it[0] += n_chain
                 left -= n_chain
