@@ -455,7 +455,8 @@ int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx
     return hl_launch_scale_dy(p, ws, g_logpx, B, Bp, st);
 }
 
-static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered, int mask = HL_PEND_DEFERRED, bool second = false);
+static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered, int mask = HL_PEND_DEFERRED, bool second = false,
+                             bool feed_first = false);
 
 int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* err, hlvae_stream s) {
     CHECK_B();
@@ -478,11 +479,20 @@ int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* er
 // mask: which of the pending pieces to queue now (the others stay pending).  second: this chain's end is ev[1] / HL_PEND_RUNNING2
 // instead of ev[5] / HL_PEND_RUNNING -- two chains on two side streams (ELBO scalars + metrics on one, the next batch's input
 // stage on the other) that hlvae_join waits for separately.
-static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered, int mask, bool second) {
+static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is_ordered, int mask, bool second, bool feed_first) {
     const int todo = p->pend_flags & mask & HL_PEND_DEFERRED;
     if (!todo) return 0;
     if (!side_is_ordered) HL_CHECK(hipStreamWaitEvent(side, p->ev[5], 0));
     const bool both = (todo & HL_PEND_FINALIZE) && (todo & HL_PEND_METRICS);
+    // feed_first: the next batch's input stage ahead of the ELBO scalars / metrics (fused-optimiser step: it then runs beside
+    // dU_splitk and the fused middle instead of beside the two streaming launches, where its pack kernel took 52 us instead of 13)
+    if (feed_first && (todo & HL_PEND_FEED)) {
+        const int B = p->pend_feed_B;
+        if (p->d.n_stat > 0)
+            if (int rc = hl_launch_stats_compact(p, &p->pend_feed_ws, p->pend_feed_vals, p->pend_feed_mask, p->pend_feed_rows, B, side)) return rc;
+        if (int rc = hl_launch_pack_compact(p, &p->pend_feed_ws, p->pend_feed_vals, p->pend_feed_mask, p->pend_feed_rows, B,
+                                            (B + 127) / 128 * 128, side)) return rc;
+    }
     if ((todo & HL_PEND_FINALIZE) && !both) {
         const int B = p->pend_fin_B;
         if (int rc = hl_launch_elbo_finalize(p, &p->pend_fin_ws, B, (B + 127) / 128 * 128, side)) return rc;
@@ -490,7 +500,7 @@ static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is
     if (todo & HL_PEND_METRICS)       // (both pending: the ELBO bookkeeping rides in the metrics launch -- one link less)
         if (int rc = hl_launch_step_metrics(p, &p->pend_ws, p->pend_B, p->pend_err, side, both ? &p->pend_fin_ws : nullptr, p->pend_fin_B))
             return rc;
-    if (todo & HL_PEND_FEED) {       // input stage of the NEXT batch into the other buffer set (data only, no weights)
+    if ((todo & HL_PEND_FEED) && !feed_first) {       // input stage of the NEXT batch into the other buffer set (data only, no weights)
         const int B = p->pend_feed_B;
         if (p->d.n_stat > 0)
             if (int rc = hl_launch_stats_compact(p, &p->pend_feed_ws, p->pend_feed_vals, p->pend_feed_mask, p->pend_feed_rows, B, side)) return rc;
@@ -653,7 +663,13 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
                                       tickets, "dW1_dWd_dWmu_adam", st))) return rc;
         HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
-        if (g_wy.p[0].sh == ws->wys) HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
+        // y_layer's launch starts behind dU_splitk even when it writes the second shadow pair: the fused middle (64 workgroups of
+        // 1024 threads) must be RESIDENT before the streaming launch takes every register of the chip -- started first, the
+        // middle kernel waited for three of the four streaming workgroups of its CU to retire (33 us instead of 15; 0.138 ->
+        // 0.135 ms/step, 0.134 with the input stage first on side 1).  Large batches: dU_splitk is long (62 us at 4096 rows) and
+        // the middle kernel has 256 workgroups; there the launch starts with the head kernel's end when it may (0.485 vs 0.522 ms)
+        const bool small_batch = Bp < 2048;
+        if (g_wy.p[0].sh == ws->wys || small_batch) HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
         if ((rc = hl_launch_gemm_adam(g_wy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
                                       tickets, "dWy_adam", s0))) return rc;
         if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s0))) return rc;
@@ -665,7 +681,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         if (p->pend_flags & HL_PEND_DEFERRED) {
             HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));   // forked at the head kernel like side 0: with the fork behind
             // dU_splitk the graph executor put both side chains on ONE hardware queue, y_layer's launch last (0.166 vs 0.144 ms/step)
-            if ((rc = hl_flush_deferred(p, s1, true))) return rc;
+            if ((rc = hl_flush_deferred(p, s1, true, HL_PEND_DEFERRED, false, small_batch))) return rc;
         }
         HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
         return hlvae_join(p, s);

@@ -450,6 +450,8 @@ class ELBOTrainer:
         # y_layer's shadows alternate between two buffer pairs inside a chain with an even number of steps (the graph ends where
         # it began): the optimiser launch of a step need not wait for the step's last reader of the shadows.  Never in eager
         # steps: a graph captured earlier has the buffer it starts from baked in.
+        # (below 2048 rows the library starts y_layer's launch behind dU_splitk anyway -- the fused middle must be resident first,
+        #  csrc/cabi.hip -- and the second pair changes nothing; large batches use it)
         self._wy_dbuf = len(chain) % 2 == 0
         try:
             with torch.cuda.graph(g, **self._capture_kw()):
