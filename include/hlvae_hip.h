@@ -180,7 +180,8 @@ typedef struct {
     hlvae_layer_ws xd[HLVAE_MAX_EXTRA];   /* xd[n_xd-1].a / .aT must be u / uT (y_layer's input)                          */
     /* optional second pair of y_layer shadows: hlvae_backward_adam writes the UPDATED shadows there instead of in place, so
      * that its y_layer launch need not wait for this step's last reader of wys / wyTs; the caller then passes them as wys /
-     * wyTs of the next step (and these two as that step's *_next).  NULL: in place. */
+     * wyTs of the next step (and these two as that step's *_next).  NULL: in place.  (Below 2048 rows the launch starts behind that
+     * reader anyway, so that the fused middle kernel is resident first: the second pair then changes nothing.) */
     uint16_t* wys_next; uint16_t* wyTs_next;
 } hlvae_ws;
 
