@@ -36,12 +36,13 @@ int hl_launch_conv_enc_bwd(const hlvae_plan*, const hlvae_ws*, int, hipStream_t)
 int hl_launch_gemm_f32_group(GemmGroup, const char*, hipStream_t);
 bool hl_gemm_adam_ok(int, int, int, bool);
 int hl_gemm_adam_grid(const AdamGemmGroup&);
-int hl_launch_gemm_adam(AdamGemmGroup, float*, float*, float*, int64_t*, float, float, float, float, float, unsigned, const char*, hipStream_t);
+int hl_launch_gemm_adam(AdamGemmGroup, float*, float*, float*, int64_t*, float, float, float, float, float, unsigned, const char*, hipStream_t,
+                        float* Gflat = nullptr, long flat_lo = 0, long flat_n = 0);
 int hl_wgrad_ksplit(long, int);
 int hl_launch_transpose_bf16(const bf16_t*, int, bf16_t*, int, int, int, const char*, hipStream_t);
 int hl_adam_grid(const hlvae_plan*, const hlvae_ws*, unsigned, int);
 int hl_adam_part(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, unsigned, int,
-                 unsigned, const char*, hipStream_t);
+                 unsigned, const char*, hipStream_t, long flat_n = -1);
 int hl_adam_flat(const hlvae_plan*, const hlvae_ws*, const float*, float*, float*, uint16_t*, const int64_t*, long, long, float, float,
                  float, float, float, hipStream_t);
 int hl_shadows_from_bf16(const hlvae_plan*, const hlvae_ws*, const uint16_t*, unsigned, const char*, hipStream_t);
@@ -660,9 +661,22 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     // 22 us apart), y_layer's on side 0 and the rest behind a cross-queue join: 44 us of optimiser on the critical path of a
     // 145 us step (rocprofv3 trace of the replayed graph: profiles/r2_*_step_timeline.txt).
     if (fused_opt) {
+        // The four bias vectors whose gradients the fused middle accumulates (bd, bmu, blv, b1: the END of the small region, by
+        // construction of the arena) take their Adam step in workgroup 0 of THIS launch, after its tile -- behind the middle kernel by
+        // stream order.  The rest of the small region (head parameters, y_layer's bias: gradients from the head kernel) is then
+        // independent of the backward pass: fold + Adam run at the head of side 0, and side 0 ends with y_layer's launch instead
+        // of 17 us behind it.  (An event behind the middle kernel for the small-region launch to wait on costs the caller's queue
+        // 6.6 us -- a second child of that kernel: 0.141 vs 0.134 ms; without any dependency the order held only because y_layer's
+        // 30 us launch sat in between.)
+        const long bias_lo = d.o_bd, bias_n = d.atomic_region - d.o_bd;
+        HL_REQUIRE(d.o_bd % 4 == 0 && bias_n % 4 == 0 && d.o_bmu > d.o_bd && d.o_blv > d.o_bd && d.o_b1 > d.o_bd && d.o_by < d.o_bd,
+                   HLVAE_EINVAL, "backward_adam: the arena must end its small region with [bd | bmu | blv | b1]");
         if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
-                                      tickets, "dW1_dWd_dWmu_adam", st))) return rc;
+                                      tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n))) return rc;
         HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
+        if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s0))) return rc;
+        if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tickets,
+                               "adam_small", s0, bias_lo))) return rc;      // (behind y_layer's launch instead: 0.139 vs 0.137 ms)
         // y_layer's launch starts behind dU_splitk even when it writes the second shadow pair: the fused middle (64 workgroups of
         // 1024 threads) must be RESIDENT before the streaming launch takes every register of the chip -- started first, the
         // middle kernel waited for three of the four streaming workgroups of its CU to retire (33 us instead of 15; 0.138 ->
@@ -672,9 +686,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         if (g_wy.p[0].sh == ws->wys || small_batch) HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
         if ((rc = hl_launch_gemm_adam(g_wy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
                                       tickets, "dWy_adam", s0))) return rc;
-        if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s0))) return rc;
-        if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tickets,
-                               "adam_small", s0))) return rc;
+
         HL_CHECK(hipEventRecord(p->ev[3], s0));
         // (large batches, metrics behind side 0's chain and the input stage alone on side 1: its 16-workgroup statistics kernel
         //  starves beside the streaming launches -- 110 us instead of 12 -- and the step does not move, 0.490 vs 0.483 ms)

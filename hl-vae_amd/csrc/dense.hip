@@ -99,7 +99,8 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_f32(const bf16_t* __restric
 template <int BK>
 __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
                                                           float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
-                                                          float b1, float b2, float eps, float gscale, unsigned ticket_total) {
+                                                          float b1, float b2, float eps, float gscale, unsigned ticket_total,
+                                                          float* __restrict__ Gflat, long flat_lo4, long flat_n4) {
     using G = GemmNT<64, 64, BK, 2, 2>;
     constexpr int CLD = G::CLD;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
@@ -177,6 +178,27 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, fl
                 pk.y = (uint32_t)f2bf(Cs[(r4 + 2) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 3) * CLD + c]) << 16);
                 *reinterpret_cast<uint2*>(q.shT + (size_t)(n0 + c) * q.ldT + m0 + r4) = pk;
             }
+        }
+    }
+    if (flat_n4 > 0 && blockIdx.x == 0) {
+        // workgroup 0, after its tile: Adam on a range of the small flat region whose gradients the kernel in FRONT of this launch
+        // on the same stream accumulated with atomics (the four bias vectors of the fused middle), zeroing them for the next
+        // step -- so that the small-region launch on the side stream depends on the head kernel only.  (As an extra workgroup
+        // with a branch at the top of the kernel the whole launch was 60 % slower.)
+        float4* P4 = reinterpret_cast<float4*>(P) + flat_lo4;
+        float4* G4 = reinterpret_cast<float4*>(Gflat) + flat_lo4;
+        float4* M14 = reinterpret_cast<float4*>(M1) + flat_lo4;
+        float4* M24 = reinterpret_cast<float4*>(M2) + flat_lo4;
+        for (long i = threadIdx.x; i < flat_n4; i += HL_THREADS) {
+            float4 pp = P4[i], gr = G4[i], mm = M14[i], vv = M24[i];
+            pp.x = adam_one(pp.x, gr.x, mm.x, vv.x, a);
+            pp.y = adam_one(pp.y, gr.y, mm.y, vv.y, a);
+            pp.z = adam_one(pp.z, gr.z, mm.z, vv.z, a);
+            pp.w = adam_one(pp.w, gr.w, mm.w, vv.w, a);
+            P4[i] = pp;
+            M14[i] = mm;
+            M24[i] = vv;
+            G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     if (ticket_total != 0) {
@@ -376,8 +398,10 @@ int hl_gemm_adam_grid(const AdamGemmGroup& g) {
 }
 
 int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t* step_count, float lr, float b1, float b2, float eps,
-                        float gscale, unsigned ticket_total, const char* label, hipStream_t s) {
+                        float gscale, unsigned ticket_total, const char* label, hipStream_t s, float* Gflat, long flat_lo, long flat_n) {
     HL_REQUIRE(g.n >= 1 && g.n <= 3 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm_adam: n=%d K=%d", g.n, g.K);
+    HL_REQUIRE(flat_lo % 4 == 0 && flat_n % 4 == 0 && flat_n >= 0 && (flat_n == 0 || Gflat != nullptr), HLVAE_ESHAPE,
+               "gemm_adam: flat range [%ld, +%ld) must be 4-aligned", flat_lo, flat_n);
     int t = 0;
     for (int i = 0; i < g.n; ++i) {
         AdamGemmProb& q = g.p[i];
@@ -393,8 +417,11 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
     }
     g.tiles_total = t;
     HL_PROF(label, s);
-    if (g.K % 64 == 0) k_gemm_adam<64><<<t, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total);
-    else k_gemm_adam<32><<<t, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total);
+    const int grid = t;
+    if (g.K % 64 == 0)
+        k_gemm_adam<64><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4);
+    else
+        k_gemm_adam<32><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4);
     HL_LAUNCH_CHECK();
     return 0;
 }

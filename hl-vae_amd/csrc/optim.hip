@@ -290,7 +290,7 @@ int hl_adam_grid(const hlvae_plan* p, const hlvae_ws* ws, unsigned which, int wi
 // launch of the same step behind this one).
 int hl_adam_part(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
                  float b2, float eps, float gscale, unsigned which, int with_flat, unsigned ticket_total, const char* label,
-                 hipStream_t s) {
+                 hipStream_t s, long flat_n = -1) {      // flat_n >= 0: only [0, flat_n) of the small region (same workgroup count)
     const hlvae_dims& d = p->d;
     HL_REQUIRE(d.atomic_region % 4 == 0, HLVAE_ESHAPE, "atomic region %ld not a multiple of 4", (long)d.atomic_region);
     const ShadowSet set = make_set(p, ws, which);
@@ -299,7 +299,7 @@ int hl_adam_part(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, 
     {
         HL_PROF(label, s);
         k_adam_tiled<<<grid, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 1,
-                                                 with_flat ? d.atomic_region / 4 : 0, ticket_total, nullptr, d.frozen_lo / 4,
+                                                 with_flat ? (flat_n >= 0 ? flat_n : d.atomic_region) / 4 : 0, ticket_total, nullptr, d.frozen_lo / 4,
                                                  (d.frozen_hi + 3) / 4);
         HL_LAUNCH_CHECK();
     }
