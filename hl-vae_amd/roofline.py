@@ -87,6 +87,9 @@ def algorithmic_work(model, B, trainer_world=1):
     w["adam_wy_early"] = (n_wy * 28 + sh_wy, 0)
     # y_layer's weight gradient and optimiser step as one kernel: dY^T + U^T in, master / m / v in and out, both shadows out
     w["dWy_adam"] = ((NYl * Bp + hdp * Bp) * 2 + n_wy * 24 + sh_wy, 2 * B * NYl * hd)
+    # the other three weight gradients + their optimiser step (one launch): operands, 24 B per parameter, shadows, the four biases
+    w["dW1_dWd_dWmu_adam"] = (w["dW1_dWd_dWmu"][0] - (he * Xe + hd * L + 2 * L * he) * 4 + n_rest * 24 + sh_rest + (2 * L + he + hd) * 32,
+                              w["dW1_dWd_dWmu"][1])
     w["adam_weights_shadows"] = (n_rest * 28 + sh_rest + model._atomic_region * 32, 0)
     w["adam_all_in_one"] = ((n_wy + n_rest) * 28 + sh_wy + sh_rest + model._atomic_region * 32, 0)     # data-parallel path
     w["shadow_cast"] = ((n_wy + n_rest) * 4 + sh_wy + sh_rest, 0)
