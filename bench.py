@@ -71,6 +71,10 @@ def parse():
                     help="N = 1: run the data-parallel optimiser path (flat sharded Adam -> bf16 copy -> shadows) instead of the "
                          "fused tile Adam, to price the code path the multi-GPU step uses")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the second measurement of the default run (BASELINE configs[4]: the reference's own training mode -- "
+                         "GP-prior KL + natural gradient, batch 1024 -- timed by a child process and reported as `also`)")
+    ap.add_argument("--no-in-step", action="store_true", help="skip the in-graph kernel stamps (roofline.in_step)")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--tag", default=None, help="label copied into config.tag (profiles/ bookkeeping)")
     return ap.parse_args()
@@ -247,6 +251,13 @@ def main():
     if kl == "gp":
         from hlvae_amd.elbo_functions import GPPriorHIP
         gp = GPPriorHIP.from_reference_config(model, src, P_total, dev, dp=dp if world > 1 else None)   # shipped kernels, M = 120
+    # in-graph kernel stamps (roofline.in_step): the buffer is a kernel argument, so it exists before anything is captured; its slots
+    # stay disarmed (zero) through the warm-up and the timed region
+    from hlvae_amd import _lib as _hl, roofline
+    stamps = None
+    if not a.no_in_step:
+        stamps = torch.zeros(2 * _hl.load().hlvae_stamp_slots(), dtype=torch.int64, device=dev)
+        _hl.load().hlvae_stamp_buffer(_hl.ptr(stamps))
     trainer = ELBOTrainer(model, P_total=P_total, kl=kl, gp=gp, max_batch=a.batch, dp=dp, metrics=True)
     ring = build_ring(src, a.batch, 4)
     compact = a.feed == "compact"
@@ -278,38 +289,70 @@ def main():
         # pipelined input stage (MLP): every step runs the statistics + pack kernels of the NEXT batch beside its backward pass
         # (they depend on the data only; with several ranks the statistics all-reduce rides on the same side stream) -- still
         # exactly one input stage per step inside the timed region, but off the critical path
-        feed_pf = use_graph and a.feed_prefetch and not a.conv
-        if use_graph:
+        feed_pf = (use_graph or (not a.no_graph and os.environ.get("HLVAE_BENCH_TRY_CAPTURE") == "1")) and a.feed_prefetch and not a.conv
+        try_graph = use_graph or (not a.no_graph and os.environ.get("HLVAE_BENCH_TRY_CAPTURE") == "1")     # (rehearsal: let gloo ranks try)
+
+        def agree(ok):
+            """every rank replays graphs, or none does (MIN over ranks; host-side, outside any capture)"""
+            if world > 1:
+                t = torch.tensor([int(ok)], device=dev, dtype=torch.int32)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+                ok = bool(int(t.item()))
+            return ok
+
+        if try_graph:
             R = [b["rows_dev"] for b in ring]
             Gr = [b["groups_dev"] for b in ring]
             nx = [R[(i + 1) % len(ring)] for i in range(len(ring))]
+            # Phase 1 -- the eager warm-up steps (these execute the step's real collectives; an exception here is a genuine
+            # failure of the run and is raised).  Phase 2 -- the ranks agree that all of them got here and can capture AT ALL
+            # (a trivial capture with the trainer's capture mode).  Phase 3 -- the captures proper: a captured collective is
+            # recorded, not executed, so a rank that throws in there leaves no peer blocked; every rank then reaches the
+            # second agreement and all of them replay graphs or all launch eagerly.
+            for _ in range(2):
+                trainer.step_rows(dsd, R[0], PB[0], groups=Gr[0])
+            torch.cuda.synchronize()
+            ok, graph_note = 1, None
             try:
-                # Chains of consecutive steps as ONE graph each, for every ring position a region may start at and for the lengths
-                # a.chain, 4, 2: a timed region of any length is then whole chains plus at most one single step (an even chain
-                # double-buffers y_layer's shadows and has no executor join between its steps; a short driver run of 20 steps
-                # that fell back to single-step graphs at its ragged ends measured 0.145 instead of 0.137 ms/step).
-                # Capture order keeps the two input-buffer sets in phase: position o starts on set o % 2, an even chain ends on
-                # the set it began on, the single-step graph of position o moves on to the next.
-                chain_lens = sorted({l for l in (a.chain, 16, 8, 4, 2) if l <= a.chain and l % 2 == 0 and l >= 2}, reverse=True) if (a.graph_chain and feed_pf) else []
-                for o in range(len(ring)):
-                    for l in chain_lens:
-                        idx = [(o + j) % len(ring) for j in range(l)]
-                        trainer.capture_rows(("chain", o, l), dsd, [R[k] for k in idx], [PB[k] for k in idx],
-                                             next_rows=[nx[k] for k in idx], groups=[Gr[k] for k in idx])
-                    trainer.capture_rows(o, dsd, R[o], PB[o], next_rows=nx[o] if feed_pf else None, groups=Gr[o])
-                if a.graph_chain and not feed_pf:      # (no pipelined input stage: one chain from position 0, as before)
-                    reps = max(1, a.chain // len(ring))
-                    trainer.capture_rows("ring", dsd, R * reps, PB * reps, next_rows=None, groups=Gr * reps)
-                ok = 1
-            except Exception as e:     # noqa: BLE001 -- a failed capture must not cost the whole measurement
-                ok, graph_note = 0, f"capture failed: {type(e).__name__}: {e}"
-            if world > 1:              # every rank replays graphs, or none does
-                t = torch.tensor([ok], device=dev, dtype=torch.int32)
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
-                ok = int(t.item())
+                if os.environ.get("HLVAE_BENCH_FAIL_CAPTURE_RANK") == str(rank):
+                    raise RuntimeError("forced capture failure (HLVAE_BENCH_FAIL_CAPTURE_RANK)")
+                probe = torch.cuda.CUDAGraph()
+                pt = torch.zeros(8, device=dev)
+                with torch.cuda.graph(probe, **trainer._capture_kw()):
+                    pt.add_(1.0)
+                probe.replay()
+            except Exception as e:     # noqa: BLE001
+                ok, graph_note = 0, f"capture probe failed: {type(e).__name__}: {e}"
+            if not agree(ok):
+                ok = 0
+                graph_note = graph_note or "capture probe failed on another rank"
+            if ok:
+                try:
+                    # Chains of consecutive steps as ONE graph each, for every ring position a region may start at and for the lengths
+                    # a.chain, 4, 2: a timed region of any length is then whole chains plus at most one single step (an even chain
+                    # double-buffers y_layer's shadows and has no executor join between its steps; a short driver run of 20 steps
+                    # that fell back to single-step graphs at its ragged ends measured 0.145 instead of 0.137 ms/step).
+                    # Capture order keeps the two input-buffer sets in phase: position o starts on set o % 2, an even chain ends on
+                    # the set it began on, the single-step graph of position o moves on to the next.
+                    chain_lens = sorted({l for l in (a.chain, 16, 8, 4, 2) if l <= a.chain and l % 2 == 0 and l >= 2}, reverse=True) if (a.graph_chain and feed_pf) else []
+                    for o in range(len(ring)):
+                        for l in chain_lens:
+                            idx = [(o + j) % len(ring) for j in range(l)]
+                            trainer.capture_rows(("chain", o, l), dsd, [R[k] for k in idx], [PB[k] for k in idx],
+                                                 next_rows=[nx[k] for k in idx], groups=[Gr[k] for k in idx])
+                        trainer.capture_rows(o, dsd, R[o], PB[o], next_rows=nx[o] if feed_pf else None, groups=Gr[o])
+                    if a.graph_chain and not feed_pf:      # (no pipelined input stage: one chain from position 0, as before)
+                        reps = max(1, a.chain // len(ring))
+                        trainer.capture_rows("ring", dsd, R * reps, PB * reps, next_rows=None, groups=Gr * reps)
+                except Exception as e:     # noqa: BLE001 -- a failed capture must not cost the whole measurement
+                    ok, graph_note = 0, f"capture failed: {type(e).__name__}: {e}"
+                    trainer.reset_after_failed_capture()
+                if not agree(ok):
+                    ok = 0
+                    graph_note = graph_note or "capture failed on another rank"
+            use_graph = bool(ok)
             if not ok:
-                use_graph = feed_pf = False
-                graph_note = graph_note or "capture failed on another rank"
+                feed_pf = False
                 print(f"[bench] rank {rank}: HIP-graph capture unavailable ({graph_note}); launching eagerly", file=sys.stderr, flush=True)
             elif feed_pf:
                 trainer.prime_rows(dsd, R[0])
@@ -379,19 +422,29 @@ def main():
 
     if rank == 0:
         print(f"[bench] {world} GPU(s): {value:.0f} samples/s, {1e3 * dt / a.steps:.4f} ms/step", file=sys.stderr, flush=True)
-    from hlvae_amd import roofline
+    # in-graph durations: the SAME captured step replayed a few more times with the stamp slots armed (single-step graphs: one
+    # host read per step); every rank replays (the step contains collectives), rank 0 reports
+    in_step = None
+    if stamps is not None:
+        in_step = roofline.measure_in_step(stamps, lambda: run(1), n=24)
     # every rank runs the eager per-kernel pass (the data-parallel step contains collectives); rank 0 reports
     roof = roofline.measure_dominant_kernel(trainer, ring[0], a.steps, ds=dsd if compact else None, P_batch=PB[0])
     if rank != 0:
         roof = None
     workload_key = f"{a.workload}_b{a.batch}" + ("_conv" if a.conv else "") + (f"_{a.kl}" if a.kl != "normal" else "")
-    if roof is not None:      # HBM traffic from PMC counters is collected offline (separate rocprofv3 --pmc passes, tools/pmc_traffic.py)
+    if roof is not None:
+        roofline.add_in_step(roof, in_step, trainer.model, 1e3 * dt / a.steps)
+        # HBM traffic from PMC counters is collected offline (separate rocprofv3 --pmc passes, tools/pmc_traffic.py); a file made
+        # with another build of the library (ABI tag) or another kernel behind the label is refused
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
             k = pm.get(workload_key, {}).get("kernels", {})
-            if roof["kernel"] in k:
+            abi_ok = pm.get("abi") == _hl.load().hlvae_abi_version()
+            if roof["kernel"] in k and abi_ok:
                 roof["traffic"] = k[roof["kernel"]]["traffic_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r2_pmc_traffic.json:" + workload_key
+                roof["traffic_source"] = "profiles/r3_pmc_traffic.json:" + workload_key + ":" + k[roof["kernel"]].get("kernel", "")
+            elif roof["kernel"] in k:
+                roof["traffic_note"] = f"profiles/r3_pmc_traffic.json was collected with library ABI {pm.get('abi')}, this is {_hl.load().hlvae_abi_version()}: refused"
         except Exception:
             pass
     if rank == 0:
@@ -399,6 +452,23 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(src, dims, state0, ring[0]["rows"], P_total, ring[0]["P_batch"], kl, a.cpu_steps, conv=a.conv, gp_state=gp_state)
+
+    also = None
+    default_run = (a.workload, a.batch, a.kl, a.conv, a.rows, a.sharded) == ("d4", 512, "normal", False, None, False)
+    if rank == 0 and world == 1 and default_run and not a.no_also:
+        # BASELINE configs[4] -- the reference's actual training mode (elbo_functions.py:196-285 + training.py:130-137: GP-prior KL and
+        # natural gradient beside the decoder) -- measured in the same run by a child process (never exec from a GPU process)
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "d4", "--rows", "50000", "--batch", "1024", "--kl", "gp",
+               "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-also"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            also = {"configs[4]": {k: j[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")} |
+                    {"workload": j["config"]["workload"], "kl": j["config"]["kl"], "final_nll_sum": j["config"]["final_nll_sum"],
+                     "command": "bench.py " + " ".join(cmd[2:])}}
+        except Exception as e:     # noqa: BLE001 -- the headline line must not be lost to the extra leg
+            also = {"configs[4]": {"error": f"{type(e).__name__}: {e}"}}
 
     if rank == 0:
         T = T_SUBJECT[a.workload]
@@ -424,6 +494,8 @@ def main():
                        "final_nll_sum": nll_last, **({"graph_note": graph_note} if graph_note else {}), **({"tag": a.tag} if a.tag else {})},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if also is not None:
+            line["also"] = also
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -408,8 +408,18 @@ class HLVAE(nn.Module):
             self._plan_handle = h
         Bp = _ru(max(B, 1), 128)
         if self._ws is None or Bp > self._ws.Bp_max:
+            if self._ws is not None and getattr(self, "_grow_forbidden", None):
+                raise RuntimeError(f"batch of {B} rows exceeds the workspace ({self._ws.Bp_max} rows): {self._grow_forbidden}")
             self._alloc_workspace(max(Bp, _ru(self._max_batch, 128)))
         self._sync_shadows()
+
+    def _require_capacity(self, B: int):
+        """mid-step check: the workspace was sized at the top of the step (ELBOTrainer.step_rows); growing it now would swap the
+        buffers between the forward and the backward pass"""
+        if self._ws is None or _ru(max(B, 1), 128) > self._ws.Bp_max:
+            raise RuntimeError(f"a batch of {B} rows does not fit the workspace ({0 if self._ws is None else self._ws.Bp_max} rows) "
+                               "in the middle of a step: pass the prefetched batch to step_rows(prefetch_rows=...) so that it is "
+                               "sized at the top of the step, or build the trainer with a larger max_batch")
 
     def kernel_var_order(self):
         """Order in which the head kernel walks the variables (int32 [D]; None = their own order): grouped by likelihood
@@ -488,7 +498,11 @@ class HLVAE(nn.Module):
                           f"{tag}{i}_a": t["u"] if last_dec else z(Bp, l.n_out_p), f"{tag}{i}_aT": t["uT"] if last_dec else z(l.n_out_p, Bp),
                           f"{tag}{i}_d": z(Bp, l.n_out_p), f"{tag}{i}_dT": z(l.n_out_p, Bp)})
         t["P"] = self._arena
-        t["rng"][0] = int(torch.randint(0, 2 ** 62, (1,)).item())          # Philox seed from torch's global RNG
+        old_t = getattr(self, "_ws_t", None) or None                        # ({} before the first allocation)
+        if old_t is not None and "rng" in old_t:                                         # re-allocation: the noise stream continues (seed incl. the
+            t["rng"].copy_(old_t["rng"])                                    # per-rank offset of ELBOTrainer, and the step offset)
+        else:
+            t["rng"][0] = int(torch.randint(0, 2 ** 62, (1,)).item())      # Philox seed from torch's global RNG
         ws = _lib.HlvaeWs()
         ws.Bp_max, ws.splitk_enc, ws.splitk_dec = Bp, S_e, S_d
         for name in _lib.WS_POINTERS:

@@ -81,9 +81,15 @@ void hl_prof_end(hipStream_t s) {
     if (g_prof.back().b) (void)hipEventRecord(g_prof.back().b, s);
 }
 
+static unsigned long long* g_stamp_buf = nullptr;
+unsigned long long* hl_stamp_slot(int slot) { return g_stamp_buf != nullptr ? g_stamp_buf + 2 * slot : nullptr; }
+
 extern "C" {
 
 int hlvae_abi_version(void) { return HLVAE_ABI_VERSION; }
+
+int hlvae_stamp_slots(void) { return HL_ST_N; }
+void hlvae_stamp_buffer(uint64_t* buf) { g_stamp_buf = reinterpret_cast<unsigned long long*>(buf); }
 
 void hlvae_prof_enable(int on) { g_prof_on = on != 0; }
 
@@ -519,6 +525,12 @@ int hlvae_join(const hlvae_plan* p, hlvae_stream s) {
     if (p->pend_flags & HL_PEND_RUNNING) HL_CHECK(hipStreamWaitEvent((hipStream_t)s, p->ev[5], 0));
     if (p->pend_flags & HL_PEND_RUNNING2) HL_CHECK(hipStreamWaitEvent((hipStream_t)s, p->ev[1], 0));
     p->pend_flags &= ~(HL_PEND_RUNNING | HL_PEND_RUNNING2);
+    return 0;
+}
+
+int hlvae_reset_pending(const hlvae_plan* p) {
+    HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
+    p->pend_flags = 0;          // deferred side work recorded against a capture that failed: dropped
     return 0;
 }
 

@@ -119,6 +119,27 @@ struct hlvae_plan {
     mutable const int32_t* pend_feed_rows;
 };
 
+// ---- in-graph kernel stamps (bench.py's "roofline.in_step"): when the host has handed the library a stamp buffer
+// (hlvae_stamp_buffer) BEFORE the step was launched / captured, the stamped kernels record the first start and the last end of
+// their workgroups on the 100 MHz s_memrealtime clock -- inside the replayed HIP graph, beside whatever else runs then, with no
+// extra graph node.  Slot layout: buf[2 k] = min start (armed by the host with ~0; 0 = disarmed: nothing is recorded and the
+// cost is one load per workgroup), buf[2 k + 1] = max end.
+enum { HL_ST_ENC1 = 0, HL_ST_MID_FWD, HL_ST_HEADS, HL_ST_DU, HL_ST_MID_BWD, HL_ST_ADAM_REST, HL_ST_ADAM_WY, HL_ST_N };
+unsigned long long* hl_stamp_slot(int slot);       // cabi.hip: nullptr when no buffer is set
+__device__ __forceinline__ bool hl_stamp_begin(unsigned long long* st) {
+    // thread 0 of the first 64 workgroups (dispatch starts there) takes the start; returns whether this launch is stamped
+    if (st == nullptr) return false;
+    const unsigned long long armed = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (armed == 0ull) return false;
+    if (blockIdx.x < 64 && blockIdx.y == 0) atomicMin(st, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    return true;
+}
+__device__ __forceinline__ void hl_stamp_end(unsigned long long* st) {
+    atomicMax(st + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+// usage inside a kernel (uniform per workgroup, thread 0 only):
+//   const bool stamped = threadIdx.x == 0 && hl_stamp_begin(st);  ...  if (stamped) hl_stamp_end(st);
+
 void hl_set_error(const char* fmt, ...);
 
 // optional per-kernel HIP-event timing (hlvae_prof_enable / hlvae_prof_report); a no-op when disabled

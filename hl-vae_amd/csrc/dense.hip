@@ -1,7 +1,20 @@
 // Dense-layer kernels of the HL-VAE step (SURVEY.md section 8(a) rows B, C, D and their backward):
 // every product is the NT main loop of gemm_nt.h with a different LDS-staged epilogue.
 #include "gemm_nt.h"
+#include "gemm_dma.h"
 #include "adam.h"
+#include <stdlib.h>
+
+// which GEMM main loop the K % 64 == 0 launches use: 1 = LDS-DMA staged (gemm_dma.h, round 3), 0 = register staged (gemm_nt.h).
+// HL_GEMM_CORE=nt in the environment selects the old core (A/B runs on one box).
+int g_hl_gemm_dma = -1;
+static bool hl_use_dma() {
+    if (g_hl_gemm_dma < 0) {
+        const char* e = getenv("HL_GEMM_CORE");
+        g_hl_gemm_dma = (e != nullptr && e[0] == 'n') ? 0 : 1;
+    }
+    return g_hl_gemm_dma != 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // tile helpers: the fp32 tile sits in LDS as Cs[BM][CLD]
@@ -100,7 +113,8 @@ template <int BK>
 __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
                                                           float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
                                                           float b1, float b2, float eps, float gscale, unsigned ticket_total,
-                                                          float* __restrict__ Gflat, long flat_lo4, long flat_n4) {
+                                                          float* __restrict__ Gflat, long flat_lo4, long flat_n4, unsigned long long* stamp) {
+    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
     using G = GemmNT<64, 64, BK, 2, 2>;
     constexpr int CLD = G::CLD;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
@@ -208,6 +222,120 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, fl
             if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
         }
     }
+    if (stamped) hl_stamp_end(stamp);
+}
+
+// The same kernel on the LDS-DMA core (gemm_dma.h).  The operand tiles need no staging registers, so ALL twelve float4 of
+// optimiser state a lane owns are requested before the product (the register-staged kernel above could afford the masters only:
+// m and v followed behind the product, and every workgroup of the single resident round then waited for them in phase), at
+// the same 4 workgroups per CU (LDS 32 KB: two 16 KB operand buffers, the fp32 tile aliases them).
+template <int NBUF>
+__global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam_dma(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
+                                                              float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
+                                                              float b1, float b2, float eps, float gscale, unsigned ticket_total,
+                                                              float* __restrict__ Gflat, long flat_lo4, long flat_n4, unsigned long long* stamp) {
+    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
+    using G = GemmDMA<64, 64, 2, 2, NBUF>;
+    constexpr int CLD = G::CLD;
+    __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k)
+        if (k < g.n && (int)blockIdx.x >= g.p[k].tile0) pi = k;
+    const AdamGemmProb& q = g.p[pi];
+    const int lid = pi == 0 ? xcd_remap(blockIdx.x, q.tiles_m * q.tiles_n) : (int)blockIdx.x - q.tile0;
+    const int m0 = (lid / q.tiles_n) * 64, n0 = (lid % q.tiles_n) * 64;
+    const int M = q.M, N = q.N;
+    const int c4 = (threadIdx.x & 15) * 4, rq = threadIdx.x >> 4;         // 16 float4 per tile row, 16 rows per pass
+    float4 p[4], m[4], v[4];
+    int o[4];
+    bool in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gr = m0 + rq + 16 * i;
+        long base = -1;
+        if (n0 + c4 < N) {
+            if (q.band <= 0) {
+                if (gr < M) base = q.off + (long)(q.rowmap != nullptr ? q.rowmap[gr] : gr) * N;
+            } else if (gr < q.band_rows) {
+                base = q.off + (long)gr * N;
+            } else if (gr >= q.band && gr < q.band + q.band_rows) {
+                base = q.off2 + (long)(gr - q.band) * N;
+            }
+        }
+        in[i] = base >= 0;
+        o[i] = (int)(in[i] ? base + n0 + c4 : q.off);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = *reinterpret_cast<const float4*>(P + o[i]);
+        m[i] = *reinterpret_cast<const float4*>(M1 + o[i]);
+        v[i] = *reinterpret_cast<const float4*>(M2 + o[i]);
+    }
+    typename G::Acc acc;
+    G::zero(acc);
+    G::run(q.A, q.lda, q.B, q.ldb, m0, n0, M, N, 0, g.K, smem, acc);
+    G::to_lds(acc, smem);
+    float* Cs = reinterpret_cast<float*>(smem);
+    const AdamScalars a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = rq + 16 * i;
+        const float4 gr4 = *reinterpret_cast<const float4*>(Cs + r * CLD + c4);
+        p[i].x = adam_one(p[i].x, gr4.x, m[i].x, v[i].x, a);
+        p[i].y = adam_one(p[i].y, gr4.y, m[i].y, v[i].y, a);
+        p[i].z = adam_one(p[i].z, gr4.z, m[i].z, v[i].z, a);
+        p[i].w = adam_one(p[i].w, gr4.w, m[i].w, v[i].w, a);
+        if (in[i]) {
+            *reinterpret_cast<float4*>(P + o[i]) = p[i];
+            *reinterpret_cast<float4*>(M1 + o[i]) = m[i];
+            *reinterpret_cast<float4*>(M2 + o[i]) = v[i];
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(p[i].x) | ((uint32_t)f2bf(p[i].y) << 16);
+            pk.y = (uint32_t)f2bf(p[i].z) | ((uint32_t)f2bf(p[i].w) << 16);
+            *reinterpret_cast<uint2*>(q.sh + (size_t)(m0 + r) * q.ldd + n0 + c4) = pk;
+        }
+        *reinterpret_cast<float4*>(Cs + r * CLD + c4) = in[i] ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (q.shT != nullptr) {                // block-uniform
+        __syncthreads();
+        const int r4 = (threadIdx.x & 15) * 4, cq = threadIdx.x >> 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cq + 16 * i;
+            if (m0 + r4 < M && n0 + c < N) {
+                uint2 pk;
+                pk.x = (uint32_t)f2bf(Cs[(r4 + 0) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 1) * CLD + c]) << 16);
+                pk.y = (uint32_t)f2bf(Cs[(r4 + 2) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 3) * CLD + c]) << 16);
+                *reinterpret_cast<uint2*>(q.shT + (size_t)(n0 + c) * q.ldT + m0 + r4) = pk;
+            }
+        }
+    }
+    if (flat_n4 > 0 && blockIdx.x == 0) {
+        float4* P4 = reinterpret_cast<float4*>(P) + flat_lo4;
+        float4* G4 = reinterpret_cast<float4*>(Gflat) + flat_lo4;
+        float4* M14 = reinterpret_cast<float4*>(M1) + flat_lo4;
+        float4* M24 = reinterpret_cast<float4*>(M2) + flat_lo4;
+        for (long i = threadIdx.x; i < flat_n4; i += HL_THREADS) {
+            float4 pp = P4[i], gr = G4[i], mm = M14[i], vv = M24[i];
+            pp.x = adam_one(pp.x, gr.x, mm.x, vv.x, a);
+            pp.y = adam_one(pp.y, gr.y, mm.y, vv.y, a);
+            pp.z = adam_one(pp.z, gr.z, mm.z, vv.z, a);
+            pp.w = adam_one(pp.w, gr.w, mm.w, vv.w, a);
+            P4[i] = pp;
+            M14[i] = mm;
+            M24[i] = vv;
+            G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (ticket_total != 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
+            if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
+        }
+    }
+    if (stamped) hl_stamp_end(stamp);
 }
 
 // up to three independent products of the same depth K in ONE launch (the weight gradients that become computable at
@@ -274,7 +402,8 @@ template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __restrict__ A, int lda,
                                                             const bf16_t* __restrict__ B, int ldb,
                                                             float* __restrict__ slab, int ldn, int M, int N, int K,
-                                                            int ksteps_per_split, int tiles_m, int tiles_n, int S) {
+                                                            int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp) {
+    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
     using G = GemmNT<BM, BN, BK, WM, WN>;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
     // all tiles of one K-slice run on one XCD: the slice of A and of B is pulled into that L2 once
@@ -294,7 +423,43 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __rest
     for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
         const int r = idx / BN, c = idx % BN;
         if (m0 + r < M && n0 + c < N) out[(size_t)(m0 + r) * ldn + n0 + c] = Cs[r * G::CLD + c];
-    }
+    }    if (stamped) hl_stamp_end(stamp);
+}
+
+// split-K partial products on the LDS-DMA core (K % 64 == 0)
+template <int BM, int BN, int WM, int WN, int NBUF>
+__global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
+                                                                int ldb, float* __restrict__ slab, int ldn, int M, int N, int K,
+                                                                int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp) {
+    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
+    using G = GemmDMA<BM, BN, WM, WN, NBUF>;
+    __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
+    const int tiles = tiles_m * tiles_n;
+    const int lid = xcd_remap(blockIdx.x, tiles * S);
+    const int s = lid / tiles, tl = lid % tiles;
+    const int m0 = (tl / tiles_n) * BM, n0 = (tl % tiles_n) * BN;
+    const int kb = s * ksteps_per_split * 64;
+    int ke = kb + ksteps_per_split * 64;
+    if (ke > K) ke = K;
+    typename G::Acc acc;
+    G::zero(acc);
+    G::run(A, lda, B, ldb, m0, n0, M, N, kb, ke, smem, acc);
+    G::to_lds(acc, smem);
+    const float* Cs = reinterpret_cast<const float*>(smem);
+    float* out = slab + (size_t)s * M * ldn;
+    // one float4 per lane (the slab rows are 16-byte aligned: ldn % 4 == 0 is checked by the launcher)
+    constexpr int C4 = BN / 4;
+    for (int idx = threadIdx.x; idx < BM * C4; idx += HL_THREADS) {
+        const int r = idx / C4, c = (idx % C4) * 4;
+        if (m0 + r < M && n0 + c < N) {
+            const float4 v = make_float4(Cs[r * G::CLD + c], Cs[r * G::CLD + c + 1], Cs[r * G::CLD + c + 2], Cs[r * G::CLD + c + 3]);
+            if (n0 + c + 4 <= N) *reinterpret_cast<float4*>(out + (size_t)(m0 + r) * ldn + n0 + c) = v;
+            else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+                for (int t = 0; t < 4 && n0 + c + t < N; ++t) out[(size_t)(m0 + r) * ldn + n0 + c + t] = e[t];
+            }
+        }
+    }    if (stamped) hl_stamp_end(stamp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -418,10 +583,13 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
     g.tiles_total = t;
     HL_PROF(label, s);
     const int grid = t;
-    if (g.K % 64 == 0)
-        k_gemm_adam<64><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4);
+    unsigned long long* stamp = hl_stamp_slot(g.n == 1 ? HL_ST_ADAM_WY : HL_ST_ADAM_REST);
+    if (g.K % 64 == 0 && hl_use_dma())
+        k_gemm_adam_dma<2><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp);
+    else if (g.K % 64 == 0)
+        k_gemm_adam<64><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp);
     else
-        k_gemm_adam<32><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4);
+        k_gemm_adam<32><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp);
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -467,7 +635,11 @@ int hl_launch_gemm_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, fl
     HL_REQUIRE(per * (S - 1) < ksteps, HLVAE_ESHAPE, "splitk: S=%d leaves an empty split for %d k-steps", S, ksteps);
     const int tm = (M + 63) / 64, tn = (N + 63) / 64;
     HL_PROF(label, s);
-    k_gemm_splitk<64, 64, 64, 2, 2><<<tm * tn * S, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per, tm, tn, S);
+    unsigned long long* stamp = label[0] == 'e' ? hl_stamp_slot(HL_ST_ENC1) : (label[0] == 'd' && label[1] == 'U' && label[2] == '_' ? hl_stamp_slot(HL_ST_DU) : nullptr);
+    if (hl_use_dma() && ldn % 4 == 0)
+        k_gemm_splitk_dma<64, 64, 2, 2, 3><<<tm * tn * S, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per, tm, tn, S, stamp);
+    else
+        k_gemm_splitk<64, 64, 64, 2, 2><<<tm * tn * S, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per, tm, tn, S, stamp);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -463,7 +463,8 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dyT, int Bp, float* __restrict__ logpx,
     float* __restrict__ logpx_miss, float* __restrict__ rowpart, float* __restrict__ pfull, int X,
     float* __restrict__ xhat, int B, int want_grad, const float* __restrict__ ysrc, int ldys, long long* __restrict__ clk,
-    int logvar) {
+    int logvar, unsigned long long* stamp) {
+    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
 #define HL_CLK(i) do { if (clk != nullptr && (threadIdx.x & 63) == 0) clk[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12 + (i)] = clock64(); } while (0)
     HL_CLK(0);
     // ysrc != nullptr: convolutional decoder -- the tile of y_grouped comes from the second ConvTranspose (csrc/conv.hip,
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
         if (v == 0 && gr < Bp) rowpart[(size_t)tn * Bp + gr] = gr < B ? s : 0.f;
     }
     HL_CLK(5);
-    if (!want_grad) return;
+    if (!want_grad) { if (stamped) hl_stamp_end(stamp); return; }
     // d Y^T [NY][Bp] straight from this thread's own cells of the tile (written by the head functions above: no barrier):
     // four consecutive rows of one column = one 8-byte store, and the column sums d by on the way
     if (!conv && d < D) {
@@ -713,6 +714,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
         for (int q = 0; q < 16; q += 2) { s0 += src[q * 16]; s1 += src[q * 16 + 16]; }
         out[(size_t)n * NTV + vv] = s0 + s1;
     }
+    if (stamped) hl_stamp_end(stamp);
     HL_CLK(11);
 #undef HL_CLK
 }
@@ -1010,7 +1012,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
         k_y_heads<YDv, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_sorted_dev, ws->P, ws->hgpart, d.o_by,  \
                                                           ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, \
                                                           d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing,       \
-                                                          ws->rowpart, pf, d.Theta, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY, clk, d.Theta != d.X)
+                                                          ws->rowpart, pf, d.Theta, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY, clk, d.Theta != d.X, hl_stamp_slot(HL_ST_HEADS))
         if (d.y_dim == 3) HL_LAUNCH_HEADS_Y(3, 64, 8);          // other y_dim (config/hlvae_config_file.txt: y_dim): all class counts up to 8
         else if (d.y_dim == 8) HL_LAUNCH_HEADS_Y(8, 64, 8);
         else if (p->kmax <= 3) HL_LAUNCH_HEADS(3);

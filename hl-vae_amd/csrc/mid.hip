@@ -65,8 +65,10 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     float* __restrict__ mu, float* __restrict__ lv, float* __restrict__ z, bf16_t* __restrict__ zb,
     bf16_t* __restrict__ zbT, int L, double* __restrict__ klpart,
     const bf16_t* __restrict__ wd, int hdp, int h_d, const float* __restrict__ bd, bf16_t* __restrict__ u_out,
-    bf16_t* __restrict__ uT_out, int B, const bf16_t* __restrict__ xin, int K1p, const bf16_t* __restrict__ w1) {
+    bf16_t* __restrict__ uT_out, int B, const bf16_t* __restrict__ xin, int K1p, const bf16_t* __restrict__ w1,
+    unsigned long long* stamp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
     const int lda = hep + 8;                                     // bf16 elements
     bf16_t* Ta = reinterpret_cast<bf16_t*>(smem);                // [16][hep+8]
     const int cmax = (hdp > 2 * LP ? hdp : 2 * LP) + 1;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         pk.x = (uint32_t)f2bf(Ct[r * cmax + c4]) | ((uint32_t)f2bf(Ct[r * cmax + c4 + 1]) << 16);
         pk.y = (uint32_t)f2bf(Ct[r * cmax + c4 + 2]) | ((uint32_t)f2bf(Ct[r * cmax + c4 + 3]) << 16);
         *reinterpret_cast<uint2*>(u_out + (size_t)(m0 + r) * hdp + c4) = pk;
-    }
+    }    if (stamped) hl_stamp_end(stamp);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -264,8 +266,9 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     bf16_t* __restrict__ dmlT_out, float* __restrict__ gbmu, float* __restrict__ gblv,
     const bf16_t* __restrict__ wmlT, int hep, int h_e, const bf16_t* __restrict__ t, bf16_t* __restrict__ dtT_out,
     float* __restrict__ gb1, int B, bf16_t* __restrict__ dt_out, const bf16_t* __restrict__ dyin, int NYp,
-    const bf16_t* __restrict__ wyT, float* __restrict__ zero_ptr, long zero_n4) {
+    const bf16_t* __restrict__ wyT, float* __restrict__ zero_ptr, long zero_n4, unsigned long long* stamp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
     // (the weight-gradient GEMMs that follow on this stream add split-K slices with atomics: their output region is cleared
     //  here instead of by a memset node on the critical path, 5.7 us in the replayed graph)
     for (long i = (long)blockIdx.x * MID_THREADS + threadIdx.x; i < zero_n4; i += (long)gridDim.x * MID_THREADS)
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
         }
         s = xor32_sum(xor16_sum(s));                             // the 4 row groups of a column
         if (lane < 16 && col < h_e) atomicAdd(gb1 + col, s);
-    }
+    }    if (stamped) hl_stamp_end(stamp);
 }
 
 static size_t mid_fwd_smem(int Lp, int hep, int hdp) {
@@ -500,7 +503,7 @@ int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
             ws->slab, ws->splitk_enc, Bp, d.hep, d.h_e, ws->P + d.o_b1, ws->t, ws->tT, ws->wmls, ws->P + d.o_bmu,       \
             ws->P + d.o_blv, sample ? eps : nullptr, ws->eps, sample ? ws->rng : nullptr, rng_off, ws->mu, ws->lv,     \
             ws->z, ws->zb, ws->zbT, d.L, ws->klpart, ws->wds, d.hd0p, d.h_d0, ws->P + d.o_bd, ws->u0, ws->u0T, B,       \
-            xin, d.K1p, ws->w1s);                                                                                      \
+            xin, d.K1p, ws->w1s, hl_stamp_slot(HL_ST_MID_FWD));                                                          \
     }
     // fewer than 128 sixteen-row workgroups (batches below 2048 rows) leave most CUs idle: eight rows per workgroup then
     // (four rows measured too: 0.1585 vs 0.1567 ms/step at 512 rows)
@@ -533,7 +536,7 @@ int hl_launch_mid_bwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
         k_mid_bwd_fused<LPv, MRv><<<Bp / MRv, MID_THREADS, smem, s>>>(                                                    \
             ws->slab, S, Bp, d.hd0p, d.h_d0, ws->u0, ws->duT, ws->G + d.o_bd, ws->wdTs, ws->eps, ws->lv,             \
             ws->mu, g_mu, g_lv, kl_w, d.L, ws->dmlT, ws->G + d.o_bmu, ws->G + d.o_blv, ws->wmlTs, d.hep, d.h_e, ws->t, \
-            ws->dtT, ws->G + d.o_b1, B, (d.conv || d.n_xe > 0) ? ws->dt : nullptr, dyin, d.NYlp, ws->wyTs, zero_ptr, zero_n / 4); \
+            ws->dtT, ws->G + d.o_b1, B, (d.conv || d.n_xe > 0) ? ws->dt : nullptr, dyin, d.NYlp, ws->wyTs, zero_ptr, zero_n / 4, hl_stamp_slot(HL_ST_MID_BWD)); \
     }
     const int mr = Bp / MID_ROWS < 128 ? 8 : 16;
     if (d.Lp == 32) { if (mr == 8) HL_MB(32, 8) else HL_MB(32, 16) }

@@ -188,6 +188,14 @@ class SubjectBatchSampler:
     def __len__(self):
         return len(self._bounds())
 
+    @property
+    def max_rows(self) -> int:
+        """upper bound of the rows any batch of THIS rank can have (whatever the shuffle): the largest number of subjects a batch
+        gives this rank (a folded tail included) times the longest subjects -- what ELBOTrainer(max_batch=...) must cover"""
+        n_sub = max(-(-(hi - lo) // self.world) for lo, hi in self._bounds())
+        lens = sorted((len(r) for r in self.rows_of), reverse=True)
+        return int(sum(lens[:n_sub]))
+
     def batches(self) -> Iterator[Batch]:
         r = np.arange(self.P)
         if self.shuffle:

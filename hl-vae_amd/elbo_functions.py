@@ -391,8 +391,9 @@ class GPPriorHIP:
                        iB=e(S, L, T, T), K0s=e(S, L, T, T), part=e(S, L, 4),
                        g_mu=torch.empty(B, L, dtype=torch.float32, device=dev), g_lv=torch.empty(B, L, dtype=torch.float32, device=dev))
             self._bufs[key] = buf
-            while len(self._bufs) > 8:
-                self._bufs.pop(next(iter(self._bufs)))
+            # (never evicted: a captured HIP graph has these addresses baked in -- dropping the oldest geometry once a ninth
+            #  appeared let a later replay of an earlier graph read and write freed memory.  One entry costs ~5 L B M fp64:
+            #  8 MB at the shipped configuration; data with many distinct (rows, subjects, T) geometries pays that per geometry.)
         if self._mm is None:
             L, M = self.L, self.M
             f64 = dict(dtype=torch.float64, device=dev)

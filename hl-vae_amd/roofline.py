@@ -183,3 +183,67 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None, P_
     roof["kernels_us_per_step"] = {k: round(v["us_per_step"], 2) for k, v in sorted(table.items(), key=lambda kv: -kv[1]["us_per_step"])}
     roof["sum_kernels_us_per_step"] = round(sum(v["us_per_step"] for v in table.values()), 2)
     return roof
+
+
+# labels of the stamp slots (csrc/common.h HL_ST_*, include/hlvae_hip.h hlvae_stamp_buffer)
+STAMP_LABELS = ("enc1_splitk", "mid_fwd_fused", "y_heads_loglik", "dU_splitk", "mid_bwd_fused", "dW1_dWd_dWmu_adam", "dWy_adam")
+
+
+def measure_in_step(stamps, one_step, n=24):
+    """Durations of the stamped kernels INSIDE the step as it is timed (the replayed HIP graph, side queues busy): arm the
+    slots, run one step (`one_step()`: a single-step graph replay or an eager step), read {first workgroup start, last workgroup
+    end} of every stamped kernel (10 ns ticks of s_memrealtime).  Returns label -> {"start_us" (from the step's first stamped
+    kernel), "dur_us"} medians over n steps, or None when nothing was stamped."""
+    import numpy as np
+    import torch
+    nsl = stamps.numel() // 2
+    arm = torch.zeros_like(stamps)
+    arm[0::2] = -1                                   # ~0 as uint64: armed; second word (max end) 0
+    rec = []
+    for _ in range(n):
+        stamps.copy_(arm)
+        torch.cuda.synchronize()
+        one_step()
+        torch.cuda.synchronize()
+        v = stamps.cpu().numpy().astype(np.uint64).reshape(nsl, 2)
+        rec.append(v)
+    stamps.zero_()                                   # disarmed again
+    torch.cuda.synchronize()
+    out = {}
+    armed = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for k in range(min(nsl, len(STAMP_LABELS))):
+        st, du = [], []
+        for v in rec:
+            live = [int(x[0]) for x in v if x[0] != armed and x[1] != 0]
+            if v[k][0] == armed or v[k][1] == 0 or not live:
+                continue
+            t0 = min(live)
+            st.append((int(v[k][0]) - t0) * 0.01)
+            du.append((int(v[k][1]) - int(v[k][0])) * 0.01)
+        if du:
+            out[STAMP_LABELS[k]] = {"start_us": round(float(np.median(st)), 2), "dur_us": round(float(np.median(du)), 2)}
+    return out or None
+
+
+def add_in_step(roof, in_step, model, ms_per_step):
+    """roofline.in_step: the dominant kernel priced on its duration inside the timed step (beside the kernel-alone figure of the
+    eager pass); roofline.step: the whole step on SURVEY.md 8(d)'s algorithmic bytes (32 B per parameter: bf16 weights read by
+    the forward and the backward pass, fp32 gradient, master / m / v read and written)."""
+    pn = int(model._arena_size)
+    step_bytes = 32 * pn
+    ach = step_bytes / (ms_per_step * 1e-3) / 1e9
+    roof["step"] = {"algorithmic_bytes": step_bytes, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "note": "SURVEY.md 8(d): 32 B x parameters per step, independent of the batch"}
+    if not in_step:
+        return
+    roof["in_step_timeline_us"] = in_step
+    k = roof.get("kernel")
+    if k in in_step and in_step[k]["dur_us"] > 0:
+        dur = in_step[k]["dur_us"]
+        if roof["bound"] == "hbm":
+            a = roof["algorithmic_per_launch"] / (dur * 1e-6) / 1e9
+        else:
+            a = roof["algorithmic_per_launch"] / (dur * 1e-6) / 1e12
+        roof["in_step"] = {"kernel": k, "avg_us": dur, "achieved": a, "frac": a / roof["peak"],
+                           "how": "first-workgroup start to last-workgroup end (s_memrealtime stamps) inside the replayed step"}
+        roof["frac_in_step"] = a / roof["peak"]

@@ -74,10 +74,13 @@ class ShardedAdam:
         # slice are rebuilt.  The padding rows h_e .. hep-1 fall into the (zero) slack behind the copy.
         # (not with extra encoder layers: their backward pass also reads the TRANSPOSED shadow of that Linear, which is rebuilt
         # together with the row-major one)
-        self._w1_alias = (not model.conv) and int(d.n_xe) == 0 and int(d.Xe) == int(d.Xep)
+        # (nor with extra decoder layers: the arena then continues [... W1 | extra decoder weights | Wy], and the padding rows of the
+        #  aliased shadow would land on the bf16 copy of those weights instead of on zero slack)
+        self._w1_alias = (not model.conv) and int(d.n_xe) == 0 and int(d.n_xd) == 0 and int(d.Xe) == int(d.Xep)
         slack = (int(d.hep) - int(d.h_e)) * int(d.Xep) + 64 if self._w1_alias else 0
         self.state = ShardedState(dp, self.plan, dev, slack=slack)
         if self._w1_alias:
+            assert int(d.o_w1) + int(d.h_e) * int(d.Xe) == self.plan.slices[-1].hi, "the first encoder Linear must end its slice"
             self.plan.slices[-1].which &= ~0x02
             self._alias_w1(first=True)
         model._master_sync = self.sync_masters
@@ -175,6 +178,12 @@ class ELBOTrainer:
             raise ValueError("the fused optimiser step freezes _log_vy_real / _log_vy_pos together (vy_fixed) and trains every other "
                              "parameter, as the reference does (HLVAE.py:209-216)")
         self.opt = FusedAdam(model, lr=lr) if dp is None else ShardedAdam(model, dp, lr=lr)
+        if dp is not None and dp.world > 1:
+            # a re-allocation rebuilds the bf16 shadows from the fp32 masters, which on this rank are current for its OWN slices
+            # only; bringing them up to date is a collective, and ranks do not see the same batch sizes -- so the workspace must be
+            # large enough from the start (max_batch >= the sampler's largest batch, folded tail included)
+            model._grow_forbidden = ("data-parallel run: the workspace cannot grow after the trainer is built; construct ELBOTrainer "
+                                     "with max_batch >= the largest batch of the sampler (datafeed.SubjectBatchSampler.max_rows)")
         dev, L = model.device, model.z_dim
         self._graphs = {}
         self._wy_dbuf = False        # y_layer shadows double-buffered (only inside an even chain of captured steps)
@@ -241,7 +250,10 @@ class ELBOTrainer:
         m = self.model
         lib = _lib.load()
         B = rows.shape[0]
-        m._ensure_device_state(B)
+        # the workspace is sized HERE for this batch and for the prefetched one (the sampler folds a short tail into the batch before
+        # it, so a larger-than-nominal batch is a normal event): growing it in the middle of the step would hand the backward pass
+        # the buffers the forward pass did not write
+        m._ensure_device_state(max(B, prefetch_rows.shape[0] if prefetch_rows is not None else 0))
         m._packed_key = None
         ws, s = C.byref(m._ws), m._stream()
         if prefetch_rows is not None and m.conv:
@@ -291,7 +303,7 @@ class ELBOTrainer:
         multi = self.dp is not None and self.dp.world > 1
         if feed_next is not None and not multi:   # deferred: the backward pass queues it on its side stream (hlvae_feed_prefetch)
             nds, nrows = feed_next
-            m._ensure_device_state(nrows.shape[0])
+            m._require_capacity(nrows.shape[0])
             _lib.check(lib.hlvae_feed_prefetch(m._plan_handle, C.byref(m._ws_alt), _lib.ptr(nds.values), _lib.ptr(nds.mask),
                                                _lib.ptr(nrows), nrows.shape[0], s), "feed_prefetch")
             self._pf_ref = feed_next
@@ -300,7 +312,7 @@ class ELBOTrainer:
             # of ours, so that this small all-reduce is the FIRST collective of the step on RCCL's queue and the next step starts
             # at its first GEMM instead of behind a blocking exchange
             nds, nrows = feed_next
-            m._ensure_device_state(nrows.shape[0])
+            m._require_capacity(nrows.shape[0])
             main = torch.cuda.current_stream(m.device)
             self._pf_stream.wait_stream(main)
             m._swap_input_buffers()
@@ -323,11 +335,14 @@ class ELBOTrainer:
             if dbuf:
                 m._set_wy_double_buffer(True)
                 ws = C.byref(m._ws)
-            _lib.check(lib.hlvae_backward_adam(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), B, _lib.ptr(o.m1),
-                                               _lib.ptr(o.m2), _lib.ptr(o.step_count), C.c_float(o.lr), C.c_float(o.betas[0]),
-                                               C.c_float(o.betas[1]), C.c_float(o.eps), C.c_float(1.0), s), "backward_adam")
+            try:
+                _lib.check(lib.hlvae_backward_adam(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), B, _lib.ptr(o.m1),
+                                                   _lib.ptr(o.m2), _lib.ptr(o.step_count), C.c_float(o.lr), C.c_float(o.betas[0]),
+                                                   C.c_float(o.betas[1]), C.c_float(o.eps), C.c_float(1.0), s), "backward_adam")
+            finally:
+                if dbuf:
+                    m._set_wy_double_buffer(False)       # (also when the call failed: later eager steps must not write the spare pair)
             if dbuf:
-                m._set_wy_double_buffer(False)
                 m._flip_wy_shadows()
             m.mark_shadows_fresh()
         else:
@@ -463,6 +478,23 @@ class ELBOTrainer:
             self._wy_dbuf = False
         self._graphs[key] = g
         return g
+
+    def reset_after_failed_capture(self):
+        """A capture that raised leaves host-side bookkeeping mid-step: y_layer's double-buffer pointers set, deferred side work
+        recorded against events of the dead capture, an all-gather handle pending.  Bring everything back to the eager steady
+        state (the next eager step then runs as if nothing had been captured)."""
+        m = self.model
+        self._wy_dbuf = False
+        if not m.conv:
+            m._set_wy_double_buffer(False)
+        if hasattr(self.opt, "_pending"):
+            self.opt._pending = None
+        torch.cuda.synchronize()
+        _lib.load().hlvae_reset_pending(m._plan_handle)
+        m._packed_key = None
+        m._grad_region_clean = False                 # a half-captured backward may or may not have consumed the atomic region
+        m._sync_shadows(force=True)                  # shadows from the fp32 masters (whichever shadow pair is current)
+        torch.cuda.synchronize()
 
     def _capture_kw(self):
         """several ranks: the process group's watchdog thread queries events while this thread captures -- only THIS thread's
