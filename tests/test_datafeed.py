@@ -69,3 +69,21 @@ def test_subject_sampler_semantics_and_sharding():
         assert pa == pb
         sa, sb = set(ids[ra]), set(ids[rb])
         assert not (sa & sb) and len(sa) + len(sb) == pa
+
+
+def test_sampler_max_rows_covers_every_batch():
+    """ELBOTrainer(max_batch=sampler.max_rows) must never need a larger workspace: the bound holds for every shuffle, every rank,
+    ragged subject lengths and a folded tail."""
+    from hlvae_amd.datafeed import SubjectBatchSampler
+    rng = np.random.default_rng(3)
+    lens = rng.integers(3, 21, size=23)                       # 23 subjects of 3..20 rows
+    ids = np.repeat(np.arange(23), lens)
+    for world in (1, 2, 4):
+        for rank in range(world):
+            sm = SubjectBatchSampler(ids, subjects_per_batch=8, shuffle=True, seed=5, rank=rank, world=world)
+            seen = 0
+            for _ in range(6):                                # six epochs, six shuffles
+                for b in sm.batches():
+                    seen = max(seen, len(b.rows))
+                    assert len(b.rows) <= sm.max_rows
+            assert seen > 0 and sm.max_rows <= int(np.sort(lens)[::-1][:-(-(8 + 7) // world)].sum())

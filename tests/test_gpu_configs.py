@@ -1,7 +1,7 @@
 """GPU parity at the sizes of BASELINE.json configs[2..4] (round-2 additions):
 
-  * D4 at 1024 and 4096 rows -- every D4 batch of >= 896 rows runs the 128-row instance of the head kernel
-    (csrc/heads.hip: hl_launch_y_heads `big`) and the 16-row tiles of the fused middle kernels above 2048 rows:
+  * D4 at 1024 and 4096 rows -- above 2048 rows the fused middle kernels use 16-row tiles, the head kernel gives every XCD its
+    own row blocks and y_layer's optimiser launch moves ahead of dU_splitk (csrc/heads.hip, csrc/cabi.hip):
     forward, every gradient tensor and one fused ELBOTrainer step from the compact feed against the fp64 oracle;
   * the full config-5 step: HIP decoder + GPPriorHIP on a 1024-row batch of 51 whole subjects x 20 rows + 4 rows of a
     52nd, against hlvae_oracle + gp_oracle;
@@ -152,7 +152,10 @@ def test_d4_large_batch_against_oracle(B, hid_e, hid_d):
         d_gpu = (sd2[k].detach().double().cpu() - state[k].double()).numpy()
         bad = np.abs(d_gpu - d_ref) > 1e-3                    # first Adam step: +-lr wherever the gradient keeps its sign
         _report(key + "_step", **{"flip__" + k: bad.mean()})
-        assert bad.mean() < 0.02, (k, bad.mean())
+        # per-tensor bound = 3 x the measured share: 4e-3 on the one-hidden-layer model; the decoder layers of the deeper trunk sit
+        # below two more bf16 ReLU layers whose gates flip (1.6e-2 measured on d_layers.0.weight)
+        deep_dec = len(hid_d) > 1 and k.startswith("d_layers.")
+        assert bad.mean() <= (5e-2 if deep_dec else 1.2e-2), (k, bad.mean())
     # per-step metrics (row M) ran beside the backward pass: finite, inside [0, 1] for the discrete variables
     err = tr.err.cpu().numpy()
     assert np.isfinite(err).all() and err.min() >= 0.0
@@ -314,8 +317,8 @@ def test_gp_prior_hip_against_reference_fixture(golden_dir):
 @pytest.mark.parametrize("B", [512, 1024])
 def test_conv_backward_against_oracle(B):
     """convolutional model (what config/hlvae_config_file.txt:51 selects) at 512 and 1024 rows, hidden 500, latent 32:
-    ELBO, loss and EVERY gradient tensor against the fp64 oracle on the same weights and noise.  1024 rows runs the 128-row
-    instance of the head kernel in its `ysrc` (second transposed convolution) mode."""
+    ELBO, loss and EVERY gradient tensor against the fp64 oracle on the same weights and noise (the head kernel runs in its
+    `ysrc` mode: the tile of y_grouped comes from the second transposed convolution)."""
     import hlvae_oracle as orc
     from hlvae_amd.HLVAE import HLVAE
     dev = _dev()
@@ -736,3 +739,51 @@ def test_narrow_model_paths_match_the_general_ones():
     assert abs(a[0]["nll"] - b[0]["nll"]) <= 1e-5 * abs(b[0]["nll"])
     assert rel_err(a[1], b[1]) < 2e-3, rel_err(a[1], b[1])         # parameters after four steps (Adam: +-lr per sign flip of a tiny gradient)
     assert torch.isfinite(a[3]).all()
+
+
+@pytest.mark.gpu
+def test_workspace_grows_at_the_top_of_the_step_not_inside_it():
+    """The sampler folds a short tail into the batch before it, so a prefetched batch larger than max_batch is a normal event.
+    The workspace is sized for it at the TOP of the step that prefetches it (growing it between the forward and the backward pass
+    handed the backward pass freshly zeroed buffers); the noise stream continues across the re-allocation.  Same trajectory as a
+    trainer whose workspace was large enough from the start."""
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.datafeed import CompactDataset
+    from hlvae_amd.training import ELBOTrainer
+    from tests_common import MIX_SPEC
+    dev = _dev()
+    src = synthetic.make_tabular(n_rows=320, T=8, seed=19, spec=MIX_SPEC)
+    dims = [src.cov_dim_ext, [32], 8, [32], 5]
+    dsd = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
+    small = torch.arange(0, 96, dtype=torch.int32, device=dev)
+    large = torch.arange(96, 296, dtype=torch.int32, device=dev)          # 200 rows: beyond a 128-row workspace
+    eps = [torch.randn(n, dims[2], generator=torch.Generator().manual_seed(5 + i)).to(dev) for i, n in enumerate((96, 200, 96))]
+
+    def run(max_batch):
+        torch.manual_seed(4)
+        model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=max_batch, materialize_samples=False).to(dev)
+        tr = ELBOTrainer(model, P_total=40, kl="normal", max_batch=max_batch)
+        with torch.no_grad():
+            model._ws_t["rng"][0] = 12345                       # same Philox seed in both runs
+        out = []
+        tr.prime_rows(dsd, small)
+        tr.step_rows(dsd, small, 12, eps=eps[0], prefetch_rows=large, prepacked=True)      # grows here (max_batch 128), before the forward
+        out.append(float(tr.scalars()["nll_sum"]))
+        tr.step_rows(dsd, large, 25, eps=eps[1], prefetch_rows=small, prepacked=True)
+        out.append(float(tr.scalars()["nll_sum"]))
+        tr.step_rows(dsd, small, 12, eps=eps[2], prepacked=True)
+        out.append(float(tr.scalars()["nll_sum"]))
+        torch.cuda.synchronize()
+        return out, model._arena.detach().clone(), int(model._ws.Bp_max), int(model._ws_t["rng"][0].item())
+
+    a, b = run(128), run(256)
+    assert a[2] >= 256 and b[2] == 256 and a[3] == b[3] == 12345
+    for x, y in zip(a[0], b[0]):
+        assert abs(x - y) <= 1e-6 * abs(y), (a[0], b[0])
+    assert rel_err(a[1], b[1]) < 1e-6
+    # a batch that was NOT announced at the top of the step cannot be squeezed in afterwards
+    torch.manual_seed(4)
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=128, materialize_samples=False).to(dev)
+    model._ensure_device_state(96)
+    with pytest.raises(RuntimeError, match="does not fit the workspace"):
+        model._require_capacity(200)

@@ -26,6 +26,9 @@ from tests_common import MIX_SPEC, load_mix_case, max_abs_err, rel_err   # noqa:
 
 ELBO_RTOL = 1e-4
 GRAD_RTOL = 2.5e-2
+FLIP_TOL = 1.2e-2       # share of a tensor's cells whose first Adam updates differ by more than lr (a tiny gradient changed sign under
+                        # bf16 rounding): 3 x the 4e-3 measured on the dense tensors (gpurun_out/parity_report*.json)
+GP_STATE_TOL = 1e-2     # m_new / H_new after one natural-gradient step from the device's (bf16-product) mu / log_var
 REPORT = {}
 
 
@@ -278,9 +281,13 @@ def test_training_steps_against_oracle(golden_dir):
         orc.adam_step(params, [p.grad for p in params], m1, m2, it + 1)
         nll_ref.append(float(nll))
         kl_ref = float(kl)
+    _report("training_steps", **{f"nll_rel_{i}": abs(a - b) / abs(b) for i, (a, b) in enumerate(zip(nll_gpu, nll_ref))},
+            kl_rel=abs(kl_gpu - kl_ref) / abs(kl_ref))
     for a, b in zip(nll_gpu, nll_ref):
-        assert abs(a - b) <= 2e-3 * abs(b), (nll_gpu, nll_ref)
-    assert abs(kl_gpu - kl_ref) <= 2e-2 * abs(kl_ref) + 1e-3
+        assert abs(a - b) <= ELBO_RTOL * abs(b), (nll_gpu, nll_ref)
+    # named exception: the KL of the TRAINED fixture (81.5) is a function of mu / log_var, which leave the encoder through two bf16
+    # products (measured 1e-3 of its value)
+    assert abs(kl_gpu - kl_ref) <= 5e-3 * abs(kl_ref) + 1e-3
     sd = dict(model.named_parameters())
     for k, p in zip(names, params):
         delta_ref = (p.detach() - state[k].double()).numpy()
@@ -290,7 +297,8 @@ def test_training_steps_against_oracle(golden_dir):
         # Adam's first steps move every parameter by about lr * sign(g): compare the updates, tolerating the
         # few entries whose tiny gradient changes sign under bf16 rounding
         bad = np.abs(delta - delta_ref) > 1e-3
-        assert bad.mean() < 0.02, (k, bad.mean())
+        _report("training_steps", **{"flip__" + k: float(bad.mean())})
+        assert bad.mean() <= FLIP_TOL, (k, bad.mean())
 
 
 def test_input_stage_prefetch_matches_serial(golden_dir):
@@ -409,7 +417,9 @@ def test_gp_prior_training_step_against_oracle(golden_dir, impl):
                                                      True, 2, 1e-6)
     nll = om.loss_function(out["log_p_x"]).sum()
     (nll * 80 / 8 + kld.sum()).backward()
-    assert abs(nll_gpu - float(nll)) <= 1e-3 * abs(float(nll))
+    _report("gp_prior_training_step", nll_rel=abs(nll_gpu - float(nll)) / abs(float(nll)), kld_rel=abs(kld_gpu - float(kld)) / abs(float(kld)))
+    assert abs(nll_gpu - float(nll)) <= ELBO_RTOL * abs(float(nll))
+    # named exception: the bound is evaluated at the device's mu / log_var (bf16 products behind them)
     assert abs(kld_gpu - float(kld)) <= 1e-3 * abs(float(kld)) + 1e-2
     # Adam's first update is -lr * sign(g): the encoder weights feel the GP gradient through mu / log_var
     w = dict(model.named_parameters())["mean_layer.0.weight"].detach().double().cpu()
@@ -418,7 +428,8 @@ def test_gp_prior_training_step_against_oracle(golden_dir, impl):
     big = gref.abs() > 0.05 * gref.abs().max()
     assert (torch.sign(delta[big]) == -torch.sign(gref[big])).double().mean() > 0.97
     m_ref, H_ref = gpo.natural_gradient_update(m0.cpu(), H0.cpu(), gm.detach(), gH.detach(), 0.01)
-    assert rel_err(gp.m.cpu(), m_ref) < 1e-2 and rel_err(gp.H.cpu(), H_ref) < 1e-2
+    _report("gp_prior_training_step", m_new=rel_err(gp.m.cpu(), m_ref), H_new=rel_err(gp.H.cpu(), H_ref))
+    assert rel_err(gp.m.cpu(), m_ref) < GP_STATE_TOL and rel_err(gp.H.cpu(), H_ref) < GP_STATE_TOL
 
 
 @pytest.mark.parametrize("B", [1, 17, 130, 401])
@@ -449,7 +460,7 @@ def test_ragged_batch_sizes_against_oracle(B):
         assert torch.isnan(out[4]).any()
         return
     _report(f"ragged_{B}", loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), mu=max_abs_err(out[1], ref["mu"]))
-    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss)), (float(loss), float(ref_loss))
     assert max_abs_err(out[1], ref["mu"]) < 3e-2
     # the device-side KL(q || N(0, I)) scalar (one partial per 16-row tile) against the same sum over the device mu / log_var
     kl_dev = float(model._ws_t["scal"][1])
@@ -460,7 +471,7 @@ def test_ragged_batch_sizes_against_oracle(B):
     sd = dict(model.named_parameters())
     for k in ("y_layer.0.weight", "VAE_encoder_common_layers.0.weight", "d_layers.0.bias", "obs_layer.1.weight"):
         _report(f"ragged_{B}_grads", **{k: rel_err(sd[k].grad, st[k].grad)})
-        assert rel_err(sd[k].grad, st[k].grad) < 5e-2, k
+        assert rel_err(sd[k].grad, st[k].grad) < GRAD_RTOL, k
 
 
 def test_tabular_config4_batch4096_against_oracle():
@@ -824,14 +835,16 @@ def test_other_y_dim_against_oracle(y_dim):
     loss.backward()
     torch.cuda.synchronize()
     ref, ref_loss, st = _oracle_step(src, rows, dims, state, eps, 1.3)
-    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    _report(f"y_dim_{y_dim}", loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
+    assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss)), (float(loss), float(ref_loss))
     e = np.abs(out[3].detach().double().cpu().numpy() - ref["log_p_x"].detach().numpy())
     assert np.all(e <= 5e-2 + 3e-2 * np.abs(ref["log_p_x"].detach().numpy()))
     sd = dict(model.named_parameters())
     for k in ("y_layer.0.weight", "y_layer.0.bias", "d_layers.0.bias", "obs_layer.0.weight", "obs_layer.3.weight_mean",
               "obs_layer.2.weight_region", "obs_layer.2.weight_thresholds"):
         if k in sd and st[k].grad is not None:
-            assert rel_err(sd[k].grad, st[k].grad) < 5e-2, k
+            _report(f"y_dim_{y_dim}_grads", **{k: rel_err(sd[k].grad, st[k].grad)})
+            assert rel_err(sd[k].grad, st[k].grad) < GRAD_RTOL, k
 
 
 def test_wide_categorical_and_ordinal_against_oracle():
@@ -853,17 +866,19 @@ def test_wide_categorical_and_ordinal_against_oracle():
     loss.backward()
     torch.cuda.synchronize()
     ref, ref_loss, st = _oracle_step(src, rows, dims, state, eps, 0.7)
-    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    _report("wide_k", loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
+    assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss)), (float(loss), float(ref_loss))
     e = np.abs(out[3].detach().double().cpu().numpy() - ref["log_p_x"].detach().numpy())
     assert np.all(e <= 5e-2 + 3e-2 * np.abs(ref["log_p_x"].detach().numpy()))
     sd = dict(model.named_parameters())
     n = 0
     for k, p in sd.items():
         if k.startswith("obs_layer.") and st[k].grad is not None and st[k].grad.numel() and float(st[k].grad.abs().max()) > 0:
-            assert rel_err(p.grad, st[k].grad) < 5e-2, k
+            _report("wide_k_grads", **{k: rel_err(p.grad, st[k].grad)})
+            assert rel_err(p.grad, st[k].grad) < GRAD_RTOL, k
             n += 1
     assert n >= 8
-    assert rel_err(sd["VAE_encoder_common_layers.0.weight"].grad, st["VAE_encoder_common_layers.0.weight"].grad) < 5e-2
+    assert rel_err(sd["VAE_encoder_common_layers.0.weight"].grad, st["VAE_encoder_common_layers.0.weight"].grad) < GRAD_RTOL
     # two fused optimiser steps on the odd-width model against torch.optim.Adam on the same gradients
     from hlvae_amd.training import ELBOTrainer
     m2 = _model_from_state(src, dims, state)
@@ -929,11 +944,13 @@ def test_odd_layer_widths_against_oracle():
     loss.backward()
     torch.cuda.synchronize()
     ref, ref_loss, st = _oracle_step(src, rows, dims, state, eps, 1.1)
-    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    _report("odd_widths", loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
+    assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss)), (float(loss), float(ref_loss))
     sd = dict(model.named_parameters())
     for k in ("y_layer.0.weight", "VAE_encoder_common_layers.0.weight", "d_layers.0.weight", "mean_layer.0.weight",
               "log_var_layer.0.weight", "d_layers.0.bias", "mean_layer.0.bias"):
-        assert rel_err(sd[k].grad, st[k].grad) < 5e-2, k
+        _report("odd_widths_grads", **{k: rel_err(sd[k].grad, st[k].grad)})
+        assert rel_err(sd[k].grad, st[k].grad) < GRAD_RTOL, k
     tr = ELBOTrainer(_model_from_state(src, dims, state), P_total=10, kl="normal", max_batch=128)
     for _ in range(3):
         tr.step(data, mask, 10, eps=eps.to(dev))
