@@ -407,11 +407,14 @@ class HLVAE(nn.Module):
                                              None if order is None else order.ctypes.data_as(C.c_void_p)), "hlvae_plan_create")
             self._plan_handle = h
         Bp = _ru(max(B, 1), 128)
+        grew = False
         if self._ws is None or Bp > self._ws.Bp_max:
             if self._ws is not None and getattr(self, "_grow_forbidden", None):
                 raise RuntimeError(f"batch of {B} rows exceeds the workspace ({self._ws.Bp_max} rows): {self._grow_forbidden}")
+            grew = self._ws is not None
             self._alloc_workspace(max(Bp, _ru(self._max_batch, 128)))
         self._sync_shadows()
+        return grew          # True: every per-step buffer is new (a batch packed earlier is gone)
 
     def _require_capacity(self, B: int):
         """mid-step check: the workspace was sized at the top of the step (ELBOTrainer.step_rows); growing it now would swap the

@@ -126,19 +126,18 @@ struct hlvae_plan {
 // cost is one load per workgroup), buf[2 k + 1] = max end.
 enum { HL_ST_ENC1 = 0, HL_ST_MID_FWD, HL_ST_HEADS, HL_ST_DU, HL_ST_MID_BWD, HL_ST_ADAM_REST, HL_ST_ADAM_WY, HL_ST_N };
 unsigned long long* hl_stamp_slot(int slot);       // cabi.hip: nullptr when no buffer is set
-__device__ __forceinline__ bool hl_stamp_begin(unsigned long long* st) {
-    // thread 0 of the first 64 workgroups (dispatch starts there) takes the start; returns whether this launch is stamped
-    if (st == nullptr) return false;
-    const unsigned long long armed = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (armed == 0ull) return false;
-    if (blockIdx.x < 64 && blockIdx.y == 0) atomicMin(st, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    return true;
-}
-__device__ __forceinline__ void hl_stamp_end(unsigned long long* st) {
+// The hot path of a stamped kernel gains ONE scalar instruction: the start time is taken into SGPRs at the top
+// (HL_STAMP_T0), every memory operation of the stamp -- the armed check included -- happens at the very end of the workgroup,
+// off its critical path.  (A first form that read the armed word at the top of the kernel put a divergent branch and a
+// dependent global load in front of the prefetch loads of the streaming kernels.)
+#define HL_STAMP_T0() const unsigned long long hl_t0_ = __builtin_amdgcn_s_memrealtime()
+__device__ __forceinline__ void hl_stamp_commit(unsigned long long* st, unsigned long long t0) {
+    if (st == nullptr || threadIdx.x != 0 || threadIdx.y != 0) return;
+    if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;      // disarmed
+    atomicMin(st, t0);
     atomicMax(st + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
-// usage inside a kernel (uniform per workgroup, thread 0 only):
-//   const bool stamped = threadIdx.x == 0 && hl_stamp_begin(st);  ...  if (stamped) hl_stamp_end(st);
+#define HL_STAMP_END(st) hl_stamp_commit(st, hl_t0_)
 
 void hl_set_error(const char* fmt, ...);
 

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, fl
                                                           float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
                                                           float b1, float b2, float eps, float gscale, unsigned ticket_total,
                                                           float* __restrict__ Gflat, long flat_lo4, long flat_n4, unsigned long long* stamp) {
-    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
+    HL_STAMP_T0();
     using G = GemmNT<64, 64, BK, 2, 2>;
     constexpr int CLD = G::CLD;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, fl
             if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
         }
     }
-    if (stamped) hl_stamp_end(stamp);
+    HL_STAMP_END(stamp);
 }
 
 // The same kernel on the LDS-DMA core (gemm_dma.h).  The operand tiles need no staging registers, so ALL twelve float4 of
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam_dma(AdamGemmGroup g
                                                               float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
                                                               float b1, float b2, float eps, float gscale, unsigned ticket_total,
                                                               float* __restrict__ Gflat, long flat_lo4, long flat_n4, unsigned long long* stamp) {
-    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
+    HL_STAMP_T0();
     using G = GemmDMA<64, 64, 2, 2, NBUF>;
     constexpr int CLD = G::CLD;
     __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
@@ -250,13 +250,22 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam_dma(AdamGemmGroup g
     float4 p[4], m[4], v[4];
     int o[4];
     bool in[4];
+    // master rows of this lane's four tile rows: all four (unconditional, clamped) row-map loads are issued before the first is
+    // used -- inside the address computation each one was followed by its own wait, four dependent round trips in front of the
+    // optimiser state's loads
+    int mrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gr = m0 + rq + 16 * i;
+        mrow[i] = q.rowmap != nullptr ? q.rowmap[min(gr, M - 1)] : gr;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int gr = m0 + rq + 16 * i;
         long base = -1;
         if (n0 + c4 < N) {
             if (q.band <= 0) {
-                if (gr < M) base = q.off + (long)(q.rowmap != nullptr ? q.rowmap[gr] : gr) * N;
+                if (gr < M) base = q.off + (long)mrow[i] * N;
             } else if (gr < q.band_rows) {
                 base = q.off + (long)gr * N;
             } else if (gr >= q.band && gr < q.band + q.band_rows) {
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam_dma(AdamGemmGroup g
             if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
         }
     }
-    if (stamped) hl_stamp_end(stamp);
+    HL_STAMP_END(stamp);
 }
 
 // up to three independent products of the same depth K in ONE launch (the weight gradients that become computable at
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __rest
                                                             const bf16_t* __restrict__ B, int ldb,
                                                             float* __restrict__ slab, int ldn, int M, int N, int K,
                                                             int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp) {
-    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
+    HL_STAMP_T0();
     using G = GemmNT<BM, BN, BK, WM, WN>;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
     // all tiles of one K-slice run on one XCD: the slice of A and of B is pulled into that L2 once
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __rest
     for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
         const int r = idx / BN, c = idx % BN;
         if (m0 + r < M && n0 + c < N) out[(size_t)(m0 + r) * ldn + n0 + c] = Cs[r * G::CLD + c];
-    }    if (stamped) hl_stamp_end(stamp);
+    }    HL_STAMP_END(stamp);
 }
 
 // split-K partial products on the LDS-DMA core (K % 64 == 0)
@@ -431,7 +440,7 @@ template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                                 int ldb, float* __restrict__ slab, int ldn, int M, int N, int K,
                                                                 int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp) {
-    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
+    HL_STAMP_T0();
     using G = GemmDMA<BM, BN, WM, WN, NBUF>;
     __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
     const int tiles = tiles_m * tiles_n;
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk_dma(const bf16_t* __
                 for (int t = 0; t < 4 && n0 + c + t < N; ++t) out[(size_t)(m0 + r) * ldn + n0 + c + t] = e[t];
             }
         }
-    }    if (stamped) hl_stamp_end(stamp);
+    }    HL_STAMP_END(stamp);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     float* __restrict__ logpx_miss, float* __restrict__ rowpart, float* __restrict__ pfull, int X,
     float* __restrict__ xhat, int B, int want_grad, const float* __restrict__ ysrc, int ldys, long long* __restrict__ clk,
     int logvar, unsigned long long* stamp) {
-    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
+    HL_STAMP_T0();
 #define HL_CLK(i) do { if (clk != nullptr && (threadIdx.x & 63) == 0) clk[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12 + (i)] = clock64(); } while (0)
     HL_CLK(0);
     // ysrc != nullptr: convolutional decoder -- the tile of y_grouped comes from the second ConvTranspose (csrc/conv.hip,
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
         if (v == 0 && gr < Bp) rowpart[(size_t)tn * Bp + gr] = gr < B ? s : 0.f;
     }
     HL_CLK(5);
-    if (!want_grad) { if (stamped) hl_stamp_end(stamp); return; }
+    if (!want_grad) { HL_STAMP_END(stamp); return; }
     // d Y^T [NY][Bp] straight from this thread's own cells of the tile (written by the head functions above: no barrier):
     // four consecutive rows of one column = one 8-byte store, and the column sums d by on the way
     if (!conv && d < D) {
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
         for (int q = 0; q < 16; q += 2) { s0 += src[q * 16]; s1 += src[q * 16 + 16]; }
         out[(size_t)n * NTV + vv] = s0 + s1;
     }
-    if (stamped) hl_stamp_end(stamp);
+    HL_STAMP_END(stamp);
     HL_CLK(11);
 #undef HL_CLK
 }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     bf16_t* __restrict__ uT_out, int B, const bf16_t* __restrict__ xin, int K1p, const bf16_t* __restrict__ w1,
     unsigned long long* stamp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
+    HL_STAMP_T0();
     const int lda = hep + 8;                                     // bf16 elements
     bf16_t* Ta = reinterpret_cast<bf16_t*>(smem);                // [16][hep+8]
     const int cmax = (hdp > 2 * LP ? hdp : 2 * LP) + 1;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         pk.x = (uint32_t)f2bf(Ct[r * cmax + c4]) | ((uint32_t)f2bf(Ct[r * cmax + c4 + 1]) << 16);
         pk.y = (uint32_t)f2bf(Ct[r * cmax + c4 + 2]) | ((uint32_t)f2bf(Ct[r * cmax + c4 + 3]) << 16);
         *reinterpret_cast<uint2*>(u_out + (size_t)(m0 + r) * hdp + c4) = pk;
-    }    if (stamped) hl_stamp_end(stamp);
+    }    HL_STAMP_END(stamp);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     float* __restrict__ gb1, int B, bf16_t* __restrict__ dt_out, const bf16_t* __restrict__ dyin, int NYp,
     const bf16_t* __restrict__ wyT, float* __restrict__ zero_ptr, long zero_n4, unsigned long long* stamp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const bool stamped = threadIdx.x == 0 && hl_stamp_begin(stamp);
+    HL_STAMP_T0();
     // (the weight-gradient GEMMs that follow on this stream add split-K slices with atomics: their output region is cleared
     //  here instead of by a memset node on the critical path, 5.7 us in the replayed graph)
     for (long i = (long)blockIdx.x * MID_THREADS + threadIdx.x; i < zero_n4; i += (long)gridDim.x * MID_THREADS)
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
         }
         s = xor32_sum(xor16_sum(s));                             // the 4 row groups of a column
         if (lane < 16 && col < h_e) atomicAdd(gb1 + col, s);
-    }    if (stamped) hl_stamp_end(stamp);
+    }    HL_STAMP_END(stamp);
 }
 
 static size_t mid_fwd_smem(int Lp, int hep, int hdp) {

@@ -253,7 +253,8 @@ class ELBOTrainer:
         # the workspace is sized HERE for this batch and for the prefetched one (the sampler folds a short tail into the batch before
         # it, so a larger-than-nominal batch is a normal event): growing it in the middle of the step would hand the backward pass
         # the buffers the forward pass did not write
-        m._ensure_device_state(max(B, prefetch_rows.shape[0] if prefetch_rows is not None else 0))
+        if m._ensure_device_state(max(B, prefetch_rows.shape[0] if prefetch_rows is not None else 0)):
+            prepacked = False            # the re-allocation dropped the batch a previous step had packed: its input stage runs again, here
         m._packed_key = None
         ws, s = C.byref(m._ws), m._stream()
         if prefetch_rows is not None and m.conv:

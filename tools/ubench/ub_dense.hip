@@ -15,6 +15,7 @@ static char g_err[512];
 void hl_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); }
 void hl_prof_begin(const char*, hipStream_t) {}
 void hl_prof_end(hipStream_t) {}
+unsigned long long* hl_stamp_slot(int) { return nullptr; }
 extern int g_hl_gemm_dma;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
