@@ -256,7 +256,7 @@ def main():
     from hlvae_amd import _lib as _hl, roofline
     stamps = None
     if not a.no_in_step:
-        stamps = torch.zeros(2 * _hl.load().hlvae_stamp_slots(), dtype=torch.int64, device=dev)
+        stamps = torch.zeros(_hl.load().hlvae_stamp_words(), dtype=torch.int64, device=dev)
         _hl.load().hlvae_stamp_buffer(_hl.ptr(stamps))
     trainer = ELBOTrainer(model, P_total=P_total, kl=kl, gp=gp, max_batch=a.batch, dp=dp, metrics=True)
     ring = build_ring(src, a.batch, 4)

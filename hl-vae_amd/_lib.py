@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HLVAE_LIB_PATH", os.path.join(_HERE, "libhlvae_hip.so"))      # (override: diagnostic builds)
-ABI_VERSION = 29
+ABI_VERSION = 30
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -136,6 +136,7 @@ _SIGS = {
     "hlvae_gp_adam": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
     "hlvae_reset_pending": (C.c_int, [_vp]),
     "hlvae_stamp_slots": (C.c_int, []),
+    "hlvae_stamp_words": (C.c_int, []),
     "hlvae_stamp_buffer": (None, [_vp]),
     "hlvae_prof_enable": (None, [C.c_int]),
     "hlvae_prof_report": (C.c_int, [C.c_char_p, C.c_int]),

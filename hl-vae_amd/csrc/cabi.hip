@@ -82,13 +82,14 @@ void hl_prof_end(hipStream_t s) {
 }
 
 static unsigned long long* g_stamp_buf = nullptr;
-unsigned long long* hl_stamp_slot(int slot) { return g_stamp_buf != nullptr ? g_stamp_buf + 2 * slot : nullptr; }
+unsigned long long* hl_stamp_slot(int slot) { return g_stamp_buf != nullptr ? g_stamp_buf + 8 * HL_STAMP_SUB * slot : nullptr; }
 
 extern "C" {
 
 int hlvae_abi_version(void) { return HLVAE_ABI_VERSION; }
 
 int hlvae_stamp_slots(void) { return HL_ST_N; }
+int hlvae_stamp_words(void) { return 8 * HL_STAMP_SUB * HL_ST_N; }
 void hlvae_stamp_buffer(uint64_t* buf) { g_stamp_buf = reinterpret_cast<unsigned long long*>(buf); }
 
 void hlvae_prof_enable(int on) { g_prof_on = on != 0; }

@@ -122,8 +122,9 @@ struct hlvae_plan {
 // ---- in-graph kernel stamps (bench.py's "roofline.in_step"): when the host has handed the library a stamp buffer
 // (hlvae_stamp_buffer) BEFORE the step was launched / captured, the stamped kernels record the first start and the last end of
 // their workgroups on the 100 MHz s_memrealtime clock -- inside the replayed HIP graph, beside whatever else runs then, with no
-// extra graph node.  Slot layout: buf[2 k] = min start (armed by the host with ~0; 0 = disarmed: nothing is recorded and the
-// cost is one load per workgroup), buf[2 k + 1] = max end.
+// extra graph node.  Layout: kernel k owns HL_STAMP_SUB sub-slots of 8 words (one 64-byte line each) at buf[8 HL_STAMP_SUB k]:
+// word 0 = min start (armed by the host with ~0; sub-slot 0's word 0 = 0 disarms the kernel: nothing is recorded and the cost is
+// one load per workgroup), word 1 = max end; a workgroup uses sub-slot (block id mod HL_STAMP_SUB), the host folds them.
 enum { HL_ST_ENC1 = 0, HL_ST_MID_FWD, HL_ST_HEADS, HL_ST_DU, HL_ST_MID_BWD, HL_ST_ADAM_REST, HL_ST_ADAM_WY, HL_ST_N };
 unsigned long long* hl_stamp_slot(int slot);       // cabi.hip: nullptr when no buffer is set
 // The hot path of a stamped kernel gains ONE scalar instruction: the start time is taken into SGPRs at the top
@@ -131,11 +132,14 @@ unsigned long long* hl_stamp_slot(int slot);       // cabi.hip: nullptr when no 
 // off its critical path.  (A first form that read the armed word at the top of the kernel put a divergent branch and a
 // dependent global load in front of the prefetch loads of the streaming kernels.)
 #define HL_STAMP_T0() const unsigned long long hl_t0_ = __builtin_amdgcn_s_memrealtime()
+#define HL_STAMP_SUB 32          // sub-slots per kernel, each on a 64-byte line of its own (same-address atomics from ~1000 workgroups
+                                 // cost ~20 ns each and held the kernel's end back by 15-30 us); the host folds them
 __device__ __forceinline__ void hl_stamp_commit(unsigned long long* st, unsigned long long t0) {
     if (st == nullptr || threadIdx.x != 0 || threadIdx.y != 0) return;
-    if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;      // disarmed
-    atomicMin(st, t0);
-    atomicMax(st + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;      // disarmed (word 0 of sub-slot 0)
+    unsigned long long* sub = st + 8 * ((blockIdx.x + blockIdx.y * gridDim.x) & (HL_STAMP_SUB - 1));
+    if (blockIdx.x < 2 * HL_STAMP_SUB && blockIdx.y == 0) atomicMin(sub, t0);                     // (dispatch starts at the low ids)
+    atomicMax(sub + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 #define HL_STAMP_END(st) hl_stamp_commit(st, hl_t0_)
 

@@ -8,6 +8,11 @@
 // which GEMM main loop the K % 64 == 0 launches use: 1 = LDS-DMA staged (gemm_dma.h, round 3), 0 = register staged (gemm_nt.h).
 // HL_GEMM_CORE=nt in the environment selects the old core (A/B runs on one box).
 int g_hl_gemm_dma = -1;
+int g_hl_slab_nt = -1;
+static int hl_slab_nt() {       // HL_SLAB_NT=1: split-K slabs leave with non-temporal stores (A/B)
+    if (g_hl_slab_nt < 0) { const char* e = getenv("HL_SLAB_NT"); g_hl_slab_nt = (e != nullptr && e[0] == '1') ? 1 : 0; }
+    return g_hl_slab_nt;
+}
 static bool hl_use_dma() {
     if (g_hl_gemm_dma < 0) {
         const char* e = getenv("HL_GEMM_CORE");
@@ -439,7 +444,8 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __rest
 template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                                 int ldb, float* __restrict__ slab, int ldn, int M, int N, int K,
-                                                                int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp) {
+                                                                int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp,
+                                                                int nt_store) {
     HL_STAMP_T0();
     using G = GemmDMA<BM, BN, WM, WN, NBUF>;
     __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
@@ -462,7 +468,14 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk_dma(const bf16_t* __
         const int r = idx / C4, c = (idx % C4) * 4;
         if (m0 + r < M && n0 + c < N) {
             const float4 v = make_float4(Cs[r * G::CLD + c], Cs[r * G::CLD + c + 1], Cs[r * G::CLD + c + 2], Cs[r * G::CLD + c + 3]);
-            if (n0 + c + 4 <= N) *reinterpret_cast<float4*>(out + (size_t)(m0 + r) * ldn + n0 + c) = v;
+            if (n0 + c + 4 <= N) {
+                // nt: streaming (write-through) store -- the slab is read next by ANOTHER kernel, on whatever XCD its workgroups land:
+                // lines left dirty in this XCD's L2 only have to be written back at the kernel boundary
+                typedef __attribute__((ext_vector_type(4))) float f4v;
+                f4v vv = {v.x, v.y, v.z, v.w};
+                if (nt_store) __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(out + (size_t)(m0 + r) * ldn + n0 + c));
+                else *reinterpret_cast<float4*>(out + (size_t)(m0 + r) * ldn + n0 + c) = v;
+            }
             else {
                 const float e[4] = {v.x, v.y, v.z, v.w};
                 for (int t = 0; t < 4 && n0 + c + t < N; ++t) out[(size_t)(m0 + r) * ldn + n0 + c + t] = e[t];
@@ -646,7 +659,7 @@ int hl_launch_gemm_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, fl
     HL_PROF(label, s);
     unsigned long long* stamp = label[0] == 'e' ? hl_stamp_slot(HL_ST_ENC1) : (label[0] == 'd' && label[1] == 'U' && label[2] == '_' ? hl_stamp_slot(HL_ST_DU) : nullptr);
     if (hl_use_dma() && ldn % 4 == 0)
-        k_gemm_splitk_dma<64, 64, 2, 2, 3><<<tm * tn * S, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per, tm, tn, S, stamp);
+        k_gemm_splitk_dma<64, 64, 2, 2, 3><<<tm * tn * S, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per, tm, tn, S, stamp, hl_slab_nt());
     else
         k_gemm_splitk<64, 64, 64, 2, 2><<<tm * tn * S, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per, tm, tn, S, stamp);
     HL_LAUNCH_CHECK();

@@ -39,10 +39,11 @@ struct GemmDMA {
     static constexpr int TM = BM / WM, TN = BN / WN;
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile");
     static constexpr int FM = TM / 16, FN = TN / 16;
-    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    static_assert(BM % 8 == 0 && BN % 8 == 0, "8-row DMA pieces");
+    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     static constexpr int NINST = (BM + BN) / 8;              // wave-instructions (8 rows x 128 B = 1 KB each) per k-tile
-    static_assert(NINST % NW == 0, "tile rows must split evenly over the waves");
-    static constexpr int IPW = NINST / NW;                   // per wave
+    static constexpr int IPW = (NINST + NW - 1) / NW;        // per wave; every wave issues the SAME number (vmcnt counts them): the
+    static constexpr int STAGE = IPW * NW * 1024;            // pieces past the tile re-fetch its last rows into slack behind it
     static constexpr int AB_BYTES = NBUF * STAGE;
     static constexpr int CLD = CLDV ? CLDV : BN + 1;
     static constexpr int C_BYTES = BM * CLD * 4;
@@ -69,7 +70,7 @@ struct GemmDMA {
             const int q = wave + NW * j;                     // instruction index: rows 8 q .. 8 q + 7 of the stacked [A; B] tile
             const int rt = 8 * q + (lane >> 3);
             const bool isA = 8 * q < BM;                     // (wave-uniform: 8 | BM)
-            const int r = isA ? rt : rt - BM;
+            const int r = isA ? rt : min(rt - BM, BN - 1);   // (padding pieces, q >= NINST: the tile's last row again)
             const int c = (lane & 7) ^ ((r >> 1) & 7);       // chunk this lane fetches for LDS chunk position (lane & 7)
             s.p[j] = isA ? A + (size_t)min(m0 + r, M - 1) * lda + k_begin + c * 8
                          : B + (size_t)min(n0 + r, N - 1) * ldb + k_begin + c * 8;
@@ -111,13 +112,23 @@ struct GemmDMA {
     // (k_gemm_adam: its optimiser state) simply issue first; the wait for tile 0 then covers them, and the product runs while
     // the OTHER workgroups of the CU stream.
     // K range [k_begin, k_end) must be a multiple of 64 and in bounds.  Ends on a barrier (the LDS tiles may be reused).
+    struct NoHook { __device__ __forceinline__ void operator()() const {} };
     __device__ static __forceinline__ void run(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int m0,
                                                int n0, int M, int N, int k_begin, int k_end, char* smem, Acc& acc) {
+        run(A, lda, B, ldb, m0, n0, M, N, k_begin, k_end, smem, acc, NoHook(), NoHook());
+    }
+    // first_tile: called once behind the first tile's wait and barrier -- every vector-memory operation the caller issued
+    // BEFORE run() has completed by then (vmcnt retires in order), so an epilogue can park prefetched values in LDS there
+    // without a wait of its own; second_tile: the same one k-step later (for loads first_tile itself issued).
+    template <class Hook, class Hook2>
+    __device__ static __forceinline__ void run(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int m0,
+                                               int n0, int M, int N, int k_begin, int k_end, char* smem, Acc& acc, Hook first_tile,
+                                               Hook2 second_tile) {
         const int tid = threadIdx.x, lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int wm = wave / WN, wn = wave % WN;
         const int nk = (k_end - k_begin) / BK;
-        if (nk <= 0) return;
+        if (nk <= 0) { first_tile(); second_tile(); return; }
         Src s;
         src_init(s, A, lda, B, ldb, m0, n0, M, N, k_begin, wave, lane);
 #pragma unroll
@@ -135,6 +146,8 @@ struct GemmDMA {
             int nb = cur + NBUF - 1;
             nb = nb >= NBUF ? nb - NBUF : nb;
             if (nt < nk) issue(s, nt * BK, smem + nb * STAGE, wave);
+            if (kt == 0) first_tile();
+            if (kt == 1 || (kt == 0 && nk == 1)) second_tile();
             compute(smem + cur * STAGE, acc, lane, wm, wn);
             cur = cur + 1 == NBUF ? 0 : cur + 1;
         }

@@ -18,6 +18,7 @@
 // only where the mask is 1 -> dY and all head-parameter gradients are gated by the mask.
 #include <stdlib.h>
 #include "gemm_nt.h"
+#include "gemm_dma.h"
 
 #define HL_LOG2PI 1.8378770664093453f
 #define HL_ROW(rg, i) (4 * (rg) + ((i) & 3) + 64 * ((i) >> 2))
@@ -455,7 +456,9 @@ __device__ __forceinline__ int acc_dest(const hlvae_var& var, int n) {
     return -1;
 }
 
-template <int YD, int BM, int KMAX>
+// DMA: the U x Wy^T tile runs on the LDS-DMA core (gemm_dma.h, round 3: no staging registers, no ds_write pass, swizzled
+// conflict-free fragment reads, two 20 KB buffers instead of two 23 KB ones); false: the register-staged core of rounds 1-2
+template <int YD, int BM, int KMAX, bool DMA = true>
 __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) void k_y_heads(
     const bf16_t* __restrict__ U, int ldu, const bf16_t* __restrict__ Wy, int K, const hlvae_var* __restrict__ vars,
     const float* __restrict__ P, float* __restrict__ hgpart, long o_by, const float* __restrict__ norm, int n_stat,
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     // ysrc != nullptr: convolutional decoder -- the tile of y_grouped comes from the second ConvTranspose (csrc/conv.hip,
     // bias included) instead of the y_layer GEMM; d Y leaves in row-major layout only and d by is not ours
     constexpr int BN = 16 * YD;
-    using Gm = GemmNT<BM, BN, 64, 4, 1, 3, BN + 4>;
+    using Gm = typename std::conditional<DMA, GemmDMA<BM, BN, 4, 1, 2, BN + 4>, GemmNT<BM, BN, 64, 4, 1, 3, BN + 4>>::type;
     constexpr int CLD = Gm::CLD;
     constexpr int RPT = BM / 16;                                  // rows per thread
     constexpr int NHEAD = HeadAcc<YD, KMAX>::N;                   // head-parameter gradient accumulators of a variable
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     // after the epilogue: [C tile with dY | acc[n][thread] image]
     constexpr int POST_BYTES = BM * CLD * 4 + NACC * RST * 4;
     constexpr int SMEM_TOTAL = Gm::SMEM_BYTES + SCR_BYTES > POST_BYTES ? Gm::SMEM_BYTES + SCR_BYTES : POST_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_TOTAL];
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM_TOTAL];
     // 1-D grid, XCD-aware.  Up to 8 row blocks (512 rows): the row blocks that share one 16-variable panel of Wy get
     // consecutive logical ids and therefore one XCD's L2; U (<= 0.5 MB) stays in every L2.  Larger batches: U no longer fits
     // beside the streams of a 4 MB L2 and was re-read for every panel an XCD owns (PMC at 4096 rows: 630 MB fetched + written
@@ -1008,19 +1011,24 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
         const int grid = NT * (Bp / 64);
         long long* clk = hl_heads_clk_buffer(grid);
 #define HL_LAUNCH_HEADS(KMv) HL_LAUNCH_HEADS_Y(5, 64, KMv)
-#define HL_LAUNCH_HEADS_Y(YDv, BMv, KMv)                                                                               \
-        k_y_heads<YDv, BMv, KMv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_sorted_dev, ws->P, ws->hgpart, d.o_by,  \
+#define HL_LAUNCH_HEADS_Y(YDv, BMv, KMv) HL_LAUNCH_HEADS_V(YDv, BMv, KMv, true)
+#define HL_LAUNCH_HEADS_V(YDv, BMv, KMv, DMAv)                                                                         \
+        k_y_heads<YDv, BMv, KMv, DMAv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_sorted_dev, ws->P, ws->hgpart, d.o_by,  \
                                                           ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, \
                                                           d.NYp, ws->dyT, Bp, ws->log_p_x, ws->log_p_x_missing,       \
                                                           ws->rowpart, pf, d.Theta, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY, clk, d.Theta != d.X, hl_stamp_slot(HL_ST_HEADS))
         if (d.y_dim == 3) HL_LAUNCH_HEADS_Y(3, 64, 8);          // other y_dim (config/hlvae_config_file.txt: y_dim): all class counts up to 8
         else if (d.y_dim == 8) HL_LAUNCH_HEADS_Y(8, 64, 8);
         else if (p->kmax <= 3) HL_LAUNCH_HEADS(3);
-        else if (p->kmax <= 5) HL_LAUNCH_HEADS(5);
+        else if (p->kmax <= 5) {          // (the D4 / tabular instance keeps the register-staged form too: HL_GEMM_CORE=nt, A/B on one box)
+            static const bool nt = [] { const char* e = getenv("HL_GEMM_CORE"); return e != nullptr && e[0] == 'n'; }();
+            if (nt) HL_LAUNCH_HEADS_V(5, 64, 5, false); else HL_LAUNCH_HEADS(5);
+        }
         else if (p->kmax <= 8) HL_LAUNCH_HEADS(8);
         else HL_LAUNCH_HEADS(16);                                // 9..16 classes: one instance
 #undef HL_LAUNCH_HEADS
 #undef HL_LAUNCH_HEADS_Y
+#undef HL_LAUNCH_HEADS_V
     }
     HL_LAUNCH_CHECK();
     return 0;

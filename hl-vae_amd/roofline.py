@@ -196,30 +196,39 @@ def measure_in_step(stamps, one_step, n=24):
     kernel), "dur_us"} medians over n steps, or None when nothing was stamped."""
     import numpy as np
     import torch
-    nsl = stamps.numel() // 2
-    arm = torch.zeros_like(stamps)
-    arm[0::2] = -1                                   # ~0 as uint64: armed; second word (max end) 0
+    nk = len(STAMP_LABELS)
+    sub = stamps.numel() // (8 * nk)                 # sub-slots per kernel (csrc/common.h HL_STAMP_SUB), 8 words each
+    arm = torch.zeros_like(stamps).view(nk, sub, 8)
+    arm[:, :, 0] = -1                                # ~0 as uint64: armed; word 1 (max end) 0
+    arm = arm.view(-1)
     rec = []
     for _ in range(n):
         stamps.copy_(arm)
         torch.cuda.synchronize()
         one_step()
         torch.cuda.synchronize()
-        v = stamps.cpu().numpy().astype(np.uint64).reshape(nsl, 2)
-        rec.append(v)
+        v = stamps.cpu().numpy().astype(np.uint64).reshape(nk, sub, 8)
+        armed = np.uint64(0xFFFFFFFFFFFFFFFF)
+        row = []
+        for k in range(nk):
+            st = v[k, :, 0]
+            en = v[k, :, 1]
+            st = st[st != armed]
+            en = en[en != 0]
+            row.append((int(st.min()), int(en.max())) if len(st) and len(en) else None)
+        rec.append(row)
     stamps.zero_()                                   # disarmed again
     torch.cuda.synchronize()
     out = {}
-    armed = np.uint64(0xFFFFFFFFFFFFFFFF)
-    for k in range(min(nsl, len(STAMP_LABELS))):
+    for k in range(nk):
         st, du = [], []
-        for v in rec:
-            live = [int(x[0]) for x in v if x[0] != armed and x[1] != 0]
-            if v[k][0] == armed or v[k][1] == 0 or not live:
+        for row in rec:
+            live = [r[0] for r in row if r is not None]
+            if row[k] is None or not live:
                 continue
             t0 = min(live)
-            st.append((int(v[k][0]) - t0) * 0.01)
-            du.append((int(v[k][1]) - int(v[k][0])) * 0.01)
+            st.append((row[k][0] - t0) * 0.01)
+            du.append((row[k][1] - row[k][0]) * 0.01)
         if du:
             out[STAMP_LABELS[k]] = {"start_us": round(float(np.median(st)), 2), "dur_us": round(float(np.median(du)), 2)}
     return out or None

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 29
+#define HLVAE_ABI_VERSION 30
 #define HLVAE_STAT_CHUNKS 16
 /* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
 #define HLVAE_HEAD_ACC 95
@@ -432,15 +432,18 @@ int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* 
 void hlvae_prof_enable(int on);
 int  hlvae_prof_report(char* buf, int buflen);
 
-/* In-graph kernel stamps (bench.py "roofline.in_step"; no counterpart in the reference): buf = device uint64 [2 * hlvae_stamp_slots()],
- * or NULL to switch the feature off (the default).  Set BEFORE the step is launched or captured: the pointer is a kernel argument.
- * Slot k (0 enc1 split-K, 1 fused middle fwd, 2 head kernel, 3 dU split-K, 4 fused middle bwd, 5 grouped weight gradient + Adam,
- * 6 y_layer weight gradient + Adam) holds {first workgroup start, last workgroup end} in 10 ns ticks of s_memrealtime; the host
- * arms a slot by writing ~0 into its first word and 0 into its second, and disarms it with 0 in the first (nothing is recorded). */
 /* forget the side work that hlvae_step_metrics / hlvae_decoder_fwd(want_grad = 2) / hlvae_feed_prefetch deferred and that no
  * hlvae_backward* / hlvae_join has queued yet (host bookkeeping only; used after a HIP-graph capture that failed mid-step) */
 int  hlvae_reset_pending(const hlvae_plan* p);
+
+/* In-graph kernel stamps (bench.py "roofline.in_step"; no counterpart in the reference): buf = device uint64 [hlvae_stamp_words()],
+ * or NULL to switch the feature off (the default).  Set BEFORE the step is launched or captured: the pointer is a kernel argument.
+ * Kernel k (0 enc1 split-K, 1 fused middle fwd, 2 head kernel, 3 dU split-K, 4 fused middle bwd, 5 grouped weight gradient + Adam,
+ * 6 y_layer weight gradient + Adam) owns 32 sub-slots of 8 words at buf[256 k]: word 0 = earliest workgroup start, word 1 = latest
+ * workgroup end, in 10 ns ticks of s_memrealtime (a workgroup uses sub-slot block-id mod 32; fold them on the host).  Arm: word 0
+ * of every sub-slot = ~0, word 1 = 0.  Disarm: word 0 of sub-slot 0 = 0 (nothing is recorded). */
 int  hlvae_stamp_slots(void);
+int  hlvae_stamp_words(void);
 void hlvae_stamp_buffer(uint64_t* buf);
 
 /* generic bf16 NT GEMM  C[M][N] (fp32, ldc) = A[M][K] * B[N][K]^T, exposed for unit tests */
