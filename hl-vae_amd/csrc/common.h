@@ -127,18 +127,23 @@ struct hlvae_plan {
 // one load per workgroup), word 1 = max end; a workgroup uses sub-slot (block id mod HL_STAMP_SUB), the host folds them.
 enum { HL_ST_ENC1 = 0, HL_ST_MID_FWD, HL_ST_HEADS, HL_ST_DU, HL_ST_MID_BWD, HL_ST_ADAM_REST, HL_ST_ADAM_WY, HL_ST_N };
 unsigned long long* hl_stamp_slot(int slot);       // cabi.hip: nullptr when no buffer is set
-// The hot path of a stamped kernel gains ONE scalar instruction: the start time is taken into SGPRs at the top
-// (HL_STAMP_T0), every memory operation of the stamp -- the armed check included -- happens at the very end of the workgroup,
-// off its critical path.  (A first form that read the armed word at the top of the kernel put a divergent branch and a
-// dependent global load in front of the prefetch loads of the streaming kernels.)
-#define HL_STAMP_T0() const unsigned long long hl_t0_ = __builtin_amdgcn_s_memrealtime()
+// Cost when no buffer is set: none (uniform null check).  Buffer set but disarmed: thread 0 of the first 32 workgroups reads one
+// cached word at the top, thread 0 of every workgroup one at the end.  Armed: those 32 take s_memrealtime at the top, every
+// workgroup at its end + one or two atomics on its sub-slot.  (Measured the hard way, round 3: s_memrealtime executed by every wave
+// at the top of k_gemm_adam -- or one uncached same-address load per workgroup there -- made that kernel 29 -> 46 us: 3264 waves
+// queue on one counter / one memory channel in front of the prefetch loads the kernel lives on.)
 #define HL_STAMP_SUB 32          // sub-slots per kernel, each on a 64-byte line of its own (same-address atomics from ~1000 workgroups
                                  // cost ~20 ns each and held the kernel's end back by 15-30 us); the host folds them
+#define HL_STAMP_T0(st)                                                                                                          \
+    unsigned long long hl_t0_ = 0ull;                                                                                            \
+    if ((st) != nullptr && blockIdx.x < HL_STAMP_SUB && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) {               \
+        if (*(const volatile unsigned long long*)(st) != 0ull) hl_t0_ = (unsigned long long)__builtin_amdgcn_s_memrealtime();   \
+    }
 __device__ __forceinline__ void hl_stamp_commit(unsigned long long* st, unsigned long long t0) {
     if (st == nullptr || threadIdx.x != 0 || threadIdx.y != 0) return;
-    if (__hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;      // disarmed (word 0 of sub-slot 0)
+    if (*(const volatile unsigned long long*)st == 0ull) return;                                   // disarmed (word 0 of sub-slot 0)
     unsigned long long* sub = st + 8 * ((blockIdx.x + blockIdx.y * gridDim.x) & (HL_STAMP_SUB - 1));
-    if (blockIdx.x < 2 * HL_STAMP_SUB && blockIdx.y == 0) atomicMin(sub, t0);                     // (dispatch starts at the low ids)
+    if (t0 != 0ull) atomicMin(sub, t0);
     atomicMax(sub + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 #define HL_STAMP_END(st) hl_stamp_commit(st, hl_t0_)

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, fl
                                                           float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
                                                           float b1, float b2, float eps, float gscale, unsigned ticket_total,
                                                           float* __restrict__ Gflat, long flat_lo4, long flat_n4, unsigned long long* stamp) {
-    HL_STAMP_T0();
+    HL_STAMP_T0(stamp);
     using G = GemmNT<64, 64, BK, 2, 2>;
     constexpr int CLD = G::CLD;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
@@ -230,18 +230,23 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, fl
     HL_STAMP_END(stamp);
 }
 
-// The same kernel on the LDS-DMA core (gemm_dma.h).  The operand tiles need no staging registers, so ALL twelve float4 of
-// optimiser state a lane owns are requested before the product (the register-staged kernel above could afford the masters only:
-// m and v followed behind the product, and every workgroup of the single resident round then waited for them in phase), at
-// the same 4 workgroups per CU (LDS 32 KB: two 16 KB operand buffers, the fp32 tile aliases them).
-template <int NBUF>
-__global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam_dma(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
-                                                              float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
-                                                              float b1, float b2, float eps, float gscale, unsigned ticket_total,
-                                                              float* __restrict__ Gflat, long flat_lo4, long flat_n4, unsigned long long* stamp) {
-    HL_STAMP_T0();
-    using G = GemmDMA<64, 64, 2, 2, NBUF>;
+// The same kernel on the LDS-DMA core (gemm_dma.h).  The operand tiles need no staging registers, so ALL the optimiser state a
+// lane owns is requested before the product (the register-staged kernel above could afford the masters only: m and v followed
+// behind the product, and every workgroup of the single resident round then waited for them in phase).
+// BM x BN = tile shape (template): 64 x 64 is one resident round for the D4 matrices (816 / 664 tiles on 1024 slots); smaller
+// tiles trade operand re-reads through L2 for several rounds per CU, i.e. workgroups in different phases -- loads, product,
+// stores -- at the same time instead of the whole chip reading, then multiplying, then writing (ubench: tools/ubench).
+template <int BM, int BN, int NBUF, int MINW>
+__global__ __launch_bounds__(HL_THREADS, MINW) void k_gemm_adam_dma(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
+                                                                 float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
+                                                                 float b1, float b2, float eps, float gscale, unsigned ticket_total,
+                                                                 float* __restrict__ Gflat, long flat_lo4, long flat_n4,
+                                                                 unsigned long long* stamp) {
+    HL_STAMP_T0(stamp);
+    using G = GemmDMA<BM, BN, 2, 2, NBUF, BN + 4>;
     constexpr int CLD = G::CLD;
+    constexpr int C4 = BN / 4, RPP = HL_THREADS / C4, NP = BM / RPP;          // float4 per tile row, rows per pass, passes
+    static_assert(BM % RPP == 0 && NP >= 1, "tile rows split over the passes");
     __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
     int pi = 0;
 #pragma unroll
@@ -249,24 +254,23 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam_dma(AdamGemmGroup g
         if (k < g.n && (int)blockIdx.x >= g.p[k].tile0) pi = k;
     const AdamGemmProb& q = g.p[pi];
     const int lid = pi == 0 ? xcd_remap(blockIdx.x, q.tiles_m * q.tiles_n) : (int)blockIdx.x - q.tile0;
-    const int m0 = (lid / q.tiles_n) * 64, n0 = (lid % q.tiles_n) * 64;
+    const int m0 = (lid / q.tiles_n) * BM, n0 = (lid % q.tiles_n) * BN;
     const int M = q.M, N = q.N;
-    const int c4 = (threadIdx.x & 15) * 4, rq = threadIdx.x >> 4;         // 16 float4 per tile row, 16 rows per pass
-    float4 p[4], m[4], v[4];
-    int o[4];
-    bool in[4];
-    // master rows of this lane's four tile rows: all four (unconditional, clamped) row-map loads are issued before the first is
-    // used -- inside the address computation each one was followed by its own wait, four dependent round trips in front of the
-    // optimiser state's loads
-    int mrow[4];
+    const int c4 = (threadIdx.x % C4) * 4, rq = threadIdx.x / C4;
+    float4 p[NP], m[NP], v[NP];
+    int o[NP];
+    bool in[NP];
+    // master rows of this lane's tile rows: all the (unconditional, clamped) row-map loads are issued before the first is used --
+    // inside the address computation each one was followed by its own wait: dependent round trips in front of the state's loads
+    int mrow[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gr = m0 + rq + 16 * i;
+    for (int i = 0; i < NP; ++i) {
+        const int gr = m0 + rq + RPP * i;
         mrow[i] = q.rowmap != nullptr ? q.rowmap[min(gr, M - 1)] : gr;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gr = m0 + rq + 16 * i;
+    for (int i = 0; i < NP; ++i) {
+        const int gr = m0 + rq + RPP * i;
         long base = -1;
         if (n0 + c4 < N) {
             if (q.band <= 0) {
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam_dma(AdamGemmGroup g
         o[i] = (int)(in[i] ? base + n0 + c4 : q.off);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NP; ++i) {
         p[i] = *reinterpret_cast<const float4*>(P + o[i]);
         m[i] = *reinterpret_cast<const float4*>(M1 + o[i]);
         v[i] = *reinterpret_cast<const float4*>(M2 + o[i]);
@@ -293,8 +297,8 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam_dma(AdamGemmGroup g
     float* Cs = reinterpret_cast<float*>(smem);
     const AdamScalars a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = rq + 16 * i;
+    for (int i = 0; i < NP; ++i) {
+        const int r = rq + RPP * i;
         const float4 gr4 = *reinterpret_cast<const float4*>(Cs + r * CLD + c4);
         p[i].x = adam_one(p[i].x, gr4.x, m[i].x, v[i].x, a);
         p[i].y = adam_one(p[i].y, gr4.y, m[i].y, v[i].y, a);
@@ -309,14 +313,17 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam_dma(AdamGemmGroup g
             pk.y = (uint32_t)f2bf(p[i].z) | ((uint32_t)f2bf(p[i].w) << 16);
             *reinterpret_cast<uint2*>(q.sh + (size_t)(m0 + r) * q.ldd + n0 + c4) = pk;
         }
+        // (each lane rewrites only the four cells it has just read: no barrier needed before the write)
         *reinterpret_cast<float4*>(Cs + r * CLD + c4) = in[i] ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (q.shT != nullptr) {                // block-uniform
         __syncthreads();
-        const int r4 = (threadIdx.x & 15) * 4, cq = threadIdx.x >> 4;
+        // transposed shadow: lane -> (column, 4 consecutive rows), one 8-byte store (rows outside the matrix: zeros = padding)
+        constexpr int R4 = BM / 4, CPP = HL_THREADS / R4;                       // row quads per column, columns per pass
+        const int r4 = (threadIdx.x % R4) * 4, cq = threadIdx.x / R4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = cq + 16 * i;
+        for (int i = 0; i < BN / CPP; ++i) {
+            const int c = cq + CPP * i;
             if (m0 + r4 < M && n0 + c < N) {
                 uint2 pk;
                 pk.x = (uint32_t)f2bf(Cs[(r4 + 0) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 1) * CLD + c]) << 16);
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __rest
                                                             const bf16_t* __restrict__ B, int ldb,
                                                             float* __restrict__ slab, int ldn, int M, int N, int K,
                                                             int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp) {
-    HL_STAMP_T0();
+    HL_STAMP_T0(stamp);
     using G = GemmNT<BM, BN, BK, WM, WN>;
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
     // all tiles of one K-slice run on one XCD: the slice of A and of B is pulled into that L2 once
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk_dma(const bf16_t* __
                                                                 int ldb, float* __restrict__ slab, int ldn, int M, int N, int K,
                                                                 int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp,
                                                                 int nt_store) {
-    HL_STAMP_T0();
+    HL_STAMP_T0(stamp);
     using G = GemmDMA<BM, BN, WM, WN, NBUF>;
     __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
     const int tiles = tiles_m * tiles_n;
@@ -578,9 +585,30 @@ bool hl_gemm_adam_ok(int M, int N, int K, bool may_be_small) {
            (may_be_small || hl_wgrad_ksplit((long)((M + 63) / 64) * ((N + 63) / 64), K) == 1);
 }
 
+// tile shape of the fused gradient + optimiser launches on the LDS-DMA core: 0 = 64 x 64, 1 = 32 x 64, 2 = 64 x 32, 3 = 32 x 32
+// (HL_ADAM_TILE in the environment; the micro-benchmark sets the global)
+int g_hl_adam_tile = -1;
+static int hl_adam_tile() {
+    if (g_hl_adam_tile < 0) {
+        const char* e = getenv("HL_ADAM_TILE");
+        g_hl_adam_tile = (e != nullptr && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;
+    }
+    return g_hl_adam_tile;
+}
+static void hl_adam_tile_shape(int K, int& bm, int& bn) {
+    bm = bn = 64;
+    if (K % 64 == 0 && hl_use_dma()) {
+        const int t = hl_adam_tile();
+        bm = (t & 1) ? 32 : 64;
+        bn = (t & 2) ? 32 : 64;
+    }
+}
+
 int hl_gemm_adam_grid(const AdamGemmGroup& g) {
+    int bm, bn;
+    hl_adam_tile_shape(g.K, bm, bn);
     int t = 0;
-    for (int i = 0; i < g.n; ++i) t += ((g.p[i].M + 63) / 64) * ((g.p[i].N + 63) / 64);
+    for (int i = 0; i < g.n; ++i) t += ((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn);
     return t;
 }
 
@@ -589,6 +617,8 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
     HL_REQUIRE(g.n >= 1 && g.n <= 3 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm_adam: n=%d K=%d", g.n, g.K);
     HL_REQUIRE(flat_lo % 4 == 0 && flat_n % 4 == 0 && flat_n >= 0 && (flat_n == 0 || Gflat != nullptr), HLVAE_ESHAPE,
                "gemm_adam: flat range [%ld, +%ld) must be 4-aligned", flat_lo, flat_n);
+    int bm, bn;
+    hl_adam_tile_shape(g.K, bm, bn);
     int t = 0;
     for (int i = 0; i < g.n; ++i) {
         AdamGemmProb& q = g.p[i];
@@ -597,8 +627,8 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
                    q.lda, q.ldb);
         HL_REQUIRE(q.off + (long)q.M * q.N < (1l << 31) && q.off2 + (long)q.M * q.N < (1l << 31), HLVAE_ESHAPE,
                    "gemm_adam problem %d: arena offsets beyond 2^31 elements", i);          // the kernel keeps them in 32 bits
-        q.tiles_m = (q.M + 63) / 64;
-        q.tiles_n = (q.N + 63) / 64;
+        q.tiles_m = (q.M + bm - 1) / bm;
+        q.tiles_n = (q.N + bn - 1) / bn;
         q.tile0 = t;
         t += q.tiles_m * q.tiles_n;
     }
@@ -606,12 +636,17 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
     HL_PROF(label, s);
     const int grid = t;
     unsigned long long* stamp = hl_stamp_slot(g.n == 1 ? HL_ST_ADAM_WY : HL_ST_ADAM_REST);
-    if (g.K % 64 == 0 && hl_use_dma())
-        k_gemm_adam_dma<2><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp);
-    else if (g.K % 64 == 0)
+#define HL_GA(BMv, BNv, MINWv) k_gemm_adam_dma<BMv, BNv, 2, MINWv><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp)
+    if (g.K % 64 == 0 && hl_use_dma()) {
+        if (bm == 64 && bn == 64) HL_GA(64, 64, 4);
+        else if (bm == 32 && bn == 64) HL_GA(32, 64, 6);
+        else if (bm == 64 && bn == 32) HL_GA(64, 32, 6);
+        else HL_GA(32, 32, 6);
+    } else if (g.K % 64 == 0)
         k_gemm_adam<64><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp);
     else
         k_gemm_adam<32><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp);
+#undef HL_GA
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -255,195 +255,13 @@ __global__ __launch_bounds__(256) void k_gp_spd_inv(const double* __restrict__ A
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Blocked form (round 3): the same in-place Gauss-Jordan sweep, four pivots per phase.  For the pivot set K = {k0 .. k0 + 3}
-//     A[K][K] <- P^-1,   A[K][j] <- P^-1 A[K][j],   A[i][K] <- -A[i][K] P^-1,   A[i][j] <- A[i][j] - A[i][K] P^-1 A[K][j]    (i, j not in K)
-// (the sweep operator on a block; sweeping every block in turn leaves the inverse).  The scalar pivots met while P (4 x 4, the
-// current Schur complement of K) is inverted without pivoting are exactly the pivots of the unblocked elimination, so the
-// log-determinant and the positivity check are unchanged.  Why: the unblocked kernel above spends ~1400 clocks per pivot on a
-// serial chain (publish row / column, barrier, v_rcp_f64 + two Newton steps, 16 LDS reads) around 64 FMAs per lane; here a phase is two
-// barriers and one 4 x 4 inversion (redundantly in every lane: four dependent reciprocals) around 256 FMAs per lane -- 30 phases
-// instead of 120 pivots for M = 120.  (fp64 MFMA would not help: on MI355X v_mfma_f64_16x16x4 runs at the vector FMA rate.)
-// Panels are double-buffered in LDS: phase p + 1 publishes into the other set while slow waves still read phase p's.
-// ------------------------------------------------------------------------------------------------------------
-#define GPB_W (GP_MMAX)
-struct GpBlkLds {
-    double rw[2][4][GPB_W];      // raw pivot rows          A[K][:]
-    double cl[2][4][GPB_W];      // raw pivot columns       A[:][K]   (cl[q][i] = A[i][k0 + q])
-    double rn[2][4][GPB_W];      // scaled pivot rows       P^-1 A[K][:]
-    double pv[GP_MMAX];
-};
-
-template <int KB>
-__device__ __forceinline__ void gjb_phases(double (&a)[8][8], GpBlkLds& sm, int N, int ti, int tj) {
-#pragma unroll 1
-    for (int sb = 0; sb < 4; ++sb) {
-        const int kr0 = 4 * sb, k0 = KB * 16 + kr0;
-        if (k0 >= N) return;
-        const int par = (k0 >> 2) & 1;
-        double (*rw)[GPB_W] = sm.rw[par];
-        double (*cl)[GPB_W] = sm.cl[par];
-        double (*rn)[GPB_W] = sm.rn[par];
-        const bool rowK = (ti >> 2) == sb, colK = (tj >> 2) == sb;
-        const int qi = ti & 3, qj = tj & 3;
-        if (rowK) {
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) rw[qi][tj + 16 * jj] = a[KB][jj];
-        }
-        if (colK) {
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii) cl[qj][ti + 16 * ii] = a[ii][KB];
-        }
-        __syncthreads();
-        // P^-1 in every lane (4 x 4 Gauss-Jordan without pivoting; all indices static)
-        double P[4][4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) P[p][q] = rw[p][k0 + q];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double piv = P[k][k];
-            const double pk = gp_rcp(piv);
-            if (ti == 0 && tj == 0) sm.pv[k0 + k] = piv;
-            double rk[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rk[j] = P[k][j] * pk;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i == k) continue;
-                const double f = P[i][k];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j != k) P[i][j] = fma(-f, rk[j], P[i][j]);
-                P[i][k] = -f * pk;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j != k) P[k][j] = rk[j];
-            P[k][k] = pk;
-        }
-        // the owners of the pivot rows scale them: rn[q][j] = sum_p Pinv[q][p] rw[p][j]  (row q = this lane's, its 8 columns)
-        if (rowK) {
-            double pq[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) pq[p] = qi == 0 ? P[0][p] : (qi == 1 ? P[1][p] : (qi == 2 ? P[2][p] : P[3][p]));
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int j = tj + 16 * jj;
-                rn[qi][j] = fma(pq[0], rw[0][j], fma(pq[1], rw[1][j], fma(pq[2], rw[2][j], pq[3] * rw[3][j])));
-            }
-        }
-        __syncthreads();
-        double cz[8][4], rz[4][8];
-#pragma unroll
-        for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cz[ii][q] = cl[q][ti + 16 * ii];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) rz[q][jj] = rn[q][tj + 16 * jj];
-        // new pivot-column values for the rows outside K: -sum_p C[i][p] Pinv[p][q], q = this lane's pivot column
-        double cn[8];
-        if (colK) {
-            double pc[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) pc[p] = qj == 0 ? P[p][0] : (qj == 1 ? P[p][1] : (qj == 2 ? P[p][2] : P[p][3]));
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii)
-                cn[ii] = -fma(cz[ii][0], pc[0], fma(cz[ii][1], pc[1], fma(cz[ii][2], pc[2], cz[ii][3] * pc[3])));
-        }
-        // generic update, leaving pivot rows and columns alone (their factors are zeroed)
-        if (rowK) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cz[KB][q] = 0.0;
-        }
-        if (colK) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rz[q][KB] = 0.0;
-        }
-#pragma unroll
-        for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                double acc = a[ii][jj];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc = fma(-cz[ii][q], rz[q][jj], acc);
-                a[ii][jj] = acc;
-            }
-        if (rowK) {                                          // pivot rows: P^-1 A[K][j]; inside K: P^-1 itself
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) a[KB][jj] = rn[qi][tj + 16 * jj];
-        }
-        if (colK) {
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii) a[ii][KB] = cn[ii];
-        }
-        if (rowK && colK) {
-            const double r0 = qj == 0 ? P[0][0] : (qj == 1 ? P[0][1] : (qj == 2 ? P[0][2] : P[0][3]));
-            const double r1 = qj == 0 ? P[1][0] : (qj == 1 ? P[1][1] : (qj == 2 ? P[1][2] : P[1][3]));
-            const double r2 = qj == 0 ? P[2][0] : (qj == 1 ? P[2][1] : (qj == 2 ? P[2][2] : P[2][3]));
-            const double r3 = qj == 0 ? P[3][0] : (qj == 1 ? P[3][1] : (qj == 2 ? P[3][2] : P[3][3]));
-            a[KB][KB] = qi == 0 ? r0 : (qi == 1 ? r1 : (qi == 2 ? r2 : r3));
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_gp_spd_inv_blk(const double* __restrict__ A, int N, double* __restrict__ inv,
-                                                        double* __restrict__ logdet, int* __restrict__ fail, int n_neg,
-                                                        double* __restrict__ logdet_neg) {
-    __shared__ GpBlkLds sm;
-    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-    const double* src = A + (size_t)blockIdx.x * N * N;
-    double a[8][8];
-#pragma unroll
-    for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int i = ti + 16 * ii, j = tj + 16 * jj;
-            a[ii][jj] = (i < N && j < N) ? src[(size_t)i * N + j] : (i == j ? 1.0 : 0.0);
-        }
-    gjb_phases<0>(a, sm, N, ti, tj);
-    gjb_phases<1>(a, sm, N, ti, tj);
-    gjb_phases<2>(a, sm, N, ti, tj);
-    gjb_phases<3>(a, sm, N, ti, tj);
-    gjb_phases<4>(a, sm, N, ti, tj);
-    gjb_phases<5>(a, sm, N, ti, tj);
-    gjb_phases<6>(a, sm, N, ti, tj);
-    gjb_phases<7>(a, sm, N, ti, tj);
-    double* dst = inv + (size_t)blockIdx.x * N * N;
-#pragma unroll
-    for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int i = ti + 16 * ii, j = tj + 16 * jj;
-            if (i < N && j < N) dst[(size_t)i * N + j] = a[ii][jj];
-        }
-    __syncthreads();
-    if (tid < 64) {                                        // log-determinant = sum of log pivots
-        double ld = 0.0;
-        bool bad = false;
-        for (int k = tid; k < N; k += 64) {
-            const double p = sm.pv[k];
-            bad |= !(p > 0.0);
-            ld += log(p);
-        }
-        ld = wave_sum_d(ld);
-        if (bad && fail != nullptr) atomicExch(fail, 1);
-        if (tid == 0) {
-            logdet[blockIdx.x] = ld;
-            if ((int)blockIdx.x < n_neg) logdet_neg[blockIdx.x] = -ld;
-        }
-    }
-}
-
-// which of the two inversion kernels the launchers use (HL_GP_SPD=unblocked selects the round-1 form: A/B on one box)
-static bool gp_spd_blocked() {
-    static const bool on = [] { const char* e = getenv("HL_GP_SPD"); return !(e != nullptr && e[0] == 'u'); }();
-    return on;
-}
-
+// (Round 3 built a blocked form of this sweep -- four pivots per phase: P^-1 of the 4 x 4 pivot block in every lane, the scaled
+//  pivot rows published by their owners, a rank-4 update of the 8 x 8 register block, 30 phases of two barriers instead of 120
+//  pivots -- and dropped it: 105 us against 84 us for this kernel on [iH_new | K0zz] (64 matrices of 120 x 120), and 2.6e-5
+//  instead of 5e-7 on the natural-gradient terms of the ill-conditioned (1e8) config-5 matrices.  The redundant 4 x 4 inversion
+//  is four DEPENDENT reciprocal chains per phase, and the rank-4 update reads 64 LDS doubles per lane where the rank-1 form reads
+//  16: the phase costs 3500 clocks against 4 x 1400.  fp64 MFMA would not help either: v_mfma_f64_16x16x4 runs at the vector
+//  FMA rate on MI355X.  What bounds this kernel is the per-pivot chain publish -> barrier -> reciprocal -> broadcast.)
 // ------------------------------------------------------------------------------------------------------------
 // per (subject, latent) block.  T <= 32 rows per subject (padded), M <= 128 inducing points, 256 threads as a
 // 16 x 16 grid: lane (ti, tj) owns the 2 x 2 elements (ti + 16 ii, tj + 16 jj) of the T x T blocks.
@@ -1259,8 +1077,7 @@ int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* hyp, int n_sl
 int hlvae_gp_chol_inv(const double* A, int n, int N, double* inv, double* logdet, int* fail, hlvae_stream s) {
     HL_REQUIRE(A && inv && logdet && n > 0 && N > 0 && N <= GP_MMAX, HLVAE_EINVAL, "gp_chol_inv: N=%d (max %d)", N, GP_MMAX);
     HL_PROF("gp_spd_inv", (hipStream_t)s);
-    if (gp_spd_blocked()) k_gp_spd_inv_blk<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, 0, nullptr);
-    else k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, 0, nullptr);
+    k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, 0, nullptr);
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -1379,8 +1196,7 @@ int hlvae_gp_spd_inv2(const double* A, int n, int N, double* inv, double* logdet
     HL_REQUIRE(A && inv && logdet && n > 0 && N > 0 && N <= GP_MMAX && n_neg >= 0 && n_neg <= n && (n_neg == 0 || logdet_neg),
                HLVAE_EINVAL, "gp_spd_inv2: N=%d (max %d) n=%d n_neg=%d", N, GP_MMAX, n, n_neg);
     HL_PROF("gp_spd_inv", (hipStream_t)s);
-    if (gp_spd_blocked()) k_gp_spd_inv_blk<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, n_neg, logdet_neg);
-    else k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, n_neg, logdet_neg);
+    k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, n_neg, logdet_neg);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     float* __restrict__ logpx_miss, float* __restrict__ rowpart, float* __restrict__ pfull, int X,
     float* __restrict__ xhat, int B, int want_grad, const float* __restrict__ ysrc, int ldys, long long* __restrict__ clk,
     int logvar, unsigned long long* stamp) {
-    HL_STAMP_T0();
+    HL_STAMP_T0(stamp);
 #define HL_CLK(i) do { if (clk != nullptr && (threadIdx.x & 63) == 0) clk[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12 + (i)] = clock64(); } while (0)
     HL_CLK(0);
     // ysrc != nullptr: convolutional decoder -- the tile of y_grouped comes from the second ConvTranspose (csrc/conv.hip,

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     bf16_t* __restrict__ uT_out, int B, const bf16_t* __restrict__ xin, int K1p, const bf16_t* __restrict__ w1,
     unsigned long long* stamp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    HL_STAMP_T0();
+    HL_STAMP_T0(stamp);
     const int lda = hep + 8;                                     // bf16 elements
     bf16_t* Ta = reinterpret_cast<bf16_t*>(smem);                // [16][hep+8]
     const int cmax = (hdp > 2 * LP ? hdp : 2 * LP) + 1;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     float* __restrict__ gb1, int B, bf16_t* __restrict__ dt_out, const bf16_t* __restrict__ dyin, int NYp,
     const bf16_t* __restrict__ wyT, float* __restrict__ zero_ptr, long zero_n4, unsigned long long* stamp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    HL_STAMP_T0();
+    HL_STAMP_T0(stamp);
     // (the weight-gradient GEMMs that follow on this stream add split-K slices with atomics: their output region is cleared
     //  here instead of by a memset node on the critical path, 5.7 us in the replayed graph)
     for (long i = (long)blockIdx.x * MID_THREADS + threadIdx.x; i < zero_n4; i += (long)gridDim.x * MID_THREADS)

@@ -17,6 +17,9 @@ void hl_prof_begin(const char*, hipStream_t) {}
 void hl_prof_end(hipStream_t) {}
 unsigned long long* hl_stamp_slot(int) { return nullptr; }
 extern int g_hl_gemm_dma;
+extern int g_hl_adam_tile;
+static const char* VN[5] = {"old 64x64", "dma 64x64", "dma 32x64", "dma 64x32", "dma 32x32"};
+static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_tile = v > 0 ? v - 1 : 0; }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -71,21 +74,25 @@ int main(int argc, char** argv) {
             AdamGemmGroup g{};
             g.n = 1; g.K = Bp;
             g.p[0] = AdamGemmProb{dyT, uT, nullptr, sh[set], shT[set], 0, 0, Bp, Bp, M, N, 0, 0, Np, Mp, 0, 0, 0};
-            g_hl_gemm_dma = dma;
+            set_variant(dma);
             if (hl_launch_gemm_adam(g, P[set], M1[set], M2[set], step, 1e-3f, 0.9f, 0.999f, 1e-8f, 1.f, 0u, "x", 0, nullptr, 0, 0)) { printf("launch failed: %s\n", g_err); exit(1); }
         };
-        // correctness: sets 0 and 1 hold identical state
-        CK(hipMemcpy(P[1], P[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[1], M1[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[1], M2[0], arena * 4, hipMemcpyDeviceToDevice));
-        launch(0, 0); launch(1, 1); CK(hipDeviceSynchronize());
-        printf("gemm_adam wy  old vs dma: max|dP| %.3g  max|dM1| %.3g  max|dM2| %.3g  shadow cells differing %zu  shadowT %zu\n",
-               maxdiff(d2h(P[0], arena), d2h(P[1], arena)), maxdiff(d2h(M1[0], arena), d2h(M1[1], arena)), maxdiff(d2h(M2[0], arena), d2h(M2[1], arena)),
-               ndiff16(d2h(sh[0], (size_t)Mp * Np), d2h(sh[1], (size_t)Mp * Np)), ndiff16(d2h(shT[0], (size_t)Np * Mp), d2h(shT[1], (size_t)Np * Mp)));
-        std::vector<float> t[2];
+        // correctness: set 2 keeps a pristine copy of set 0's state; set 1 is reloaded from it for every variant
+        CK(hipMemcpy(P[2], P[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[2], M1[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[2], M2[0], arena * 4, hipMemcpyDeviceToDevice));
+        launch(0, 0);
+        for (int v = 1; v < 5; ++v) {
+            CK(hipMemcpy(P[1], P[2], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[1], M1[2], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[1], M2[2], arena * 4, hipMemcpyDeviceToDevice));
+            launch(1, v); CK(hipDeviceSynchronize());
+            printf("gemm_adam wy  old vs %s: max|dP| %.3g  max|dM1| %.3g  max|dM2| %.3g  shadow cells differing %zu  shadowT %zu\n", VN[v],
+                   maxdiff(d2h(P[0], arena), d2h(P[1], arena)), maxdiff(d2h(M1[0], arena), d2h(M1[1], arena)), maxdiff(d2h(M2[0], arena), d2h(M2[1], arena)),
+                   ndiff16(d2h(sh[0], (size_t)Mp * Np), d2h(sh[1], (size_t)Mp * Np)), ndiff16(d2h(shT[0], (size_t)Np * Mp), d2h(shT[1], (size_t)Np * Mp)));
+        }
+        std::vector<float> t[5];
         int set = 0;
         for (int r = 0; r < reps; ++r)
-            for (int v = 0; v < 2; ++v) { set = (set + 1) % NSETS; t[v].push_back(T.run([&] { launch(set, v); })); }
+            for (int v = 0; v < 5; ++v) { set = (set + 1) % NSETS; t[v].push_back(T.run([&] { launch(set, v); })); }
         const double bytes = (double)(M + N) * Bp * 2 + 24.0 * M * N + 2.0 * 2 * M * N;
-        for (int v = 0; v < 2; ++v) printf("gemm_adam wy  %s: median %.2f us  min %.2f  -> %.2f TB/s algorithmic (%.1f MB)\n", v ? "dma" : "old", med(t[v]), *std::min_element(t[v].begin(), t[v].end()), bytes / med(t[v]) * 1e-6, bytes * 1e-6);
+        for (int v = 0; v < 5; ++v) printf("gemm_adam wy  %s: median %.2f us  min %.2f  -> %.2f TB/s algorithmic (%.1f MB)\n", VN[v], med(t[v]), *std::min_element(t[v].begin(), t[v].end()), bytes / med(t[v]) * 1e-6, bytes * 1e-6);
         // the other three in one launch: dW1 [500][5184], dWd [500][32], d[Wmu;Wlv] [64][500]
         {
             const int h = 500, X = 5184, L = 32;
@@ -104,18 +111,22 @@ int main(int argc, char** argv) {
                 g.p[0] = AdamGemmProb{dtT, xnT, nullptr, w1s, nullptr, o_w1, 0, Bp, Bp, h, X, 0, 0, X, 0, 0, 0, 0};
                 g.p[1] = AdamGemmProb{duT, zbT, nullptr, wds, wdTs, o_wd, 0, Bp, Bp, h, L, 0, 0, 32, 512, 0, 0, 0};
                 g.p[2] = AdamGemmProb{dmlT, tT, nullptr, wmls, wmlTs, o_wmu, o_wlv, Bp, Bp, 64, h, 32, L, 512, 64, 0, 0, 0};
-                g_hl_gemm_dma = dma;
+                set_variant(dma);
                 if (hl_launch_gemm_adam(g, P[set], M1[set], M2[set], step, 1e-3f, 0.9f, 0.999f, 1e-8f, 1.f, 0u, "x", 0, nullptr, 0, 0)) { printf("launch failed: %s\n", g_err); exit(1); }
             };
-            CK(hipMemcpy(P[1], P[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[1], M1[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[1], M2[0], arena * 4, hipMemcpyDeviceToDevice));
-            launch3(0, 0); auto w_old = d2h(w1s, (size_t)512 * X); launch3(1, 1); CK(hipDeviceSynchronize());
-            printf("gemm_adam rest old vs dma: max|dP| %.3g  max|dM1| %.3g  shadow cells differing %zu\n", maxdiff(d2h(P[0], arena), d2h(P[1], arena)),
-                   maxdiff(d2h(M1[0], arena), d2h(M1[1], arena)), ndiff16(w_old, d2h(w1s, (size_t)512 * X)));
-            std::vector<float> t3[2];
+            CK(hipMemcpy(P[2], P[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[2], M1[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[2], M2[0], arena * 4, hipMemcpyDeviceToDevice));
+            launch3(0, 0); auto w_old = d2h(w1s, (size_t)512 * X);
+            for (int v = 1; v < 5; ++v) {
+                CK(hipMemcpy(P[1], P[2], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[1], M1[2], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[1], M2[2], arena * 4, hipMemcpyDeviceToDevice));
+                launch3(1, v); CK(hipDeviceSynchronize());
+                printf("gemm_adam rest old vs %s: max|dP| %.3g  max|dM1| %.3g  shadow cells differing %zu\n", VN[v], maxdiff(d2h(P[0], arena), d2h(P[1], arena)),
+                       maxdiff(d2h(M1[0], arena), d2h(M1[1], arena)), ndiff16(w_old, d2h(w1s, (size_t)512 * X)));
+            }
+            std::vector<float> t3[5];
             for (int r = 0; r < reps; ++r)
-                for (int v = 0; v < 2; ++v) { set = (set + 1) % NSETS; t3[v].push_back(T.run([&] { launch3(set, v); })); }
+                for (int v = 0; v < 5; ++v) { set = (set + 1) % NSETS; t3[v].push_back(T.run([&] { launch3(set, v); })); }
             const double b3 = (double)(h + X) * Bp * 2 + 26.0 * h * X + (double)(h + L) * Bp * 2 + (double)(64 + h) * Bp * 2 + 28.0 * (h * L + 2 * L * h);
-            for (int v = 0; v < 2; ++v) printf("gemm_adam rest %s: median %.2f us  min %.2f  -> %.2f TB/s algorithmic (%.1f MB)\n", v ? "dma" : "old", med(t3[v]), *std::min_element(t3[v].begin(), t3[v].end()), b3 / med(t3[v]) * 1e-6, b3 * 1e-6);
+            for (int v = 0; v < 5; ++v) printf("gemm_adam rest %s: median %.2f us  min %.2f  -> %.2f TB/s algorithmic (%.1f MB)\n", VN[v], med(t3[v]), *std::min_element(t3[v].begin(), t3[v].end()), b3 / med(t3[v]) * 1e-6, b3 * 1e-6);
         }
     }
     // ---------------- split-K products ------------------------------------------------------------------------------------------
