@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HLVAE_LIB_PATH", os.path.join(_HERE, "libhlvae_hip.so"))      # (override: diagnostic builds)
-ABI_VERSION = 30
+ABI_VERSION = 31
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -112,7 +112,7 @@ _SIGS = {
     "hlvae_gp_chol_inv": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "hlvae_gp_subject_fwd": (C.c_int, [C.POINTER(HlvaeGpKernel), C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp,
                                        _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, _vp, _vp, _vp,
-                                       _vp, _vp, _vp, _vp, _vp]),
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hlvae_gp_subject_bwd": (C.c_int, [C.POINTER(HlvaeGpKernel), C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp,
                                        _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp,
                                        _vp]),

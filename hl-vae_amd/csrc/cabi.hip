@@ -1,6 +1,7 @@
 // extern "C" boundary of libhlvae_hip.so (include/hlvae_hip.h): argument validation against what the
 // kernels' grids assume, then stream-ordered launches.  No allocation of caller memory, no device sync.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <vector>
@@ -684,6 +685,30 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         const long bias_lo = d.o_bd, bias_n = d.atomic_region - d.o_bd;
         HL_REQUIRE(d.o_bd % 4 == 0 && bias_n % 4 == 0 && d.o_bmu > d.o_bd && d.o_blv > d.o_bd && d.o_b1 > d.o_bd && d.o_by < d.o_bd,
                    HLVAE_EINVAL, "backward_adam: the arena must end its small region with [bd | bmu | blv | b1]");
+        static const bool one_side = getenv("HL_ONE_SIDE") != nullptr;
+        if (one_side && Bp < 2048) {
+            // Variant (round 3, A/B): BOTH streaming launches on the caller's queue, back to back, and ONE side queue for everything
+            // small (gradient fold, small-region Adam, the next batch's input stage, ELBO scalars + metrics).  Measured before: the two
+            // HBM-bound launches side by side take as long as one after the other (45 + 40 us together, 29 + 25 alone), so the second
+            // hardware queue bought nothing but a fork, a join and a cross-queue parent for the step's end.
+            if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
+                                          tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n))) return rc;
+            // (y_layer's shadows: in place or into the caller's second pair, as above -- dU_splitk, this step's last reader of the
+            //  first pair, ran before on this queue either way)
+            if ((rc = hl_launch_gemm_adam(g_wy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
+                                          tickets, "dWy_adam", st))) return rc;
+            HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));
+            if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s1))) return rc;
+            if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tickets,
+                                   "adam_small", s1, bias_lo))) return rc;
+            if (p->pend_flags & HL_PEND_DEFERRED) {
+                if ((rc = hl_flush_deferred(p, s1, true, HL_PEND_DEFERRED, false, true))) return rc;
+            } else {
+                HL_CHECK(hipEventRecord(p->ev[5], s1));
+                p->pend_flags |= HL_PEND_RUNNING;
+            }
+            return hlvae_join(p, s);
+        }
         if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
                                       tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n))) return rc;
         HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));

@@ -274,8 +274,15 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     const double* __restrict__ x, const double* __restrict__ noise, const int32_t* __restrict__ idx, int T,
     const double* __restrict__ Kxz, int Bn, int M, const double* __restrict__ resid, const float* __restrict__ lv, double c,
     double* __restrict__ iB_out, double* __restrict__ K0_out, double* __restrict__ V_out, double* __restrict__ v_out,
-    double* __restrict__ part, float* __restrict__ g_mu, float* __restrict__ g_lv) {
+    double* __restrict__ part, float* __restrict__ g_mu, float* __restrict__ g_lv, const double* __restrict__ iKm,
+    const float* __restrict__ mu, double* __restrict__ u_acc, double* __restrict__ p1_acc) {
+    // iKm != nullptr (training step, round 3): the residual a = K0xz (iK m) - mu of the subject's rows is computed HERE from the
+    // staged rows of K0xz (`resid` is then unused: one launch and one 31 MB pass less), and the two matrix^T-vector sums over
+    // the batch that followed as launches of their own -- u = K0xz^T v and P1 = V^T mu = Ks^T (iB mu), one streaming pass over
+    // K0xz / V each, 76 + 32 us on the natural-gradient chain -- are accumulated per subject into u_acc / p1_acc [L][M] (fp64
+    // atomics, zeroed by the caller) from the same LDS tile.
     __shared__ double xs[GP_TMAX * GP_XS];
+    __shared__ double vsh[GP_TMAX], wsh[GP_TMAX], mus[GP_TMAX];
     __shared__ double ib[GP_TMAX * GP_TS], kzs[GP_TMAX * GP_TS];
     extern __shared__ __attribute__((aligned(16))) char dsm_fwd[];
     double* ks = reinterpret_cast<double*>(dsm_fwd);      // the subject's rows of K0xz, [T][M] (sized for the actual T, M:
@@ -303,11 +310,25 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
             if (e < T * M) ks[e] = rows[e / M] >= 0 ? tk[u] : 0.0;
         }
     }
-    if (tid < T) rs[tid] = rows[tid] >= 0 ? resid[(size_t)l * Bn + rows[tid]] : 0.0;
+    if (iKm == nullptr && tid < T) rs[tid] = rows[tid] >= 0 ? resid[(size_t)l * Bn + rows[tid]] : 0.0;
+    if (tid < GP_TMAX) {
+        vsh[tid] = wsh[tid] = 0.0;
+        mus[tid] = (mu != nullptr && tid < T && rows[tid] >= 0) ? (double)mu[(size_t)rows[tid] * L + l] : 0.0;
+    }
     GpHyp h0, h1;
     gp_hoist(k0, hyp, n_slots, L, l, h0);
     gp_hoist(k1, hyp, n_slots, L, l, h1);
     __syncthreads();
+    if (iKm != nullptr) {                                         // a[t] = sum_m Ks[t][m] (iK m)[m] - mu[t]: 8 lanes per row
+        const int t = tid >> 3, sub = tid & 7;                    // (256 threads = 32 rows x 8)
+        double sa = 0.0;
+        if (t < T)
+            for (int mm = sub; mm < M; mm += 8) sa += ks[t * M + mm] * iKm[(size_t)l * M + mm];
+        sa += __shfl_xor(sa, 4, 64);
+        sa += __shfl_xor(sa, 2, 64);
+        sa += __shfl_xor(sa, 1, 64);
+        if (sub == 0 && t < T) rs[t] = rows[t] >= 0 ? sa - mus[t] : 0.0;
+    }
     const double nz = noise[l];
     // covariance entries: the kernels are symmetric, so the T (T + 1) / 2 = 210 pairs i <= j are evaluated once, one per
     // thread, into LDS (in the 2 x 2 register blocking of the Gauss-Jordan below 16 threads would evaluate 4 pairs each)
@@ -360,8 +381,10 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     if (tid < T) {
         if (rows[tid] >= 0) {
             const int i = tid, r = rows[i];
-            double acc = 0.0;
-            for (int j = 0; j < T; ++j) acc += ib[i * GP_TS + j] * rs[j];
+            double acc = 0.0, accw = 0.0;
+            for (int j = 0; j < T; ++j) { acc += ib[i * GP_TS + j] * rs[j]; accw += ib[i * GP_TS + j] * mus[j]; }
+            vsh[i] = acc;                                         // v = iB a
+            wsh[i] = accw;                                        // iB mu
             const double e = exp((double)lv[(size_t)r * L + l]);
             v_out[(size_t)l * Bn + r] = acc;
             pa = rs[i] * acc;                                     // (:256)
@@ -383,6 +406,16 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     pa = wave_sum_d(pa); pb = wave_sum_d(pb); d1 = wave_sum_d(d1); pc = wave_sum_d(pc);
     if ((tid & 63) == 0) { red[0][tid >> 6] = pa; red[1][tid >> 6] = pb; red[2][tid >> 6] = d1; }
     __syncthreads();
+    if (u_acc != nullptr && tid < M) {                            // this subject's share of K0xz^T v and of V^T mu = Ks^T (iB mu)
+        double su = 0.0, sp = 0.0;
+        for (int i = 0; i < T; ++i) {
+            const double kv = ks[i * M + tid];
+            su += kv * vsh[i];
+            sp += kv * wsh[i];
+        }
+        atomicAdd(u_acc + (size_t)l * M + tid, su);
+        atomicAdd(p1_acc + (size_t)l * M + tid, sp);
+    }
     if (tid == 0) {
         double* p = part + ((size_t)s * L + l) * 4;
         p[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
@@ -1085,14 +1118,18 @@ int hlvae_gp_chol_inv(const double* A, int n, int N, double* inv, double* logdet
 int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* hyp, int n_slots, int L, int Q,
                          const double* x, const double* noise, const int32_t* idx, int S, int T, const double* Kxz, int B,
                          int M, const double* resid, const float* lv, double c, double* iB, double* K0s, double* V,
-                         double* v, double* part, float* g_mu, float* g_lv, hlvae_stream s) {
+                         double* v, double* part, float* g_mu, float* g_lv, const double* iKm, const float* mu, double* u_acc,
+                         double* p1_acc, hlvae_stream s) {
     if (int rc = gp_check_kernel(k0, n_slots, Q)) return rc;
     if (int rc = gp_check_kernel(k1, n_slots, Q)) return rc;
     HL_REQUIRE(T >= 1 && T <= GP_TMAX && S >= 1 && Q <= 8 && M <= GP_MMAX, HLVAE_ESHAPE,
                "gp_subject_fwd: T=%d (max %d), M=%d (max %d)", T, GP_TMAX, M, GP_MMAX);
+    HL_REQUIRE((iKm == nullptr || mu != nullptr) && (resid != nullptr || iKm != nullptr) && ((u_acc == nullptr) == (p1_acc == nullptr)) &&
+                   (u_acc == nullptr || mu != nullptr), HLVAE_EINVAL,
+               "gp_subject_fwd: resid or (iKm, mu); u_acc / p1_acc both or none, with mu");
     HL_PROF("gp_subject_fwd", (hipStream_t)s);
     k_gp_subject_fwd<<<dim3(S, L), 256, (size_t)T * M * sizeof(double), (hipStream_t)s>>>(*k0, *k1, hyp, n_slots, L, Q, x, noise, idx, T, Kxz, B, M, resid,
-                                                           lv, c, iB, K0s, V, v, part, g_mu, g_lv);
+                                                           lv, c, iB, K0s, V, v, part, g_mu, g_lv, iKm, mu, u_acc, p1_acc);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -318,6 +318,8 @@ class GPPriorHIP:
         self._ldK, self._ldH = self._ld2[L:], torch.zeros(L, **f64)
         self._fact_key = None
         self._xchg = torch.zeros(L * M * M + 2 * L * M + 1, **f64)    # [W | P1 | u | bound]: the one DP exchange buffer
+        import os as _os
+        self._fuse_sums = _os.environ.get("HL_GP_FUSE", "1") != "0"  # residual + P1 + u inside k_gp_subject_fwd (HL_GP_FUSE=0: separate launches, A/B)
         self.last_kld = self._xchg[-1:]
         self._groups = _GroupCache()
         self._grad_m = self._grad_H = self._iH = self._tmp = None
@@ -464,13 +466,27 @@ class GPPriorHIP:
         iK, iH, ldK, ldH = self._iK, self._iHb, self._ldK, self._ldH
         self._iH = iH
         iKm = self._bmv(iK, self.m, mm["iKm"])                               # [L,M,1]
-        resid = buf["resid"]                                                 # K0xz iK m - mu^T   [L,B]
-        _lib.check(lib.hlvae_gp_resid(_lib.ptr(Kxz), _lib.ptr(iKm), _lib.ptr(mu), L, B, M, _lib.ptr(resid), st), "gp_resid")
+        LMM, LM = L * M * M, L * M
+        W = self._xchg[:LMM].view(L, M, M)
+        P1 = self._xchg[LMM:LMM + LM].view(L, M, 1)
+        u = self._xchg[LMM + LM:LMM + 2 * LM].view(L, M, 1)
+        fused = self._fuse_sums
+        if fused:
+            # the residual a = K0xz iK m - mu^T and the two matrix^T-vector sums P1 = V^T mu, u = K0xz^T v (elbo_functions.py:
+            # 262-266) are computed inside the per-subject kernel from its LDS tile of K0xz (round 3): three launches and three
+            # 31 MB passes less (gp_resid 9 us on the critical path, the two gemv_t 76 + 32 us on the natural-gradient chain)
+            self._xchg[LMM:LMM + 2 * LM].zero_()
+            resid = None
+        else:
+            resid = buf["resid"]                                             # K0xz iK m - mu^T   [L,B]
+            _lib.check(lib.hlvae_gp_resid(_lib.ptr(Kxz), _lib.ptr(iKm), _lib.ptr(mu), L, B, M, _lib.ptr(resid), st), "gp_resid")
         iB, K0s, V, v, part, g_mu, g_lv = (buf[k] for k in ("iB", "K0s", "V", "v", "part", "g_mu", "g_lv"))
         _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x),
                                             _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(Kxz), B, M, _lib.ptr(resid),
                                             _lib.ptr(log_v), _C.c_double(c), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
-                                            _lib.ptr(part), _lib.ptr(g_mu), _lib.ptr(g_lv), st), "gp_subject_fwd")
+                                            _lib.ptr(part), _lib.ptr(g_mu), _lib.ptr(g_lv), _lib.ptr(iKm) if fused else None,
+                                            _lib.ptr(mu) if fused else None, _lib.ptr(u) if fused else None,
+                                            _lib.ptr(P1) if fused else None, st), "gp_subject_fwd")
         # g_mu / g_lv -- all the VAE's backward pass needs -- are final here.  What follows (the bound's value, the natural-gradient
         # terms, the chain rule into hyper-parameters and inducing points) is two independent chains of latency-bound kernels:
         # they run side by side on two streams of ours, and with join = False also beside whatever the caller queues next on
@@ -481,10 +497,6 @@ class GPPriorHIP:
         N1 = self._bmm_into(iK, HiK, mm["N1"], D=iK, alpha=-1.0, beta=1.0)   # iK - iK H iK
         sA.wait_stream(main)
         sC.wait_stream(main)
-        LMM, LM = L * M * M, L * M
-        W = self._xchg[:LMM].view(L, M, M)
-        P1 = self._xchg[LMM:LMM + LM].view(L, M, 1)
-        u = self._xchg[LMM + LM:LMM + 2 * LM].view(L, M, 1)
         world = 1 if self.dp is None else self.dp.world
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
         with torch.cuda.stream(sC):      # chain C: gradient w.r.t. K0xz and the subject blocks
@@ -501,8 +513,9 @@ class GPPriorHIP:
             st = self._stream()
             self._gemm(Kxz, True, V, W, M, M, B)                             # sum_s Ks^T iB Ks = Kxz^T V   [L,M,M]
             # P1 = V^T mu (natural-gradient term, elbo_functions.py:262-266) and u = Kxz^T v: one streaming pass per latent each
-            _lib.check(lib.hlvae_gp_gemv_t_f32(_lib.ptr(V), _lib.ptr(mu), 1, L, _lib.ptr(P1), L, B, M, st), "gp_gemv_t_f32")
-            _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(Kxz), _lib.ptr(v), v.stride(0), v.stride(1), _lib.ptr(u), L, B, M, st), "gp_gemv_t")
+            if not fused:
+                _lib.check(lib.hlvae_gp_gemv_t_f32(_lib.ptr(V), _lib.ptr(mu), 1, L, _lib.ptr(P1), L, B, M, st), "gp_gemv_t_f32")
+                _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(Kxz), _lib.ptr(v), v.stride(0), v.stride(1), _lib.ptr(u), L, B, M, st), "gp_gemv_t")
             _lib.check(lib.hlvae_gp_bound(_lib.ptr(part), S, _lib.ptr(W), _lib.ptr(iK), _lib.ptr(N1), _lib.ptr(self.H), _lib.ptr(self.m),
                                           _lib.ptr(iKm), _lib.ptr(ldK), _lib.ptr(ldH), _lib.ptr(log_v), B, L, M, _C.c_double(c),
                                           _C.c_double(float(self.N_total)), _C.c_double(1.0 / world), _lib.ptr(self.last_kld), st),
@@ -575,7 +588,7 @@ class GPPriorHIP:
         _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(px),
                                             _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(K0xz), Np, M, _lib.ptr(mu64T),
                                             _lib.ptr(zeros32), _C.c_double(1.0), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
-                                            _lib.ptr(part), _lib.ptr(g1), _lib.ptr(g2), st), "gp_subject_fwd(predict)")
+                                            _lib.ptr(part), _lib.ptr(g1), _lib.ptr(g2), None, None, None, None, st), "gp_subject_fwd(predict)")
         K0zx = K0xz.transpose(1, 2)
         inv, _ = self.chol_inv(torch.cat([K0zz + K0zx @ V, K0zz]))                       # H = K0zz + sum_s Ks^T iB Ks (:156-157)
         iH, iK = inv[:L], inv[L:]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 30
+#define HLVAE_ABI_VERSION 31
 #define HLVAE_STAT_CHUNKS 16
 /* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
 #define HLVAE_HEAD_ACC 95
@@ -355,11 +355,15 @@ int hlvae_gp_chol_inv(const double* A, int n, int N, double* inv, double* logdet
 /* the per-subject loop of elbo_functions.py:243-266 as one workgroup per (subject, latent).  idx [S][T]: batch row of the
  * t-th observation of subject s, -1 = padding (T <= 32).  resid [L][B] = K0xz iK0zz m - mu^T.  Outputs: iB, K0s [S][L][T][T];
  * V [L][B][M] = iB_s K0xz_s (row-indexed by batch row); v [L][B] = iB_s resid_s; part [S][L][4] = {A, B, C, sum(iB*K0)}
- * contributions; g_mu, g_lv [B][L] fp32 = d(KL bound)/d(mu, log_var) with c = P / P_batch. */
+ * contributions; g_mu, g_lv [B][L] fp32 = d(KL bound)/d(mu, log_var) with c = P / P_batch.
+ * iKm [L][M] = iK0zz m (or NULL): the residual is then computed inside from the staged rows of K0xz and mu [B][L] (resid unused).
+ * u_acc, p1_acc [L][M] (both or NULL; need mu): += this batch's K0xz^T v and V^T mu (elbo_functions.py:262-266), per-subject
+ * fp64 atomics -- the caller zeroes them. */
 int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* hyp, int n_slots, int L, int Q,
                          const double* x, const double* noise, const int32_t* idx, int S, int T, const double* Kxz, int B,
                          int M, const double* resid, const float* lv, double c, double* iB, double* K0s, double* V,
-                         double* v, double* part, float* g_mu, float* g_lv, hlvae_stream s);
+                         double* v, double* part, float* g_mu, float* g_lv, const double* iKm, const float* mu, double* u_acc,
+                         double* p1_acc, hlvae_stream s);
 /* gradients of the bound w.r.t. B_st and K0_st chained into the hyper-parameters (accumulates into gprm [n_slots][L]).
  * Y [L][B][M] = V (iK0zz - iK0zz H iK0zz). */
 int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* hyp, int n_slots, int L, int Q,

@@ -22,10 +22,17 @@ def rel(a, b):
 
 def main():
     kl = sys.argv[1]
-    dist.init_process_group("gloo")
+    backend = sys.argv[2] if len(sys.argv) > 2 else "gloo"      # "nccl" (= RCCL): one rank per GPU, needs >= world devices
+    if backend == "nccl":
+        lr_ = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr_)
+        dev = torch.device("cuda", lr_)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(dev)
     import hlvae_amd  # noqa: F401
     from hlvae_amd import synthetic
     from hlvae_amd.HLVAE import HLVAE
@@ -77,6 +84,16 @@ def main():
         nll_d.append(float(part[0]))
         kld_d.append(float(gp_d.last_kld) if gp_d is not None else float(part[1]))
     torch.cuda.synchronize()
+    captured = None
+    if backend == "nccl" and kl == "normal":
+        # the captured form of the same step (thread_local capture mode, async reduce-scatter / all-gather handles inside the
+        # capture): two replays must leave the parameters finite and moving, and identical on every rank
+        tr_d.capture_rows("c", dsd, [rows_dev, rows_dev], [P_batch, P_batch], next_rows=[rows_dev, rows_dev], groups=[groups_dev, groups_dev])
+        tr_d.prime_rows(dsd, rows_dev)
+        before = model_d._arena.clone()
+        tr_d.replay("c")
+        torch.cuda.synchronize()
+        captured = bool(torch.isfinite(model_d._arena).all()) and not torch.equal(before, model_d._arena)
     model_d.state_dict()                    # collective: gathers the fp32 masters of the other rank's slices
     out = dict(kl=kl, world=world, rows=[int(len(rows))], nll_single=nll_s, nll_dp=nll_d, kld_single=kld_s, kld_dp=kld_d,
                params=rel(model_d._arena, model_s._arena))
@@ -90,6 +107,7 @@ def main():
         dist.broadcast(chk, 0)
         drift = max(drift, float((chk - t).abs().max()))
     out["replica_drift"] = drift
+    out["backend"], out["captured_ok"] = backend, captured
     # the shadows ARE the bf16 rounding of the gathered masters
     d = model_d._dims
     wy = model_d.y_layer[0].weight.detach()[torch.as_tensor(model_d.kernel_wy_rows(), device=dev)]   # shadow rows: kernel's variable order

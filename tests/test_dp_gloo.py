@@ -126,6 +126,41 @@ def _sharded_worker(rank, world, port, tmp):
     dims = [src.cov_dim_ext, [16], 4, [16], 5]
     state = orc.init_state(dims, src.types_info, src.n_variables, seed=5, std=0.2)
     dp = DataParallel(dist.group.WORLD)
+    if os.environ.get("HLVAE_TEST_DEFERRED") == "1":
+        # asynchronous semantics without RCCL: with async_op the collective happens only inside handle.wait(), and until then the
+        # output buffer is poisoned -- a consumer that forgot to wait (or waited on the wrong handle) computes with NaN.  This is
+        # what the native branch's Work handles mean; gloo's emulation in DataParallel is synchronous and would hide such a bug.
+        class _Deferred:
+            def __init__(self, fn):
+                self.fn, self.done = fn, False
+
+            def wait(self):
+                if not self.done:
+                    self.fn()
+                    self.done = True
+                return True
+
+        class DeferredDP(DataParallel):
+            def reduce_scatter(self, out, inp, async_op=False):
+                base = DataParallel.reduce_scatter
+                if not async_op:
+                    return base(self, out, inp)
+                snap = inp.clone()                       # (RCCL reads the input when the collective runs on its stream: here at issue)
+                out.fill_(float("nan"))
+                return _Deferred(lambda: base(self, out, snap))
+
+            def all_gather(self, full, mine, async_op=False):
+                base = DataParallel.all_gather
+                if not async_op:
+                    return base(self, full, mine)
+                snap = mine.clone()
+                r, n = self.rank, mine.numel()
+                keep = full[r * n:(r + 1) * n].clone()
+                full.fill_(float("nan"))
+                full[r * n:(r + 1) * n] = keep
+                return _Deferred(lambda: base(self, full, snap))
+
+        dp = DeferredDP(dist.group.WORLD)
     # flat arena in the product's order: small tensors first, then the dense matrices with y_layer's weight LAST
     dense = ["d_layers.0.weight", "mean_layer.0.weight", "log_var_layer.0.weight", "VAE_encoder_common_layers.0.weight", "y_layer.0.weight"]
     names = [k for k in state if not k.startswith("hidden.") and k not in dense and k != "_disp_param"] + dense
@@ -186,10 +221,14 @@ def _sharded_worker(rank, world, port, tmp):
             g = sstate.gsh[k][:hi - lo]
             orc.adam_step([P[lo:hi]], [g], [m1[lo:hi]], [m2[lo:hi]], it + 1)
             sstate.own_copy_view(k)[:hi - lo] = P[lo:hi].to(torch.bfloat16)
-            sstate.all_gather_slice(k)
         orc.adam_step([P[:a0]], [G[:a0]], [m1[:a0]], [m2[:a0]], it + 1)
         W[:a0] = P[:a0]
-        for k, s_ in enumerate(splan.slices):
+        # all-gathers issued LAST slice first and consumed in that order, as training.py does (the slice with the first Linear is
+        # needed first by the next step)
+        gath = [(k, sstate.all_gather_slice(k, async_op=True)) for k in range(len(splan.slices))[::-1]]
+        for k, h in gath:
+            h.wait()
+            s_ = splan.slices[k]
             W[s_.lo:s_.hi] = sstate.pb[k][:s_.hi - s_.lo].to(torch.float64)
         # --- single process on the whole global batch
         Gr, _ = grads_for(W_ref, np.sort(bref.rows), None, eps_all[np.sort(bref.rows)], scale)
@@ -206,12 +245,13 @@ def _sharded_worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_optimizer_matches_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,deferred", [(2, False), (4, False), (2, True)])
+def test_sharded_optimizer_matches_single_process(tmp_path, world, deferred, monkeypatch):
     """three global batches of whole subjects (the last one larger: a 1-subject tail is folded into it so that every rank takes
     part in every exchange), each: statistics all-reduce, reduce-scatter of the two dense gradient slices, Adam on the owned
     slices, all-gather of the bf16 copies, replicated small region -- against one process stepping on the global batches."""
-    port = 29500 + ((os.getpid() + 7 * world) % 500)
+    port = 29500 + ((os.getpid() + 7 * world + 3 * deferred) % 500)
+    monkeypatch.setenv("HLVAE_TEST_DEFERRED", "1" if deferred else "0")      # (deferred: collectives complete only in handle.wait())
     mp.spawn(_sharded_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         res = torch.load(os.path.join(tmp_path, f"s{r}.pt"))

@@ -16,10 +16,18 @@ void hl_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprin
 void hl_prof_begin(const char*, hipStream_t) {}
 void hl_prof_end(hipStream_t) {}
 unsigned long long* hl_stamp_slot(int) { return nullptr; }
+#ifdef UB_OLD_TREE          // built against the round-2 sources (.old/): one kernel, no switches
+static const int NV = 1;
+static const char* VN[5] = {"round-2 tree 64x64", "", "", "", ""};
+static void set_variant(int) {}
+static int g_hl_gemm_dma = 0;
+#else
+static const int NV = 5;
 extern int g_hl_gemm_dma;
 extern int g_hl_adam_tile;
 static const char* VN[5] = {"old 64x64", "dma 64x64", "dma 32x64", "dma 64x32", "dma 32x32"};
 static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_tile = v > 0 ? v - 1 : 0; }
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -80,7 +88,7 @@ int main(int argc, char** argv) {
         // correctness: set 2 keeps a pristine copy of set 0's state; set 1 is reloaded from it for every variant
         CK(hipMemcpy(P[2], P[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[2], M1[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[2], M2[0], arena * 4, hipMemcpyDeviceToDevice));
         launch(0, 0);
-        for (int v = 1; v < 5; ++v) {
+        for (int v = 1; v < NV; ++v) {
             CK(hipMemcpy(P[1], P[2], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[1], M1[2], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[1], M2[2], arena * 4, hipMemcpyDeviceToDevice));
             launch(1, v); CK(hipDeviceSynchronize());
             printf("gemm_adam wy  old vs %s: max|dP| %.3g  max|dM1| %.3g  max|dM2| %.3g  shadow cells differing %zu  shadowT %zu\n", VN[v],
@@ -90,9 +98,36 @@ int main(int argc, char** argv) {
         std::vector<float> t[5];
         int set = 0;
         for (int r = 0; r < reps; ++r)
-            for (int v = 0; v < 5; ++v) { set = (set + 1) % NSETS; t[v].push_back(T.run([&] { launch(set, v); })); }
+            for (int v = 0; v < NV; ++v) { set = (set + 1) % NSETS; t[v].push_back(T.run([&] { launch(set, v); })); }
         const double bytes = (double)(M + N) * Bp * 2 + 24.0 * M * N + 2.0 * 2 * M * N;
-        for (int v = 0; v < 5; ++v) printf("gemm_adam wy  %s: median %.2f us  min %.2f  -> %.2f TB/s algorithmic (%.1f MB)\n", VN[v], med(t[v]), *std::min_element(t[v].begin(), t[v].end()), bytes / med(t[v]) * 1e-6, bytes * 1e-6);
+        for (int v = 0; v < NV; ++v) printf("gemm_adam wy  %s: median %.2f us  min %.2f  -> %.2f TB/s algorithmic (%.1f MB)\n", VN[v], med(t[v]), *std::min_element(t[v].begin(), t[v].end()), bytes / med(t[v]) * 1e-6, bytes * 1e-6);
+        // ---- as bench.py launches it: master rows through a row map (the head kernel's variable order), completion tickets, state
+        // NOT rotated (one set: what the Infinity Cache keeps between two steps) -- each switch on its own
+        {
+            std::vector<int32_t> hmap(Mp);
+            for (int r = 0; r < Mp; ++r) hmap[r] = r;
+            // D4-like grouping by kind: variables (5 rows each) in runs of 18 are pulled to the front
+            { std::vector<int32_t> a, b; for (int d = 0; d < M / 5; ++d) (((d / 18) & 1) ? b : a).push_back(d);
+              int r = 0; for (int d : a) for (int k = 0; k < 5; ++k) hmap[r++] = d * 5 + k; for (int d : b) for (int k = 0; k < 5; ++k) hmap[r++] = d * 5 + k; }
+            int32_t* dmap = dalloc<int32_t>(Mp);
+            CK(hipMemcpy(dmap, hmap.data(), Mp * 4, hipMemcpyHostToDevice));
+            for (int cfg = 0; cfg < 8; ++cfg) {
+                const bool use_map = cfg & 1, use_tick = cfg & 2, rotate = !(cfg & 4);
+                for (int v = 0; v < (NV > 1 ? 2 : 1); ++v) {
+                    std::vector<float> tt;
+                    for (int r = 0; r < reps; ++r) {
+                        set = rotate ? (set + 1) % NSETS : 3;
+                        AdamGemmGroup g{};
+                        g.n = 1; g.K = Bp;
+                        g.p[0] = AdamGemmProb{dyT, uT, use_map ? dmap : nullptr, sh[set], shT[set], 0, 0, Bp, Bp, M, N, 0, 0, Np, Mp, 0, 0, 0};
+                        set_variant(v);
+                        const unsigned tick = use_tick ? (unsigned)hl_gemm_adam_grid(g) : 0u;
+                        tt.push_back(T.run([&] { if (hl_launch_gemm_adam(g, P[set], M1[set], M2[set], step, 1e-3f, 0.9f, 0.999f, 1e-8f, 1.f, tick, "x", 0, nullptr, 0, 0)) { printf("launch failed: %s\n", g_err); exit(1); } }));
+                    }
+                    printf("gemm_adam wy  %-18s rowmap %d tickets %d state %s: median %.2f us (min %.2f)\n", VN[v], (int)use_map, (int)use_tick, rotate ? "rotated (HBM)" : "one set (warm) ", med(tt), *std::min_element(tt.begin(), tt.end()));
+                }
+            }
+        }
         // the other three in one launch: dW1 [500][5184], dWd [500][32], d[Wmu;Wlv] [64][500]
         {
             const int h = 500, X = 5184, L = 32;
@@ -116,7 +151,7 @@ int main(int argc, char** argv) {
             };
             CK(hipMemcpy(P[2], P[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[2], M1[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[2], M2[0], arena * 4, hipMemcpyDeviceToDevice));
             launch3(0, 0); auto w_old = d2h(w1s, (size_t)512 * X);
-            for (int v = 1; v < 5; ++v) {
+            for (int v = 1; v < NV; ++v) {
                 CK(hipMemcpy(P[1], P[2], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[1], M1[2], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[1], M2[2], arena * 4, hipMemcpyDeviceToDevice));
                 launch3(1, v); CK(hipDeviceSynchronize());
                 printf("gemm_adam rest old vs %s: max|dP| %.3g  max|dM1| %.3g  shadow cells differing %zu\n", VN[v], maxdiff(d2h(P[0], arena), d2h(P[1], arena)),
@@ -124,9 +159,9 @@ int main(int argc, char** argv) {
             }
             std::vector<float> t3[5];
             for (int r = 0; r < reps; ++r)
-                for (int v = 0; v < 5; ++v) { set = (set + 1) % NSETS; t3[v].push_back(T.run([&] { launch3(set, v); })); }
+                for (int v = 0; v < NV; ++v) { set = (set + 1) % NSETS; t3[v].push_back(T.run([&] { launch3(set, v); })); }
             const double b3 = (double)(h + X) * Bp * 2 + 26.0 * h * X + (double)(h + L) * Bp * 2 + (double)(64 + h) * Bp * 2 + 28.0 * (h * L + 2 * L * h);
-            for (int v = 0; v < 5; ++v) printf("gemm_adam rest %s: median %.2f us  min %.2f  -> %.2f TB/s algorithmic (%.1f MB)\n", VN[v], med(t3[v]), *std::min_element(t3[v].begin(), t3[v].end()), b3 / med(t3[v]) * 1e-6, b3 * 1e-6);
+            for (int v = 0; v < NV; ++v) printf("gemm_adam rest %s: median %.2f us  min %.2f  -> %.2f TB/s algorithmic (%.1f MB)\n", VN[v], med(t3[v]), *std::min_element(t3[v].begin(), t3[v].end()), b3 / med(t3[v]) * 1e-6, b3 * 1e-6);
         }
     }
     // ---------------- split-K products ------------------------------------------------------------------------------------------
@@ -140,18 +175,18 @@ int main(int argc, char** argv) {
             g_hl_gemm_dma = dma;
             if (hl_launch_gemm_splitk(A, K, B, K, slab[dma], N, M, N, K, S, "x", 0)) { printf("launch failed: %s\n", g_err); exit(1); }
         };
-        launch(0); launch(1); CK(hipDeviceSynchronize());
-        auto s0 = d2h(slab[0], (size_t)S * M * N), s1 = d2h(slab[1], (size_t)S * M * N);
+        launch(0); if (NV > 1) launch(1); CK(hipDeviceSynchronize());
+        auto s0 = d2h(slab[0], (size_t)S * M * N), s1 = d2h(slab[NV > 1 ? 1 : 0], (size_t)S * M * N);
         double mx = 0; for (auto x : s0) mx = std::max(mx, (double)fabsf(x));
         printf("splitk %s old vs dma: max|d| %.3g (max |value| %.3g)\n", which ? "dU " : "enc1", maxdiff(s0, s1), mx);
         std::vector<float> t[2], tw[2];
         for (int r = 0; r < reps; ++r)
-            for (int v = 0; v < 2; ++v) {
+            for (int v = 0; v < (NV > 1 ? 2 : 1); ++v) {
                 CK(hipMemsetAsync(flush, r, (size_t)320 << 20, 0));          // operands and slabs out of L2 / Infinity Cache
                 t[v].push_back(T.run([&] { launch(v); }));
                 tw[v].push_back(T.run([&] { launch(v); }));                   // and once more, warm
             }
-        for (int v = 0; v < 2; ++v) printf("splitk %s %s: cold median %.2f us (min %.2f)   warm median %.2f us (min %.2f)\n", which ? "dU " : "enc1", v ? "dma" : "old", med(t[v]),
+        for (int v = 0; v < (NV > 1 ? 2 : 1); ++v) printf("splitk %s %s: cold median %.2f us (min %.2f)   warm median %.2f us (min %.2f)\n", which ? "dU " : "enc1", v ? "dma" : "old", med(t[v]),
                                            *std::min_element(t[v].begin(), t[v].end()), med(tw[v]), *std::min_element(tw[v].begin(), tw[v].end()));
     }
     return 0;
