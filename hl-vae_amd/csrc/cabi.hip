@@ -38,12 +38,12 @@ int hl_launch_gemm_f32_group(GemmGroup, const char*, hipStream_t);
 bool hl_gemm_adam_ok(int, int, int, bool);
 int hl_gemm_adam_grid(const AdamGemmGroup&);
 int hl_launch_gemm_adam(AdamGemmGroup, float*, float*, float*, int64_t*, float, float, float, float, float, unsigned, const char*, hipStream_t,
-                        float* Gflat = nullptr, long flat_lo = 0, long flat_n = 0);
+                        float* Gflat, long flat_lo, long flat_n, unsigned long long* tick_shards);
 int hl_wgrad_ksplit(long, int);
 int hl_launch_transpose_bf16(const bf16_t*, int, bf16_t*, int, int, int, const char*, hipStream_t);
 int hl_adam_grid(const hlvae_plan*, const hlvae_ws*, unsigned, int);
 int hl_adam_part(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, unsigned, int,
-                 unsigned, const char*, hipStream_t, long flat_n = -1);
+                 unsigned, const char*, hipStream_t, long flat_n = -1, int tick_slot = 0);
 int hl_adam_flat(const hlvae_plan*, const hlvae_ws*, const float*, float*, float*, uint16_t*, const int64_t*, long, long, float, float,
                  float, float, float, hipStream_t);
 int hl_shadows_from_bf16(const hlvae_plan*, const hlvae_ws*, const uint16_t*, unsigned, const char*, hipStream_t);
@@ -244,6 +244,7 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     hlvae_plan* p = new hlvae_plan();
     p->d = d;
     p->vars_dev = nullptr; p->col2var_dev = nullptr; p->stat_var_dev = nullptr; p->vars_sorted_dev = nullptr; p->wy_rowsrc_dev = nullptr;
+    p->tick_dev = nullptr;
     p->kmax = 2;
     p->pend_flags = 0;
     for (int i = 0; i < d.D; ++i)
@@ -255,6 +256,8 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     for (auto& ev : p->ev)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&p->tick_dev, sizeof(unsigned long long) * HL_TICK_SLOTS * HL_TICK_WORDS);
+    if (e == hipSuccess) e = hipMemset(p->tick_dev, 0, sizeof(unsigned long long) * HL_TICK_SLOTS * HL_TICK_WORDS);
     if (e == hipSuccess) e = hipMalloc(&p->vars_dev, sizeof(hlvae_var) * d.D);
     if (e == hipSuccess) e = hipMalloc(&p->col2var_dev, sizeof(int32_t) * d.Xp);
     if (e == hipSuccess) e = hipMalloc(&p->stat_var_dev, sizeof(int32_t) * stat_var.size());
@@ -277,6 +280,7 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
 void hlvae_plan_destroy(hlvae_plan* p) {
     if (!p) return;
     if (p->vars_dev) (void)hipFree(p->vars_dev);
+    if (p->tick_dev) (void)hipFree(p->tick_dev);
     if (p->vars_sorted_dev) (void)hipFree(p->vars_sorted_dev);
     if (p->wy_rowsrc_dev) (void)hipFree(p->wy_rowsrc_dev);
     if (p->col2var_dev) (void)hipFree(p->col2var_dev);
@@ -618,7 +622,8 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         g_wy.K = Bp;
         g_wy.p[0] = AdamGemmProb{dylT, ws->uT, p->wy_rowsrc_dev, wys_out, wyTs_out, (long)d.o_wy, 0, Bp, Bp, d.NYl, d.h_d, 0, 0, d.hdp,
                                  d.NYlp, 0, 0, 0};
-        tickets = (unsigned)(hl_gemm_adam_grid(g_rest) + hl_gemm_adam_grid(g_wy) + hl_adam_grid(p, ws, 0u, 1));
+        // (shard units of the three launches: common.h hl_take_ticket; slots 0 / 1 / 2 = the grouped launch, y_layer's, the small region's)
+        tickets = hl_ticket_units(hl_gemm_adam_grid(g_rest)) + hl_ticket_units(hl_gemm_adam_grid(g_wy)) + hl_ticket_units(hl_adam_grid(p, ws, 0u, 1));
         // (y_layer's launch created BEFORE dU_splitk -- the head kernel's first child starts at once, the caller's chain pays the
         // cross-queue start instead: dU_splitk 21 us late and 25 us long beside it, 0.142 vs 0.137 ms/step)
     }
@@ -692,15 +697,15 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
             // HBM-bound launches side by side take as long as one after the other (45 + 40 us together, 29 + 25 alone), so the second
             // hardware queue bought nothing but a fork, a join and a cross-queue parent for the step's end.
             if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
-                                          tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n))) return rc;
+                                          tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n, p->tick_dev))) return rc;
             // (y_layer's shadows: in place or into the caller's second pair, as above -- dU_splitk, this step's last reader of the
             //  first pair, ran before on this queue either way)
             if ((rc = hl_launch_gemm_adam(g_wy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
-                                          tickets, "dWy_adam", st))) return rc;
+                                          tickets, "dWy_adam", st, nullptr, 0, 0, p->tick_dev + HL_TICK_WORDS))) return rc;
             HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));
             if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s1))) return rc;
             if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tickets,
-                                   "adam_small", s1, bias_lo))) return rc;
+                                   "adam_small", s1, bias_lo, 2))) return rc;
             if (p->pend_flags & HL_PEND_DEFERRED) {
                 if ((rc = hl_flush_deferred(p, s1, true, HL_PEND_DEFERRED, false, true))) return rc;
             } else {
@@ -710,11 +715,11 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
             return hlvae_join(p, s);
         }
         if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
-                                      tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n))) return rc;
+                                      tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n, p->tick_dev))) return rc;
         HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
         if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s0))) return rc;
         if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tickets,
-                               "adam_small", s0, bias_lo))) return rc;      // (behind y_layer's launch instead: 0.139 vs 0.137 ms)
+                               "adam_small", s0, bias_lo, 2))) return rc;      // (behind y_layer's launch instead: 0.139 vs 0.137 ms)
         // y_layer's launch starts behind dU_splitk even when it writes the second shadow pair: the fused middle (64 workgroups of
         // 1024 threads) must be RESIDENT before the streaming launch takes every register of the chip -- started first, the
         // middle kernel waited for three of the four streaming workgroups of its CU to retire (33 us instead of 15; 0.138 ->
@@ -723,7 +728,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         const bool small_batch = Bp < 2048;
         if (g_wy.p[0].sh == ws->wys || small_batch) HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
         if ((rc = hl_launch_gemm_adam(g_wy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
-                                      tickets, "dWy_adam", s0))) return rc;
+                                      tickets, "dWy_adam", s0, nullptr, 0, 0, p->tick_dev + HL_TICK_WORDS))) return rc;
 
         HL_CHECK(hipEventRecord(p->ev[3], s0));
         // (large batches, metrics behind side 0's chain and the input stage alone on side 1: its 16-workgroup statistics kernel
@@ -818,7 +823,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         // (two concurrent Adam launches thrash HBM), but NOT behind side 1: its deferred kernels only have to be done
         // by the end of the step
         if ((rc = conv_opt ? hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1,
-                                          (unsigned)hl_adam_grid(p, ws, 0u, 1), "adam_small", st)
+                                          hl_ticket_units(hl_adam_grid(p, ws, 0u, 1)), "adam_small", st)
                            : hl_adam(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, st,
                                      (skip_wy || small_wy) ? 0 : 1)))
             return rc;
@@ -866,7 +871,7 @@ int hlvae_adam_shard(const hlvae_plan* p, const hlvae_ws* ws, const float* grad_
 int hlvae_adam_small(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float beta1,
                      float beta2, float eps, float grad_scale, hlvae_stream s) {
     HL_REQUIRE(p && ws && m1 && m2 && step_count, HLVAE_EINVAL, "adam_small: null argument");
-    return hl_adam_part(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, 0u, 1, (unsigned)hl_adam_grid(p, ws, 0u, 1),
+    return hl_adam_part(p, ws, m1, m2, step_count, lr, beta1, beta2, eps, grad_scale, 0u, 1, hl_ticket_units(hl_adam_grid(p, ws, 0u, 1)),
                         "adam_small", (hipStream_t)s);
 }
 

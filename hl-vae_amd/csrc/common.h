@@ -94,6 +94,32 @@ __device__ __forceinline__ float xor32_sum(float a) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// ---- completion tickets of an optimiser step --------------------------------------------------------------------------------
+// The launches that apply one optimiser step may run concurrently on different streams; the workgroup that finishes LAST, over all
+// of them, commits the device-side step number (step_count[0] += 1).  Rounds 1-2: every workgroup took a returning atomic on ONE
+// word (step_count[1]).  In a single-round streaming launch all ~800 workgroups reach that line within a microsecond or two and
+// the atomics serialise at the memory side (~12-20 ns each): the LAST return -- the kernel's end -- came 10-17 us after the last
+// store (round-3 micro-benchmark: 25 -> 43 us for y_layer's launch with tickets on).  Two levels now: a workgroup takes its ticket
+// on one of 32 shard counters of ITS launch (own 64-byte lines, library-owned memory, <= ~26 arrivals each); whoever completes a
+// shard takes one ticket on step_count[1], whose expected total is the number of shards with arrivals over all launches of the
+// step (hl_ticket_units per launch).  shards == nullptr: the one-level protocol (units_total = workgroups).
+#define HL_TICK_SHARDS 32
+#define HL_TICK_WORDS (8 * HL_TICK_SHARDS)                  // uint64 words per launch slot
+#define HL_TICK_SLOTS 4                                     // launch slots per plan
+static inline unsigned hl_ticket_units(int grid) { return (unsigned)(grid < HL_TICK_SHARDS ? grid : HL_TICK_SHARDS); }
+// thread 0 of the workgroup, behind the barrier that follows its last store
+__device__ __forceinline__ void hl_take_ticket(int64_t* step_count, unsigned long long* shards, unsigned units_total) {
+    if (shards != nullptr) {
+        const unsigned nblk = gridDim.x * gridDim.y, b = blockIdx.x + blockIdx.y * gridDim.x, s = b & (HL_TICK_SHARDS - 1);
+        const unsigned expect = (nblk - s + HL_TICK_SHARDS - 1) / HL_TICK_SHARDS;       // workgroups of this launch on shard s
+        const unsigned long long got = atomicAdd(shards + 8 * s, 1ull);
+        if (got != expect - 1) return;
+        shards[8 * s] = 0ull;                               // (the last arrival: nobody else touches the shard before the next step)
+    }
+    const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
+    if (done == units_total - 1) { step_count[1] = 0; step_count[0] += 1; }
+}
+
 struct hlvae_plan {
     hlvae_dims d;
     hlvae_var* vars_dev;      // [D]
@@ -102,6 +128,7 @@ struct hlvae_plan {
                                   // nullptr: identity (convolutional model, or variables already grouped)
     int32_t* col2var_dev;     // [Xp]  variable of an expanded column, -1 in the padding
     int32_t* stat_var_dev;    // [n_stat] variable index of each statistics row
+    unsigned long long* tick_dev;   // [HL_TICK_SLOTS][HL_TICK_WORDS] shard counters of the optimiser launches' completion tickets (zero between steps)
     int kmax;                 // largest class count among cat / ordinal variables (selects the head-kernel instance)
     // fork/join side streams: independent weight-gradient GEMMs run beside the critical path of the backward
     hipStream_t side[2];

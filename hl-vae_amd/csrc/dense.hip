@@ -118,7 +118,8 @@ template <int BK>
 __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
                                                           float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
                                                           float b1, float b2, float eps, float gscale, unsigned ticket_total,
-                                                          float* __restrict__ Gflat, long flat_lo4, long flat_n4, unsigned long long* stamp) {
+                                                          float* __restrict__ Gflat, long flat_lo4, long flat_n4, unsigned long long* stamp,
+                                                          unsigned long long* tick_shards) {
     HL_STAMP_T0(stamp);
     using G = GemmNT<64, 64, BK, 2, 2>;
     constexpr int CLD = G::CLD;
@@ -222,10 +223,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, fl
     }
     if (ticket_total != 0) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
-            if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
-        }
+        if (threadIdx.x == 0) hl_take_ticket(step_count, tick_shards, ticket_total);
     }
     HL_STAMP_END(stamp);
 }
@@ -241,7 +239,8 @@ __global__ __launch_bounds__(HL_THREADS, MINW) void k_gemm_adam_dma(AdamGemmGrou
                                                                  float* __restrict__ M2, int64_t* __restrict__ step_count, float lr,
                                                                  float b1, float b2, float eps, float gscale, unsigned ticket_total,
                                                                  float* __restrict__ Gflat, long flat_lo4, long flat_n4,
-                                                                 unsigned long long* stamp) {
+                                                                 unsigned long long* stamp, int stagger,
+                                                                 unsigned long long* tick_shards) {
     HL_STAMP_T0(stamp);
     using G = GemmDMA<BM, BN, 2, 2, NBUF, BN + 4>;
     constexpr int CLD = G::CLD;
@@ -284,15 +283,29 @@ __global__ __launch_bounds__(HL_THREADS, MINW) void k_gemm_adam_dma(AdamGemmGrou
         in[i] = base >= 0;
         o[i] = (int)(in[i] ? base + n0 + c4 : q.off);
     }
+    // stagger: the workgroups are all resident at once (one round), so they would all read their state, then all multiply (an
+    // L2 -> LDS phase: 816 tiles x 131 KB of operands, HBM idle), then all write.  Odd tiles therefore run the product FIRST
+    // and request their state behind it: while one half of the chip streams from HBM the other half multiplies out of L2.
+    const bool late = stagger && (lid & 1);
+    if (!late) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        p[i] = *reinterpret_cast<const float4*>(P + o[i]);
-        m[i] = *reinterpret_cast<const float4*>(M1 + o[i]);
-        v[i] = *reinterpret_cast<const float4*>(M2 + o[i]);
+        for (int i = 0; i < NP; ++i) {
+            p[i] = *reinterpret_cast<const float4*>(P + o[i]);
+            m[i] = *reinterpret_cast<const float4*>(M1 + o[i]);
+            v[i] = *reinterpret_cast<const float4*>(M2 + o[i]);
+        }
     }
     typename G::Acc acc;
     G::zero(acc);
     G::run(q.A, q.lda, q.B, q.ldb, m0, n0, M, N, 0, g.K, smem, acc);
+    if (late) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            p[i] = *reinterpret_cast<const float4*>(P + o[i]);
+            m[i] = *reinterpret_cast<const float4*>(M1 + o[i]);
+            v[i] = *reinterpret_cast<const float4*>(M2 + o[i]);
+        }
+    }
     G::to_lds(acc, smem);
     float* Cs = reinterpret_cast<float*>(smem);
     const AdamScalars a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
@@ -351,10 +364,7 @@ __global__ __launch_bounds__(HL_THREADS, MINW) void k_gemm_adam_dma(AdamGemmGrou
     }
     if (ticket_total != 0) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
-            if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
-        }
+        if (threadIdx.x == 0) hl_take_ticket(step_count, tick_shards, ticket_total);
     }
     HL_STAMP_END(stamp);
 }
@@ -595,6 +605,11 @@ static int hl_adam_tile() {
     }
     return g_hl_adam_tile;
 }
+int g_hl_adam_stagger = -1;
+static int hl_adam_stagger() {       // HL_ADAM_STAGGER=0 switches the phase stagger off (A/B)
+    if (g_hl_adam_stagger < 0) { const char* e = getenv("HL_ADAM_STAGGER"); g_hl_adam_stagger = (e != nullptr && e[0] == '0') ? 0 : 1; }
+    return g_hl_adam_stagger;
+}
 static void hl_adam_tile_shape(int K, int& bm, int& bn) {
     bm = bn = 64;
     if (K % 64 == 0 && hl_use_dma()) {
@@ -613,7 +628,10 @@ int hl_gemm_adam_grid(const AdamGemmGroup& g) {
 }
 
 int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t* step_count, float lr, float b1, float b2, float eps,
-                        float gscale, unsigned ticket_total, const char* label, hipStream_t s, float* Gflat, long flat_lo, long flat_n) {
+                        float gscale, unsigned ticket_total, const char* label, hipStream_t s, float* Gflat, long flat_lo, long flat_n,
+                        unsigned long long* tick_shards) {
+    // tick_shards: this launch's shard counters (common.h hl_take_ticket; ticket_total then counts shard units over the step's
+    // launches), or nullptr: one-level tickets (ticket_total = workgroups)
     HL_REQUIRE(g.n >= 1 && g.n <= 3 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm_adam: n=%d K=%d", g.n, g.K);
     HL_REQUIRE(flat_lo % 4 == 0 && flat_n % 4 == 0 && flat_n >= 0 && (flat_n == 0 || Gflat != nullptr), HLVAE_ESHAPE,
                "gemm_adam: flat range [%ld, +%ld) must be 4-aligned", flat_lo, flat_n);
@@ -636,16 +654,16 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
     HL_PROF(label, s);
     const int grid = t;
     unsigned long long* stamp = hl_stamp_slot(g.n == 1 ? HL_ST_ADAM_WY : HL_ST_ADAM_REST);
-#define HL_GA(BMv, BNv, MINWv) k_gemm_adam_dma<BMv, BNv, 2, MINWv><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp)
+#define HL_GA(BMv, BNv, MINWv) k_gemm_adam_dma<BMv, BNv, 2, MINWv><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp, hl_adam_stagger(), tick_shards)
     if (g.K % 64 == 0 && hl_use_dma()) {
         if (bm == 64 && bn == 64) HL_GA(64, 64, 4);
         else if (bm == 32 && bn == 64) HL_GA(32, 64, 6);
         else if (bm == 64 && bn == 32) HL_GA(64, 32, 6);
         else HL_GA(32, 32, 6);
     } else if (g.K % 64 == 0)
-        k_gemm_adam<64><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp);
+        k_gemm_adam<64><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp, tick_shards);
     else
-        k_gemm_adam<32><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp);
+        k_gemm_adam<32><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp, tick_shards);
 #undef HL_GA
     HL_LAUNCH_CHECK();
     return 0;

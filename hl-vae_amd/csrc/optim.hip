@@ -38,7 +38,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
                                                            int64_t* __restrict__ step_count, float lr, float b1,
                                                            float b2, float eps, float gscale, int update, long n4_flat,
                                                            unsigned ticket_total, const bf16_t* __restrict__ Pb16,
-                                                           long frozen_lo4, long frozen_hi4) {
+                                                           long frozen_lo4, long frozen_hi4, unsigned long long* tick_shards) {
     // update: 0 = shadows only; 1 = Adam with step number step_count[0] + 1.  Workgroups past the tiles (if the launch
     // has any) update the small flat region [0, 4 n4_flat) and zero its gradients.  ticket_total = workgroups of ALL the
     // launches of this optimiser step (0: this launch takes no tickets).
@@ -70,10 +70,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
             G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);           // the atomically accumulated gradients start the next step at 0
         }
         __syncthreads();
-        if (threadIdx.x == 0 && ticket_total != 0) {
-            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
-            if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
-        }
+        if (threadIdx.x == 0 && ticket_total != 0) hl_take_ticket(step_count, tick_shards, ticket_total);
         return;
     }
     int mi = 0;
@@ -188,10 +185,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_adam_tiled(ShadowSet set, float*
     }
     if (update && ticket_total != 0) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step_count + 1), 1ull);
-            if (done == ticket_total - 1) { step_count[1] = 0; step_count[0] += 1; }
-        }
+        if (threadIdx.x == 0) hl_take_ticket(step_count, tick_shards, ticket_total);
     }
 }
 
@@ -267,7 +261,7 @@ int hl_refresh_shadows(const hlvae_plan* p, const hlvae_ws* ws, hipStream_t s) {
     {
         HL_PROF("shadow_cast", s);
         k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 0u,
-                                                            nullptr, 0, 0);
+                                                            nullptr, 0, 0, nullptr);
         HL_LAUNCH_CHECK();
     }
     if (p->d.conv) return hl_conv_pack_weights(p, ws, s);
@@ -290,7 +284,8 @@ int hl_adam_grid(const hlvae_plan* p, const hlvae_ws* ws, unsigned which, int wi
 // launch of the same step behind this one).
 int hl_adam_part(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
                  float b2, float eps, float gscale, unsigned which, int with_flat, unsigned ticket_total, const char* label,
-                 hipStream_t s, long flat_n = -1) {      // flat_n >= 0: only [0, flat_n) of the small region (same workgroup count)
+                 hipStream_t s, long flat_n = -1, int tick_slot = 0) {      // flat_n >= 0: only [0, flat_n) of the small region (same workgroup count)
+    // ticket_total: shard units of ALL the launches of this step (common.h hl_ticket_units per launch); tick_slot: this launch's slot
     const hlvae_dims& d = p->d;
     HL_REQUIRE(d.atomic_region % 4 == 0, HLVAE_ESHAPE, "atomic region %ld not a multiple of 4", (long)d.atomic_region);
     const ShadowSet set = make_set(p, ws, which);
@@ -300,7 +295,7 @@ int hl_adam_part(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, 
         HL_PROF(label, s);
         k_adam_tiled<<<grid, HL_THREADS, 0, s>>>(set, ws->P, ws->G, m1, m2, step_count, lr, b1, b2, eps, gscale, 1,
                                                  with_flat ? (flat_n >= 0 ? flat_n : d.atomic_region) / 4 : 0, ticket_total, nullptr, d.frozen_lo / 4,
-                                                 (d.frozen_hi + 3) / 4);
+                                                 (d.frozen_hi + 3) / 4, p->tick_dev + (size_t)tick_slot * HL_TICK_WORDS);
         HL_LAUNCH_CHECK();
     }
     if (with_flat && d.conv) return hl_conv_pack_weights(p, ws, s);   // the convolution weights live in the flat region
@@ -311,7 +306,7 @@ int hl_adam_part(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, 
 int hl_adam(const hlvae_plan* p, const hlvae_ws* ws, float* m1, float* m2, int64_t* step_count, float lr, float b1,
             float b2, float eps, float gscale, hipStream_t s, int skip_wy) {
     const unsigned which = all_matrices(p->d) & (skip_wy ? ~0x01u : ~0u);
-    return hl_adam_part(p, ws, m1, m2, step_count, lr, b1, b2, eps, gscale, which, 1, (unsigned)hl_adam_grid(p, ws, which, 1),
+    return hl_adam_part(p, ws, m1, m2, step_count, lr, b1, b2, eps, gscale, which, 1, hl_ticket_units(hl_adam_grid(p, ws, which, 1)),
                         skip_wy ? "adam_weights_shadows" : "adam_all_in_one", s);
 }
 
@@ -383,7 +378,7 @@ int hl_shadows_from_bf16(const hlvae_plan* p, const hlvae_ws* ws, const uint16_t
     if (set.total_tiles == 0) return 0;
     HL_PROF(label, s);
     k_adam_tiled<<<set.total_tiles, HL_THREADS, 0, s>>>(set, ws->P, ws->G, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 0u,
-                                                        pb16, 0, 0);
+                                                        pb16, 0, 0, nullptr);
     HL_LAUNCH_CHECK();
     return 0;
 }

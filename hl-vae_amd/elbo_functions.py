@@ -324,6 +324,7 @@ class GPPriorHIP:
         self._groups = _GroupCache()
         self._grad_m = self._grad_H = self._iH = self._tmp = None
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
+        self._prep, self._prep_stream = None, None
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
             for t in (self._theta, self.m, self._KH):
                 dp.broadcast_(t)
@@ -435,24 +436,32 @@ class GPPriorHIP:
             self.fail.zero_()
             raise RuntimeError("GPPriorHIP: a covariance (K0zz, H, iH_new or a subject block) is not positive definite")
 
-    def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None, join=True):
-        """mu, log_v: fp32 [B, L] (the workspace tensors of the VAE); returns fp32 [B, L] gradients.  Hyper-parameter
-        and inducing-point gradients are left in ``prm.grad`` / ``zt_list.grad``.  Every product, reduction and element-wise
-        step runs in the kernels of csrc/gp.hip; no host synchronisation when ``groups`` comes from the sampler."""
-        lib, st = _lib.load(), self._stream()
-        L, M, Q, B = self.L, self.M, self.Q, mu.shape[0]
-        dev = mu.device
-        c = float(P_total) / float(P_batch)
-        x = train_x.contiguous()
-        # subject structure of the batch: [S, T] batch rows of each subject, -1 = padding.  The sampler knows it when it builds
-        # the batch (datafeed.subject_index, no device work); from a bare covariate tensor it costs a host round trip, cached
-        idx = groups if groups is not None else self._group(x)
-        if idx.dtype != torch.int32 or not idx.is_contiguous() or idx.dim() != 2:
-            raise ValueError("groups: contiguous int32 [S, T] tensor of batch-row indices, -1 = padding")
-        S, T = idx.shape
-        if mu.dtype != torch.float32 or log_v.dtype != torch.float32 or not mu.is_contiguous() or not log_v.is_contiguous():
-            mu, log_v = mu.to(torch.float32).contiguous(), log_v.to(torch.float32).contiguous()
-        k0, k1, z = self.k0, self.k1, self.zt_list
+    def prepare(self, labels, rows=None, groups=None):
+        """Everything of the bound that depends on the prior's own state and on the batch's COVARIATES only -- transformed
+        hyper-parameters, K0xz, (the factorisations when none were left behind), iK m, H iK, iK - iK H iK, the cleared
+        accumulators -- queued on a stream of the prior's, forked from the caller's here.  Called at the top of a training step
+        (ELBOTrainer) it runs UNDER the VAE's forward pass (encoder, fused middle, head kernel: ~75 us at 1024 rows) instead of
+        between it and the per-subject kernel (~80 us of the step's critical path, round-3 timeline); ``kl_and_grads`` joins it.
+        labels [N, Q] covariates; rows (int32 device tensor): the batch's rows of ``labels`` (the gather runs on the side stream
+        too); groups: the subject structure, as for kl_and_grads."""
+        dev = labels.device
+        main = torch.cuda.current_stream(dev)
+        if self._prep_stream is None:
+            self._prep_stream = torch.cuda.Stream(device=dev)
+        sP = self._prep_stream
+        sP.wait_stream(main)
+        with torch.cuda.stream(sP):
+            x = labels if rows is None else labels.index_select(0, rows.long())
+            x = x.contiguous()
+            idx = groups if groups is not None else self._group(x)
+            st_ = self._prepare_state(x, idx.shape[0], idx.shape[1], x.shape[0], dev)
+        self._prep = (x, idx) + st_
+        return x
+
+    def _prepare_state(self, x, S, T, B, dev):
+        """the state-only launches (current stream); returns (buf, hyp, Kxz, iKm, HiK, N1)"""
+        L, M = self.L, self.M
+        k0, z = self.k0, self.zt_list
         buf = self._step_buffers(B, S, T, dev)
         mm = self._mm
         hyp = self._transform()
@@ -463,9 +472,50 @@ class GPPriorHIP:
             self.kernel_matrix(k0, z, z, jitter=self.eps, out=self._KH[:L])
             self._spd_inv(self._KH[:L], self._iK, self._ldK)
             self._spd_inv(self.H, self._iHb, self._ldH)
+        iK = self._iK
+        iKm = self._bmv(iK, self.m, mm["iKm"])                               # [L,M,1]
+        HiK = self._bmm_into(self.H, iK, mm["HiK"])
+        N1 = self._bmm_into(iK, HiK, mm["N1"], D=iK, alpha=-1.0, beta=1.0)   # iK - iK H iK
+        if self._fuse_sums:
+            LMM, LM = L * M * M, L * M
+            self._xchg[LMM:LMM + 2 * LM].zero_()                             # P1, u: accumulated by the per-subject kernel
+        return buf, hyp, Kxz, iKm, HiK, N1
+
+    def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None, join=True):
+        """mu, log_v: fp32 [B, L] (the workspace tensors of the VAE); returns fp32 [B, L] gradients.  Hyper-parameter
+        and inducing-point gradients are left in ``prm.grad`` / ``zt_list.grad``.  Every product, reduction and element-wise
+        step runs in the kernels of csrc/gp.hip; no host synchronisation when ``groups`` comes from the sampler.
+        train_x None: the batch ``prepare`` was called for."""
+        lib, st = _lib.load(), self._stream()
+        L, M, Q, B = self.L, self.M, self.Q, mu.shape[0]
+        dev = mu.device
+        c = float(P_total) / float(P_batch)
+        prep, self._prep = self._prep, None
+        if prep is not None and (train_x is None or train_x is prep[0]):
+            x, idx, buf, hyp, Kxz, iKm, HiK, N1 = prep
+            torch.cuda.current_stream(dev).wait_stream(self._prep_stream)
+            x.record_stream(torch.cuda.current_stream(dev))                  # (allocated on the side stream, read on this one)
+            if x.shape[0] != B:
+                raise ValueError(f"kl_and_grads: prepare() saw {x.shape[0]} rows, the encoder outputs have {B}")
+        else:
+            if train_x is None:
+                raise ValueError("kl_and_grads(train_x=None) needs a preceding prepare()")
+            if prep is not None:                                             # prepared for another batch: drop it (ordered, unused)
+                torch.cuda.current_stream(dev).wait_stream(self._prep_stream)
+            x = train_x.contiguous()
+            # subject structure of the batch: [S, T] batch rows of each subject, -1 = padding.  The sampler knows it when it builds
+            # the batch (datafeed.subject_index, no device work); from a bare covariate tensor it costs a host round trip, cached
+            idx = groups if groups is not None else self._group(x)
+            buf, hyp, Kxz, iKm, HiK, N1 = self._prepare_state(x, idx.shape[0], idx.shape[1], B, dev)
+        if idx.dtype != torch.int32 or not idx.is_contiguous() or idx.dim() != 2:
+            raise ValueError("groups: contiguous int32 [S, T] tensor of batch-row indices, -1 = padding")
+        S, T = idx.shape
+        if mu.dtype != torch.float32 or log_v.dtype != torch.float32 or not mu.is_contiguous() or not log_v.is_contiguous():
+            mu, log_v = mu.to(torch.float32).contiguous(), log_v.to(torch.float32).contiguous()
+        k0, k1, z = self.k0, self.k1, self.zt_list
+        mm = self._mm
         iK, iH, ldK, ldH = self._iK, self._iHb, self._ldK, self._ldH
         self._iH = iH
-        iKm = self._bmv(iK, self.m, mm["iKm"])                               # [L,M,1]
         LMM, LM = L * M * M, L * M
         W = self._xchg[:LMM].view(L, M, M)
         P1 = self._xchg[LMM:LMM + LM].view(L, M, 1)
@@ -475,7 +525,6 @@ class GPPriorHIP:
             # the residual a = K0xz iK m - mu^T and the two matrix^T-vector sums P1 = V^T mu, u = K0xz^T v (elbo_functions.py:
             # 262-266) are computed inside the per-subject kernel from its LDS tile of K0xz (round 3): three launches and three
             # 31 MB passes less (gp_resid 9 us on the critical path, the two gemv_t 76 + 32 us on the natural-gradient chain)
-            self._xchg[LMM:LMM + 2 * LM].zero_()
             resid = None
         else:
             resid = buf["resid"]                                             # K0xz iK m - mu^T   [L,B]
@@ -493,8 +542,6 @@ class GPPriorHIP:
         # its own stream (ELBOTrainer: the VAE's backward pass + optimiser); optimizer_step() / join() wait for them.
         main = torch.cuda.current_stream(dev)
         sA, sC = self._streams(dev)
-        HiK = self._bmm_into(self.H, iK, mm["HiK"])
-        N1 = self._bmm_into(iK, HiK, mm["N1"], D=iK, alpha=-1.0, beta=1.0)   # iK - iK H iK
         sA.wait_stream(main)
         sC.wait_stream(main)
         world = 1 if self.dp is None else self.dp.world

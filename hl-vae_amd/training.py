@@ -16,6 +16,7 @@ pass as the forward.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Optional
 
 import torch
@@ -261,7 +262,13 @@ class ELBOTrainer:
             raise ValueError("step_rows(prefetch_rows=...): the convolutional input stage reads the weights, it cannot run ahead")
         if not prepacked:
             self._feed_stage(ds, rows, B)
-        train_x = ds.labels.index_select(0, rows.long()) if self.kl == "gp" else None
+        train_x = None
+        if self.kl == "gp":
+            if hasattr(self.gp, "prepare") and os.environ.get("HL_GP_PREPARE", "1") != "0":
+                # the prior's state-only launches (and the covariate gather) run on a stream of its own under the VAE's forward pass
+                train_x = self.gp.prepare(ds.labels, rows, groups=groups)
+            else:
+                train_x = ds.labels.index_select(0, rows.long())
         self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None,
                         feed_next=None if prefetch_rows is None else (ds, prefetch_rows), groups=groups)
 

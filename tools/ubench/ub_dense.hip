@@ -16,6 +16,11 @@ void hl_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprin
 void hl_prof_begin(const char*, hipStream_t) {}
 void hl_prof_end(hipStream_t) {}
 unsigned long long* hl_stamp_slot(int) { return nullptr; }
+#ifdef UB_OLD_TREE
+#define UB_TICK_NULL
+#else
+#define UB_TICK_NULL , nullptr
+#endif
 #ifdef UB_OLD_TREE          // built against the round-2 sources (.old/): one kernel, no switches
 static const int NV = 1;
 static const char* VN[5] = {"round-2 tree 64x64", "", "", "", ""};
@@ -25,8 +30,9 @@ static int g_hl_gemm_dma = 0;
 static const int NV = 5;
 extern int g_hl_gemm_dma;
 extern int g_hl_adam_tile;
-static const char* VN[5] = {"old 64x64", "dma 64x64", "dma 32x64", "dma 64x32", "dma 32x32"};
-static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_tile = v > 0 ? v - 1 : 0; }
+extern int g_hl_adam_stagger;
+static const char* VN[5] = {"old 64x64", "dma 64x64", "dma 64x64 stagger", "dma 32x64 stagger", "dma 64x32 stagger"};
+static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_tile = v >= 3 ? v - 2 : 0; g_hl_adam_stagger = v >= 2; }
 #endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -83,7 +89,7 @@ int main(int argc, char** argv) {
             g.n = 1; g.K = Bp;
             g.p[0] = AdamGemmProb{dyT, uT, nullptr, sh[set], shT[set], 0, 0, Bp, Bp, M, N, 0, 0, Np, Mp, 0, 0, 0};
             set_variant(dma);
-            if (hl_launch_gemm_adam(g, P[set], M1[set], M2[set], step, 1e-3f, 0.9f, 0.999f, 1e-8f, 1.f, 0u, "x", 0, nullptr, 0, 0)) { printf("launch failed: %s\n", g_err); exit(1); }
+            if (hl_launch_gemm_adam(g, P[set], M1[set], M2[set], step, 1e-3f, 0.9f, 0.999f, 1e-8f, 1.f, 0u, "x", 0, nullptr, 0, 0 UB_TICK_NULL)) { printf("launch failed: %s\n", g_err); exit(1); }
         };
         // correctness: set 2 keeps a pristine copy of set 0's state; set 1 is reloaded from it for every variant
         CK(hipMemcpy(P[2], P[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[2], M1[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[2], M2[0], arena * 4, hipMemcpyDeviceToDevice));
@@ -111,9 +117,16 @@ int main(int argc, char** argv) {
               int r = 0; for (int d : a) for (int k = 0; k < 5; ++k) hmap[r++] = d * 5 + k; for (int d : b) for (int k = 0; k < 5; ++k) hmap[r++] = d * 5 + k; }
             int32_t* dmap = dalloc<int32_t>(Mp);
             CK(hipMemcpy(dmap, hmap.data(), Mp * 4, hipMemcpyHostToDevice));
-            for (int cfg = 0; cfg < 8; ++cfg) {
-                const bool use_map = cfg & 1, use_tick = cfg & 2, rotate = !(cfg & 4);
-                for (int v = 0; v < (NV > 1 ? 2 : 1); ++v) {
+#ifndef UB_OLD_TREE
+            unsigned long long* shards = dalloc<unsigned long long>(HL_TICK_WORDS);
+            const int NCFG = 12;
+#else
+            const int NCFG = 8;
+#endif
+            for (int cfg = 0; cfg < NCFG; ++cfg) {
+                const bool two_level = cfg >= 8;
+                const bool use_map = cfg & 1, use_tick = two_level || (cfg & 2), rotate = two_level ? !(cfg & 2) : !(cfg & 4);
+                for (int v = 0; v < (NV > 1 ? 3 : 1); ++v) {
                     std::vector<float> tt;
                     for (int r = 0; r < reps; ++r) {
                         set = rotate ? (set + 1) % NSETS : 3;
@@ -121,10 +134,15 @@ int main(int argc, char** argv) {
                         g.n = 1; g.K = Bp;
                         g.p[0] = AdamGemmProb{dyT, uT, use_map ? dmap : nullptr, sh[set], shT[set], 0, 0, Bp, Bp, M, N, 0, 0, Np, Mp, 0, 0, 0};
                         set_variant(v);
+#ifndef UB_OLD_TREE
+                        const unsigned tick = use_tick ? (two_level ? hl_ticket_units(hl_gemm_adam_grid(g)) : (unsigned)hl_gemm_adam_grid(g)) : 0u;
+                        tt.push_back(T.run([&] { if (hl_launch_gemm_adam(g, P[set], M1[set], M2[set], step, 1e-3f, 0.9f, 0.999f, 1e-8f, 1.f, tick, "x", 0, nullptr, 0, 0, two_level ? shards : nullptr)) { printf("launch failed: %s\n", g_err); exit(1); } }));
+#else
                         const unsigned tick = use_tick ? (unsigned)hl_gemm_adam_grid(g) : 0u;
                         tt.push_back(T.run([&] { if (hl_launch_gemm_adam(g, P[set], M1[set], M2[set], step, 1e-3f, 0.9f, 0.999f, 1e-8f, 1.f, tick, "x", 0, nullptr, 0, 0)) { printf("launch failed: %s\n", g_err); exit(1); } }));
+#endif
                     }
-                    printf("gemm_adam wy  %-18s rowmap %d tickets %d state %s: median %.2f us (min %.2f)\n", VN[v], (int)use_map, (int)use_tick, rotate ? "rotated (HBM)" : "one set (warm) ", med(tt), *std::min_element(tt.begin(), tt.end()));
+                    printf("gemm_adam wy  %-18s rowmap %d tickets %s state %s: median %.2f us (min %.2f)\n", VN[v], (int)use_map, two_level ? "2-level" : (use_tick ? "1-level" : "off    "), rotate ? "rotated (HBM)" : "one set (warm) ", med(tt), *std::min_element(tt.begin(), tt.end()));
                 }
             }
         }
@@ -147,7 +165,7 @@ int main(int argc, char** argv) {
                 g.p[1] = AdamGemmProb{duT, zbT, nullptr, wds, wdTs, o_wd, 0, Bp, Bp, h, L, 0, 0, 32, 512, 0, 0, 0};
                 g.p[2] = AdamGemmProb{dmlT, tT, nullptr, wmls, wmlTs, o_wmu, o_wlv, Bp, Bp, 64, h, 32, L, 512, 64, 0, 0, 0};
                 set_variant(dma);
-                if (hl_launch_gemm_adam(g, P[set], M1[set], M2[set], step, 1e-3f, 0.9f, 0.999f, 1e-8f, 1.f, 0u, "x", 0, nullptr, 0, 0)) { printf("launch failed: %s\n", g_err); exit(1); }
+                if (hl_launch_gemm_adam(g, P[set], M1[set], M2[set], step, 1e-3f, 0.9f, 0.999f, 1e-8f, 1.f, 0u, "x", 0, nullptr, 0, 0 UB_TICK_NULL)) { printf("launch failed: %s\n", g_err); exit(1); }
             };
             CK(hipMemcpy(P[2], P[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M1[2], M1[0], arena * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(M2[2], M2[0], arena * 4, hipMemcpyDeviceToDevice));
             launch3(0, 0); auto w_old = d2h(w1s, (size_t)512 * X);
