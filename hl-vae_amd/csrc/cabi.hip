@@ -690,7 +690,33 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         const long bias_lo = d.o_bd, bias_n = d.atomic_region - d.o_bd;
         HL_REQUIRE(d.o_bd % 4 == 0 && bias_n % 4 == 0 && d.o_bmu > d.o_bd && d.o_blv > d.o_bd && d.o_b1 > d.o_bd && d.o_by < d.o_bd,
                    HLVAE_EINVAL, "backward_adam: the arena must end its small region with [bd | bmu | blv | b1]");
-        static const bool one_side = getenv("HL_ONE_SIDE") != nullptr;
+        static const int one_side_mode = getenv("HL_ONE_SIDE") != nullptr ? atoi(getenv("HL_ONE_SIDE")) : 0;
+        const bool one_side = one_side_mode != 0;
+        if (one_side_mode == 2 && Bp < 2048) {
+            // as below, with all four products in ONE launch (y_layer's first: its misaligned rows want the XCD-contiguous tile order):
+            // 1480 tiles on 1024 slots -- the second round's workgroups start while the first round's are still writing
+            AdamGemmGroup g_all{};
+            g_all.n = 4;
+            g_all.K = Bp;
+            g_all.p[0] = g_wy.p[0];
+            g_all.p[1] = g_rest.p[0];
+            g_all.p[2] = g_rest.p[1];
+            g_all.p[3] = g_rest.p[2];
+            const unsigned tk = hl_ticket_units(hl_gemm_adam_grid(g_all)) + hl_ticket_units(hl_adam_grid(p, ws, 0u, 1));
+            if ((rc = hl_launch_gemm_adam(g_all, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
+                                          tk, "dWy_adam", st, ws->G, bias_lo, bias_n, p->tick_dev))) return rc;
+            HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));
+            if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s1))) return rc;
+            if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tk,
+                                   "adam_small", s1, bias_lo, 2))) return rc;
+            if (p->pend_flags & HL_PEND_DEFERRED) {
+                if ((rc = hl_flush_deferred(p, s1, true, HL_PEND_DEFERRED, false, true))) return rc;
+            } else {
+                HL_CHECK(hipEventRecord(p->ev[5], s1));
+                p->pend_flags |= HL_PEND_RUNNING;
+            }
+            return hlvae_join(p, s);
+        }
         if (one_side && Bp < 2048) {
             // Variant (round 3, A/B): BOTH streaming launches on the caller's queue, back to back, and ONE side queue for everything
             // small (gradient fold, small-region Adam, the next batch's input stage, ELBO scalars + metrics).  Measured before: the two

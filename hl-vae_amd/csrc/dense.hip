@@ -126,7 +126,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, fl
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
     int pi = 0;
 #pragma unroll
-    for (int k = 1; k < 3; ++k)
+    for (int k = 1; k < 4; ++k)
         if (k < g.n && (int)blockIdx.x >= g.p[k].tile0) pi = k;
     const AdamGemmProb& q = g.p[pi];
     // problem 0 starts at workgroup 0: its XCD-contiguous order is exact (consecutive ids share the row panel of A)
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(HL_THREADS, MINW) void k_gemm_adam_dma(AdamGemmGrou
     __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
     int pi = 0;
 #pragma unroll
-    for (int k = 1; k < 3; ++k)
+    for (int k = 1; k < 4; ++k)
         if (k < g.n && (int)blockIdx.x >= g.p[k].tile0) pi = k;
     const AdamGemmProb& q = g.p[pi];
     const int lid = pi == 0 ? xcd_remap(blockIdx.x, q.tiles_m * q.tiles_n) : (int)blockIdx.x - q.tile0;
@@ -632,7 +632,7 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
                         unsigned long long* tick_shards) {
     // tick_shards: this launch's shard counters (common.h hl_take_ticket; ticket_total then counts shard units over the step's
     // launches), or nullptr: one-level tickets (ticket_total = workgroups)
-    HL_REQUIRE(g.n >= 1 && g.n <= 3 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm_adam: n=%d K=%d", g.n, g.K);
+    HL_REQUIRE(g.n >= 1 && g.n <= 4 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm_adam: n=%d K=%d", g.n, g.K);
     HL_REQUIRE(flat_lo % 4 == 0 && flat_n % 4 == 0 && flat_n >= 0 && (flat_n == 0 || Gflat != nullptr), HLVAE_ESHAPE,
                "gemm_adam: flat range [%ld, +%ld) must be 4-aligned", flat_lo, flat_n);
     int bm, bn;
@@ -653,7 +653,7 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
     g.tiles_total = t;
     HL_PROF(label, s);
     const int grid = t;
-    unsigned long long* stamp = hl_stamp_slot(g.n == 1 ? HL_ST_ADAM_WY : HL_ST_ADAM_REST);
+    unsigned long long* stamp = hl_stamp_slot((g.n == 1 || g.n == 4) ? HL_ST_ADAM_WY : HL_ST_ADAM_REST);
 #define HL_GA(BMv, BNv, MINWv) k_gemm_adam_dma<BMv, BNv, 2, MINWv><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp, hl_adam_stagger(), tick_shards)
     if (g.K % 64 == 0 && hl_use_dma()) {
         if (bm == 64 && bn == 64) HL_GA(64, 64, 4);

@@ -324,7 +324,7 @@ class GPPriorHIP:
         self._groups = _GroupCache()
         self._grad_m = self._grad_H = self._iH = self._tmp = None
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
-        self._prep, self._prep_stream = None, None
+        self._prep, self._prep_stream, self._tail_pending = None, None, False
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
             for t in (self._theta, self.m, self._KH):
                 dp.broadcast_(t)
@@ -500,6 +500,7 @@ class GPPriorHIP:
         else:
             if train_x is None:
                 raise ValueError("kl_and_grads(train_x=None) needs a preceding prepare()")
+            self.join_tail()
             if prep is not None:                                             # prepared for another batch: drop it (ordered, unused)
                 torch.cuda.current_stream(dev).wait_stream(self._prep_stream)
             x = train_x.contiguous()
@@ -599,6 +600,7 @@ class GPPriorHIP:
     def join(self):
         """the caller's stream waits for the two chains kl_and_grads left running; (data parallel) the hyper-parameter /
         inducing-point gradients are then summed over the ranks"""
+        self.join_tail()
         if self._pending:
             main = torch.cuda.current_stream(self.zt_list.device)
             for s_ in self._side:
@@ -660,14 +662,38 @@ class GPPriorHIP:
             b[:, rt] = K1 @ mu_tilde[:, rp]
         return (a + b).squeeze(2).t().contiguous()                                       # :188
 
-    def optimizer_step(self):
+    def optimizer_step(self, defer=False):
         """Adam on [hyper-parameters | inducing points] (HLVAE_main.py:277-278; one fused kernel, device-side step counter), then
         the natural-gradient update of (m, H), training.py:130-137: iH_new = iH + lr (gH + gH^T) in place, ONE batched inversion
         of [iH_new | K0zz of the parameters Adam has just produced] -> [H_new | iK] straight into their homes (the next step
         starts with both factorisations and log-determinants in hand), m_new = H_new (iH m - lr (grad_m - 2 gH m))."""
         if self._iH is None:
             raise RuntimeError("GPPriorHIP.optimizer_step: call kl_and_grads first (it leaves grad_m, grad_H and the update's right-hand side)")
+        if defer and self.dp is None and self._pending:
+            # The state update (125 us of dependent launches: Adam -> iH update -> transform -> K0zz -> the batched inversion ->
+            # m_new) on the prior's own stream, behind its two chains -- the caller's stream does not wait: the next step's
+            # prepare() goes behind it on the same stream, and the next step's encoder / decoder forward runs beside both.
+            # join_tail() (end of a captured chain, check(), state readers) makes the caller's stream wait.
+            dev = self.zt_list.device
+            if self._prep_stream is None:
+                self._prep_stream = torch.cuda.Stream(device=dev)
+            for s_ in self._side:
+                self._prep_stream.wait_stream(s_)
+            self._pending = False
+            with torch.cuda.stream(self._prep_stream):
+                self._state_update()
+            self._tail_pending = True
+            return
         self.join()
+        self._state_update()
+
+    def join_tail(self):
+        """the caller's stream waits for a deferred state update (optimizer_step(defer=True))"""
+        if self._tail_pending:
+            torch.cuda.current_stream(self.zt_list.device).wait_stream(self._prep_stream)
+            self._tail_pending = False
+
+    def _state_update(self):
         lib, st, L, M = _lib.load(), self._stream(), self.L, self.M
         _lib.check(lib.hlvae_gp_adam(_lib.ptr(self._theta), _lib.ptr(self._gtheta), _lib.ptr(self._adam_m),
                                      _lib.ptr(self._adam_v), self._theta.numel(), _lib.ptr(self._adam_step),

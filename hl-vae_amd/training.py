@@ -188,6 +188,7 @@ class ELBOTrainer:
         dev, L = model.device, model.z_dim
         self._graphs = {}
         self._wy_dbuf = False        # y_layer shadows double-buffered (only inside an even chain of captured steps)
+        self._gp_defer = False       # GP state update deferred onto the prior's stream (only inside a captured chain, prepare() in use)
         if dp is not None and dp.world > 1:
             # every rank draws its own reparameterisation noise: the in-kernel Philox stream is indexed by the LOCAL row, so
             # the seed carries the rank (the reference's single process draws one randn_like for the whole batch, HLVAE.py:361)
@@ -402,7 +403,10 @@ class ELBOTrainer:
         m._fwd_token += 1
         m._grad_region_clean = True
         if self.kl == "gp":
-            self.gp.optimizer_step()
+            if self._gp_defer and hasattr(self.gp, "join_tail"):
+                self.gp.optimizer_step(defer=True)      # (inside a captured chain: the state update runs beside the next step's forward pass)
+            else:
+                self.gp.optimizer_step()
         if prefetch is not None:                 # join; the prefetched batch's buffers become the front set
             torch.cuda.current_stream(m.device).wait_stream(self._pf_stream)
             m._swap_input_buffers()
@@ -476,14 +480,19 @@ class ELBOTrainer:
         # (below 2048 rows the library starts y_layer's launch behind dU_splitk anyway -- the fused middle must be resident first,
         #  csrc/cabi.hip -- and the second pair changes nothing; large batches use it)
         self._wy_dbuf = len(chain) % 2 == 0
+        self._gp_defer = (self.kl == "gp" and self.dp is None and hasattr(self.gp, "join_tail") and os.environ.get("HL_GP_PREPARE", "1") != "0"
+                          and os.environ.get("HL_GP_DEFER", "1") != "0")
         try:
             with torch.cuda.graph(g, **self._capture_kw()):
                 for (r, pb), nr, gr in zip(chain, nxt, grp):
                     self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None, groups=gr)
                 if self.dp is not None:
                     self.opt.finish_pending()          # nothing may stay in flight across the end of a graph
+                if self._gp_defer:
+                    self.gp.join_tail()
         finally:
             self._wy_dbuf = False
+            self._gp_defer = False
         self._graphs[key] = g
         return g
 

@@ -1,10 +1,11 @@
-"""Build profiles/r2_pmc_traffic.json (one entry per workload, the key bench.py looks up) from two rocprofv3 PMC passes of
+"""Build profiles/r3_pmc_traffic.json (one entry per workload, the key bench.py looks up) from two rocprofv3 PMC passes of
 `bench.py --no-graph` per workload:
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dirF> -o f -- python3 bench.py --no-graph ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dirW> -o w -- python3 bench.py --no-graph ...
 Counters are in KB per dispatch.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE undercounts 16-B-per-lane
 coalesced reads by 2x; WRITE_SIZE is exact for 16-B stores and float atomics.
-usage: python tools/pmc_traffic.py <workload_key>=<fetch csv>,<write csv> [...] > profiles/r2_pmc_traffic.json"""
+usage: python tools/pmc_traffic.py abi=<library ABI version> <workload_key>=<fetch csv>,<write csv> [...] > profiles/r3_pmc_traffic.json
+(bench.py refuses the file when its "abi" differs from the library it runs with)"""
 import collections
 import csv
 import json
@@ -60,6 +61,9 @@ def main():
                          "WRITE_SIZE exact for 16-B stores and float atomics; counters are in KB"}
     for arg in sys.argv[1:]:
         key, files = arg.split("=")
+        if key == "abi":
+            out["abi"] = int(files)
+            continue
         ff, fw = files.split(",")
         f, w = per_kernel(ff, "FETCH_SIZE"), per_kernel(fw, "WRITE_SIZE")
         kern = {}

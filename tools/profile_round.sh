@@ -19,15 +19,15 @@ cd /tmp && export TMPDIR=/tmp
 for c in $cfgs; do
   fl=${F[$c]}
   echo "== $c: bench ($fl)"
-  timeout -k 10 400 python3 $R/bench.py $fl --tag ${tag}_$c > $R/gpurun_out/${tag}_${c}_bench.json 2> $R/gpurun_out/${tag}_${c}_bench.log || { echo "bench $c failed"; tail -5 $R/gpurun_out/${tag}_${c}_bench.log; exit 1; }
+  timeout -k 10 600 python3 $R/bench.py $fl --tag ${tag}_$c > $R/gpurun_out/${tag}_${c}_bench.json 2> $R/gpurun_out/${tag}_${c}_bench.log || { echo "bench $c failed"; tail -5 $R/gpurun_out/${tag}_${c}_bench.log; exit 1; }
   tail -c 400 $R/gpurun_out/${tag}_${c}_bench.json; echo
   echo "== $c: rocprofv3 --kernel-trace --stats"
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_${c}_stats -o s -- python3 $R/bench.py $fl --no-cpu-baseline > $R/gpurun_out/${tag}_${c}_stats.log 2>&1 || { echo "stats $c failed"; tail -5 $R/gpurun_out/${tag}_${c}_stats.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_${c}_stats -o s -- python3 $R/bench.py $fl --no-cpu-baseline --no-also > $R/gpurun_out/${tag}_${c}_stats.log 2>&1 || { echo "stats $c failed"; tail -5 $R/gpurun_out/${tag}_${c}_stats.log; exit 1; }
   cp $(find $R/gpurun_out/${tag}_${c}_stats -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${tag}_${c}_kernel_stats.csv
   if [ "$c" != "sharded" ]; then
     for g in FETCH_SIZE WRITE_SIZE; do
       echo "== $c: --pmc $g"
-      timeout -k 10 400 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_${c}_$g -o p -- python3 $R/bench.py $fl --no-graph --no-cpu-baseline --steps 20 --warmup 5 > $R/gpurun_out/${tag}_${c}_$g.log 2>&1 || { echo "pmc $g $c failed"; tail -5 $R/gpurun_out/${tag}_${c}_$g.log; exit 1; }
+      timeout -k 10 400 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_${c}_$g -o p -- python3 $R/bench.py $fl --no-graph --no-cpu-baseline --no-also --no-in-step --steps 20 --warmup 5 > $R/gpurun_out/${tag}_${c}_$g.log 2>&1 || { echo "pmc $g $c failed"; tail -5 $R/gpurun_out/${tag}_${c}_$g.log; exit 1; }
       cp $(find $R/gpurun_out/${tag}_${c}_$g -name "*counter_collection.csv" | head -1) $R/gpurun_out/${tag}_${c}_$g.csv
     done
   fi
