@@ -31,8 +31,9 @@ static const int NV = 5;
 extern int g_hl_gemm_dma;
 extern int g_hl_adam_tile;
 extern int g_hl_adam_stagger;
-static const char* VN[5] = {"old 64x64", "dma 64x64", "dma 64x64 stagger", "dma 32x64 stagger", "dma 64x32 stagger"};
-static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_tile = v >= 3 ? v - 2 : 0; g_hl_adam_stagger = v >= 2; }
+extern int g_hl_adam_persist;
+static const char* VN[5] = {"old 64x64", "dma 64x64", "dma 64x64 stagger", "persistent", "dma 32x64 stagger"};
+static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_tile = v == 4 ? 1 : 0; g_hl_adam_stagger = v >= 2; g_hl_adam_persist = v == 3; }
 #endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -126,7 +127,8 @@ int main(int argc, char** argv) {
             for (int cfg = 0; cfg < NCFG; ++cfg) {
                 const bool two_level = cfg >= 8;
                 const bool use_map = cfg & 1, use_tick = two_level || (cfg & 2), rotate = two_level ? !(cfg & 2) : !(cfg & 4);
-                for (int v = 0; v < (NV > 1 ? 3 : 1); ++v) {
+                for (int v = 0; v < (NV > 1 ? 4 : 1); ++v) {
+                    if (v == 1) continue;
                     std::vector<float> tt;
                     for (int r = 0; r < reps; ++r) {
                         set = rotate ? (set + 1) % NSETS : 3;
