@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HLVAE_LIB_PATH", os.path.join(_HERE, "libhlvae_hip.so"))      # (override: diagnostic builds)
-ABI_VERSION = 31
+ABI_VERSION = 32
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -135,6 +135,7 @@ _SIGS = {
                                  C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "hlvae_gp_adam": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
     "hlvae_reset_pending": (C.c_int, [_vp]),
+    "hlvae_flush": (C.c_int, [_vp, _vp]),
     "hlvae_stamp_slots": (C.c_int, []),
     "hlvae_stamp_words": (C.c_int, []),
     "hlvae_stamp_buffer": (None, [_vp]),

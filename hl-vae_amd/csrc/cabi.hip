@@ -525,6 +525,15 @@ static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is
     return 0;
 }
 
+int hlvae_flush(const hlvae_plan* p, hlvae_stream s) {
+    HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
+    // queue what hlvae_decoder_fwd(want_grad = 2) / hlvae_step_metrics / hlvae_feed_prefetch deferred NOW, on the library's side
+    // stream (behind the event they recorded); the next hlvae_backward* / hlvae_join joins it.  For callers that put long work of
+    // their own between the forward and the backward pass (the GP prior: ~400 us): the side work then runs beside it instead of
+    // behind it (round-3 timeline of configs[4]: the next batch's input stage and the metrics sat at the very end of the step).
+    return hl_flush_deferred(p, g_prof_on ? (hipStream_t)s : p->side[1], false);
+}
+
 int hlvae_join(const hlvae_plan* p, hlvae_stream s) {
     HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
     if (int rc = hl_flush_deferred(p, g_prof_on ? (hipStream_t)s : p->side[1], false)) return rc;

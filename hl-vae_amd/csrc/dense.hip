@@ -405,7 +405,7 @@ __global__ __launch_bounds__(HL_PERSIST_THREADS, 2) void k_gemm_adam_persist(Ada
                                                                           long flat_n4, unsigned long long* stamp,
                                                                           unsigned long long* tick_shards) {
     HL_STAMP_T0(stamp);
-    using G = GemmDMA<64, 64, 2, 2, 2, 68>;
+    using G = GemmDMA<64, 64, 2, 2, 4, 68>;
     constexpr int CLD = 68;
     __shared__ __attribute__((aligned(1024))) char smem[G::AB_BYTES + 64 * CLD * 4];
     float* Cs = reinterpret_cast<float*>(smem + G::AB_BYTES);
@@ -499,26 +499,15 @@ __global__ __launch_bounds__(HL_PERSIST_THREADS, 2) void k_gemm_adam_persist(Ada
             }
         }
     };
-    // G: product of tile t into Cs; both groups run the barriers
+    // G: product of tile t into Cs (four operand buffers: three k-tiles in flight behind counted waits -- with one workgroup per CU
+    // nothing else hides the DMA latency); the S waves run the same barrier sequence (nk k-step barriers + the one that ends run())
     auto product = [&](int t) {
-        typename G::Acc acc;
-        typename G::Src src;
         if (is_g) {
             const PersistTile pt = persist_decode(g, t);
             const AdamGemmProb& q = g.p[pt.pi];
+            typename G::Acc acc;
             G::zero(acc);
-            G::src_init(src, q.A, q.lda, q.B, q.ldb, pt.m0, pt.n0, q.M, q.N, 0, wave, lane);
-            G::issue(src, 0, smem, wave);
-        }
-        for (int kt = 0; kt < nk; ++kt) {
-            if (is_g) hl_wait_vm<0>();                               // (G waves have nothing else in flight: two buffers, one tile ahead)
-            __builtin_amdgcn_s_barrier();
-            if (is_g) {
-                if (kt + 1 < nk) G::issue(src, (kt + 1) * 64, smem + ((kt + 1) & 1) * G::STAGE, wave);
-                G::compute(smem + (kt & 1) * G::STAGE, acc, lane, wave >> 1, wave & 1);
-            }
-        }
-        if (is_g) {
+            G::run(q.A, q.lda, q.B, q.ldb, pt.m0, pt.n0, q.M, q.N, 0, g.K, smem, acc);
             const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
             for (int i = 0; i < G::FM; ++i)
@@ -527,6 +516,8 @@ __global__ __launch_bounds__(HL_PERSIST_THREADS, 2) void k_gemm_adam_persist(Ada
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         Cs[(wm * G::TM + i * 16 + (lane >> 4) * 4 + r) * CLD + wn * G::TN + j * 16 + (lane & 15)] = acc[i][j][r];
+        } else {
+            for (int kt = 0; kt <= nk; ++kt) __builtin_amdgcn_s_barrier();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                // gradient tile complete

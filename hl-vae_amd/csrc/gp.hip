@@ -22,6 +22,7 @@
 #define GP_TMAX 32
 #define GP_MMAX 128
 #define GP_MAX_RBF 2                                        // RBF factors per term (validated by the launchers)
+#define GP_XS 9                                             // padded covariate row in LDS
 
 // ------------------------------------------------------------------------------------------------------------
 // covariance terms.  Hyper-parameters of one latent dimension are hoisted into registers once per thread.
@@ -134,22 +135,35 @@ __global__ void k_gp_transform(const double* __restrict__ raw, int n, double* __
     hyp[(size_t)2 * n + i] = 1.0 / (p * p);
 }
 
+// One workgroup = GP_KM_ROWS rows of x1 against ALL rows of x2 (n2 <= 128) for one latent: both covariate blocks are staged
+// in LDS once (round 2 read every covariate of every element from global memory behind an integer division: 43 us alone for the
+// 31 MB of K0xz at configs[4]); thread (column j = tid & 127, row phase tid >> 7) keeps x2[j] in registers and walks its rows, so
+// a wave's stores are 64 consecutive doubles of one output row.
+#define GP_KM_ROWS 32
 __global__ __launch_bounds__(256) void k_gp_kernel_matrix(hlvae_gp_kernel k, const double* __restrict__ hyp, int n_slots, int L,
                                                           int Q, const double* __restrict__ x1, int n1, int per_latent1,
                                                           const double* __restrict__ x2, int n2, int per_latent2,
                                                           double jitter, double* __restrict__ out) {
-    // grid (chunks of n1 * n2, L)
-    const int l = blockIdx.y;
+    __shared__ double xs[GP_KM_ROWS * GP_XS], zs[GP_MMAX * GP_XS];
+    const int l = blockIdx.y, row0 = blockIdx.x * GP_KM_ROWS, tid = threadIdx.x;
+    const int nrow = min(GP_KM_ROWS, n1 - row0);
+    const double* x1l = x1 + (size_t)(per_latent1 ? l : 0) * n1 * Q;
+    const double* x2l = x2 + (size_t)(per_latent2 ? l : 0) * n2 * Q;
+    for (int e = tid; e < nrow * Q; e += 256) xs[(e / Q) * GP_XS + e % Q] = x1l[(size_t)row0 * Q + e];
+    for (int e = tid; e < n2 * Q; e += 256) zs[(e / Q) * GP_XS + e % Q] = x2l[e];
     GpHyp h;
     gp_hoist(k, hyp, n_slots, L, l, h);
-    const int total = n1 * n2;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int i = e / n2, j = e - i * n2;
-        const double* xa = x1 + ((size_t)(per_latent1 ? l : 0) * n1 + i) * Q;
-        const double* xb = x2 + ((size_t)(per_latent2 ? l : 0) * n2 + j) * Q;
-        double v = gp_value(k, h, xa, xb);
-        if (i == j) v += jitter;
-        out[(size_t)l * total + e] = v;
+    __syncthreads();
+    const int j = tid & 127, ph = tid >> 7;
+    if (j >= n2) return;
+    double xb[GP_XS];
+#pragma unroll
+    for (int q = 0; q < GP_XS - 1; ++q) xb[q] = q < Q ? zs[j * GP_XS + q] : 0.0;
+    double* o = out + ((size_t)l * n1 + row0) * n2 + j;
+    for (int i = ph; i < nrow; i += 2) {
+        double v = gp_value(k, h, xs + i * GP_XS, xb);
+        if (row0 + i == j) v += jitter;
+        o[(size_t)i * n2] = v;
     }
 }
 
@@ -266,7 +280,6 @@ __global__ __launch_bounds__(256) void k_gp_spd_inv(const double* __restrict__ A
 // per (subject, latent) block.  T <= 32 rows per subject (padded), M <= 128 inducing points, 256 threads as a
 // 16 x 16 grid: lane (ti, tj) owns the 2 x 2 elements (ti + 16 ii, tj + 16 jj) of the T x T blocks.
 // ------------------------------------------------------------------------------------------------------------
-#define GP_XS 9                                             // padded covariate row in LDS
 #define GP_TS (GP_TMAX + 1)
 
 __global__ __launch_bounds__(256) void k_gp_subject_fwd(
@@ -1098,11 +1111,10 @@ int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* hyp, int n_sl
                            hlvae_stream s) {
     if (int rc = gp_check_kernel(k, n_slots, Q)) return rc;
     HL_REQUIRE(hyp && x1 && x2 && out && L > 0 && n1 > 0 && n2 > 0, HLVAE_EINVAL, "gp_kernel_matrix: bad arguments");
-    int chunks = (n1 * n2 + 255) / 256;
-    if (chunks > 64) chunks = 64;
+    HL_REQUIRE(n2 <= GP_MMAX && Q <= 8, HLVAE_ESHAPE, "gp_kernel_matrix: n2=%d (max %d columns), Q=%d (max 8)", n2, GP_MMAX, Q);
     HL_PROF("gp_kernel_matrix", (hipStream_t)s);
-    k_gp_kernel_matrix<<<dim3(chunks, L), 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2,
-                                                                  per_latent2, jitter, out);
+    k_gp_kernel_matrix<<<dim3((n1 + GP_KM_ROWS - 1) / GP_KM_ROWS, L), 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1,
+                                                                                              x2, n2, per_latent2, jitter, out);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -331,6 +331,10 @@ class ELBOTrainer:
             self._pf_ref = feed_next
         g_mu = g_lv = None
         kl_w = 1.0 if self.kl == "normal" else 0.0
+        if self.kl == "gp" and not multi and os.environ.get("HL_GP_FLUSH", "1") != "0":
+            # the deferred side work (ELBO scalars, metrics, next batch's input stage) goes onto the library's side stream NOW: the
+            # prior's ~400 us of launches come between here and the backward pass that would otherwise queue it
+            _lib.check(lib.hlvae_flush(m._plan_handle, s), "flush")
         if self.kl == "gp":
             # the GP prior's own chains (bound, natural gradient, hyper-parameter gradients) keep running on its streams beside
             # the VAE's backward pass; gp.optimizer_step() below joins them
@@ -481,7 +485,7 @@ class ELBOTrainer:
         #  csrc/cabi.hip -- and the second pair changes nothing; large batches use it)
         self._wy_dbuf = len(chain) % 2 == 0
         self._gp_defer = (self.kl == "gp" and self.dp is None and hasattr(self.gp, "join_tail") and os.environ.get("HL_GP_PREPARE", "1") != "0"
-                          and os.environ.get("HL_GP_DEFER", "1") != "0")
+                          and os.environ.get("HL_GP_DEFER", "0") != "0")      # (measured: 0.834 vs 0.796 ms -- off by default)
         try:
             with torch.cuda.graph(g, **self._capture_kw()):
                 for (r, pb), nr, gr in zip(chain, nxt, grp):
