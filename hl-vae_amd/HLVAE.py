@@ -465,11 +465,6 @@ class HLVAE(nn.Module):
             return (ksteps + per - 1) // per
         S_e = pick(ksteps_e, (Bp // 64) * (d.hep // 64))
         S_d = pick(ksteps_d, (Bp // 64) * (d.hdp // 64))
-        if os.environ.get("HL_SPLITK"):                  # experiment switch: slices of both split-K products
-            S_e = max(1, min(ksteps_e, int(os.environ["HL_SPLITK"])))
-            S_d = max(1, min(ksteps_d, int(os.environ["HL_SPLITK"])))
-            S_e = (ksteps_e + (ksteps_e + S_e - 1) // S_e - 1) // ((ksteps_e + S_e - 1) // S_e)
-            S_d = (ksteps_d + (ksteps_d + S_d - 1) // S_d - 1) // ((ksteps_d + S_d - 1) // S_d)
         NT = (d.D + 15) // 16
         t = dict(
             G=z(self._arena_size + GRAD_SLACK, dt=f32),      # tail slack: the padded extent of the last reduce-scatter slice

@@ -525,15 +525,6 @@ static int hl_flush_deferred(const hlvae_plan* p, hipStream_t side, bool side_is
     return 0;
 }
 
-int hlvae_flush(const hlvae_plan* p, hlvae_stream s) {
-    HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
-    // queue what hlvae_decoder_fwd(want_grad = 2) / hlvae_step_metrics / hlvae_feed_prefetch deferred NOW, on the library's side
-    // stream (behind the event they recorded); the next hlvae_backward* / hlvae_join joins it.  For callers that put long work of
-    // their own between the forward and the backward pass (the GP prior: ~400 us): the side work then runs beside it instead of
-    // behind it (round-3 timeline of configs[4]: the next batch's input stage and the metrics sat at the very end of the step).
-    return hl_flush_deferred(p, g_prof_on ? (hipStream_t)s : p->side[1], false);
-}
-
 int hlvae_join(const hlvae_plan* p, hlvae_stream s) {
     HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
     if (int rc = hl_flush_deferred(p, g_prof_on ? (hipStream_t)s : p->side[1], false)) return rc;
@@ -699,56 +690,6 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         const long bias_lo = d.o_bd, bias_n = d.atomic_region - d.o_bd;
         HL_REQUIRE(d.o_bd % 4 == 0 && bias_n % 4 == 0 && d.o_bmu > d.o_bd && d.o_blv > d.o_bd && d.o_b1 > d.o_bd && d.o_by < d.o_bd,
                    HLVAE_EINVAL, "backward_adam: the arena must end its small region with [bd | bmu | blv | b1]");
-        static const int one_side_mode = getenv("HL_ONE_SIDE") != nullptr ? atoi(getenv("HL_ONE_SIDE")) : 0;
-        const bool one_side = one_side_mode != 0;
-        if (one_side_mode == 2 && Bp < 2048) {
-            // as below, with all four products in ONE launch (y_layer's first: its misaligned rows want the XCD-contiguous tile order):
-            // 1480 tiles on 1024 slots -- the second round's workgroups start while the first round's are still writing
-            AdamGemmGroup g_all{};
-            g_all.n = 4;
-            g_all.K = Bp;
-            g_all.p[0] = g_wy.p[0];
-            g_all.p[1] = g_rest.p[0];
-            g_all.p[2] = g_rest.p[1];
-            g_all.p[3] = g_rest.p[2];
-            const unsigned tk = hl_ticket_units(hl_gemm_adam_grid(g_all)) + hl_ticket_units(hl_adam_grid(p, ws, 0u, 1));
-            if ((rc = hl_launch_gemm_adam(g_all, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
-                                          tk, "dWy_adam", st, ws->G, bias_lo, bias_n, p->tick_dev))) return rc;
-            HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));
-            if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s1))) return rc;
-            if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tk,
-                                   "adam_small", s1, bias_lo, 2))) return rc;
-            if (p->pend_flags & HL_PEND_DEFERRED) {
-                if ((rc = hl_flush_deferred(p, s1, true, HL_PEND_DEFERRED, false, true))) return rc;
-            } else {
-                HL_CHECK(hipEventRecord(p->ev[5], s1));
-                p->pend_flags |= HL_PEND_RUNNING;
-            }
-            return hlvae_join(p, s);
-        }
-        if (one_side && Bp < 2048) {
-            // Variant (round 3, A/B): BOTH streaming launches on the caller's queue, back to back, and ONE side queue for everything
-            // small (gradient fold, small-region Adam, the next batch's input stage, ELBO scalars + metrics).  Measured before: the two
-            // HBM-bound launches side by side take as long as one after the other (45 + 40 us together, 29 + 25 alone), so the second
-            // hardware queue bought nothing but a fork, a join and a cross-queue parent for the step's end.
-            if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
-                                          tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n, p->tick_dev))) return rc;
-            // (y_layer's shadows: in place or into the caller's second pair, as above -- dU_splitk, this step's last reader of the
-            //  first pair, ran before on this queue either way)
-            if ((rc = hl_launch_gemm_adam(g_wy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
-                                          tickets, "dWy_adam", st, nullptr, 0, 0, p->tick_dev + HL_TICK_WORDS))) return rc;
-            HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));
-            if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, s1))) return rc;
-            if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0u, 1, tickets,
-                                   "adam_small", s1, bias_lo, 2))) return rc;
-            if (p->pend_flags & HL_PEND_DEFERRED) {
-                if ((rc = hl_flush_deferred(p, s1, true, HL_PEND_DEFERRED, false, true))) return rc;
-            } else {
-                HL_CHECK(hipEventRecord(p->ev[5], s1));
-                p->pend_flags |= HL_PEND_RUNNING;
-            }
-            return hlvae_join(p, s);
-        }
         if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
                                       tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n, p->tick_dev))) return rc;
         HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));

@@ -75,7 +75,7 @@ struct AdamGemmProb {
     int lda, ldb, M, N, band, band_rows, ldd, ldT, tiles_m, tiles_n, tile0;
 };
 struct AdamGemmGroup {
-    AdamGemmProb p[4];
+    AdamGemmProb p[3];
     int n, K, tiles_total;
 };
 

@@ -8,11 +8,6 @@
 // which GEMM main loop the K % 64 == 0 launches use: 1 = LDS-DMA staged (gemm_dma.h, round 3), 0 = register staged (gemm_nt.h).
 // HL_GEMM_CORE=nt in the environment selects the old core (A/B runs on one box).
 int g_hl_gemm_dma = -1;
-int g_hl_slab_nt = -1;
-static int hl_slab_nt() {       // HL_SLAB_NT=1: split-K slabs leave with non-temporal stores (A/B)
-    if (g_hl_slab_nt < 0) { const char* e = getenv("HL_SLAB_NT"); g_hl_slab_nt = (e != nullptr && e[0] == '1') ? 1 : 0; }
-    return g_hl_slab_nt;
-}
 static bool hl_use_dma() {
     if (g_hl_gemm_dma < 0) {
         const char* e = getenv("HL_GEMM_CORE");
@@ -126,7 +121,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void k_gemm_adam(AdamGemmGroup g, fl
     __shared__ __attribute__((aligned(16))) char smem[G::SMEM_BYTES];
     int pi = 0;
 #pragma unroll
-    for (int k = 1; k < 4; ++k)
+    for (int k = 1; k < 3; ++k)
         if (k < g.n && (int)blockIdx.x >= g.p[k].tile0) pi = k;
     const AdamGemmProb& q = g.p[pi];
     // problem 0 starts at workgroup 0: its XCD-contiguous order is exact (consecutive ids share the row panel of A)
@@ -249,7 +244,7 @@ __global__ __launch_bounds__(HL_THREADS, MINW) void k_gemm_adam_dma(AdamGemmGrou
     __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
     int pi = 0;
 #pragma unroll
-    for (int k = 1; k < 4; ++k)
+    for (int k = 1; k < 3; ++k)
         if (k < g.n && (int)blockIdx.x >= g.p[k].tile0) pi = k;
     const AdamGemmProb& q = g.p[pi];
     const int lid = pi == 0 ? xcd_remap(blockIdx.x, q.tiles_m * q.tiles_n) : (int)blockIdx.x - q.tile0;
@@ -369,212 +364,6 @@ __global__ __launch_bounds__(HL_THREADS, MINW) void k_gemm_adam_dma(AdamGemmGrou
     HL_STAMP_END(stamp);
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// Persistent, wave-specialised form of the fused gradient + optimiser kernel (round 3).
-// k_gemm_adam_dma is ONE resident round: every workgroup reads its state, multiplies, writes -- the whole chip in phase, HBM idle
-// while the products run out of L2 and the reads idle while the writes drain (97.9 MB in 25.5 us alone = 3.8 TB/s, state warm).
-// vmcnt retires in order, so a wave that stages operand tiles by LDS-DMA cannot keep the NEXT tile's state loads in flight across
-// its tile waits.  Here the two jobs belong to different waves of a 512-thread workgroup that walks several tiles:
-//   waves 0-3 (G): the product of tile t (LDS-DMA core, 64 x 64, two operand buffers) -> fp32 tile in LDS;
-//   waves 4-7 (S): request master / m / v of tile t + 1 (12 float4 per lane: 48 KB per workgroup in flight) BEFORE they take the
-//                  gradient tile t from LDS, apply Adam, store master / m / v and both bf16 shadows.
-// Both groups run the same s_barrier sequence (nk + 2 per tile); the S waves reach the k-step barriers at once, so they never hold
-// the product back.  One workgroup per CU (two register sets of optimiser state: 202 VGPRs; 50 KB LDS): 256 persistent workgroups
-// share the tiles of all problems, ~96 KB of state requests in flight per CU.
-// ------------------------------------------------------------------------------------------------------------------------------
-#define HL_PERSIST_THREADS 512
-struct PersistTile {              // decoded tile: problem, origin, validity
-    int pi, m0, n0;
-};
-__device__ __forceinline__ PersistTile persist_decode(const AdamGemmGroup& g, int t) {
-    int pi = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-        if (k < g.n && t >= g.p[k].tile0) pi = k;
-    const AdamGemmProb& q = g.p[pi];
-    // (workgroup w walks tiles w, w + G, ...: with G a multiple of 8 every tile of a workgroup has the residue of its XCD, so the
-    //  XCD-contiguous order of problem 0 keeps its meaning)
-    const int lid = pi == 0 ? xcd_remap(t, q.tiles_m * q.tiles_n) : t - q.tile0;
-    return PersistTile{pi, (lid / q.tiles_n) * 64, (lid % q.tiles_n) * 64};
-}
-
-__global__ __launch_bounds__(HL_PERSIST_THREADS, 2) void k_gemm_adam_persist(AdamGemmGroup g, float* __restrict__ P, float* __restrict__ M1,
-                                                                          float* __restrict__ M2, int64_t* __restrict__ step_count,
-                                                                          float lr, float b1, float b2, float eps, float gscale,
-                                                                          unsigned ticket_total, float* __restrict__ Gflat, long flat_lo4,
-                                                                          long flat_n4, unsigned long long* stamp,
-                                                                          unsigned long long* tick_shards) {
-    HL_STAMP_T0(stamp);
-    using G = GemmDMA<64, 64, 2, 2, 4, 68>;
-    constexpr int CLD = 68;
-    __shared__ __attribute__((aligned(1024))) char smem[G::AB_BYTES + 64 * CLD * 4];
-    float* Cs = reinterpret_cast<float*>(smem + G::AB_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_g = wave < 4;
-    const int total = g.tiles_total, nk = g.K / 64;
-    const int stid = tid & 255;                                      // index inside the S group
-    const int c4 = (stid & 15) * 4, rq = stid >> 4;
-    const AdamScalars a = adam_scalars((float)(step_count[0] + 1), lr, b1, b2, eps, gscale);
-
-    // state of ONE tile in this lane's registers (S waves)
-    struct St {
-        float4 p[4], m[4], v[4];
-        int o[4];
-        unsigned in;                                                 // bit i: row pass i is inside the matrix
-    };
-    auto request = [&](St& st, int t) {                              // address computation + 12 loads (no wait)
-        const PersistTile pt = persist_decode(g, t);
-        const AdamGemmProb& q = g.p[pt.pi];
-        const int M = q.M, N = q.N;
-        int mrow[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gr = pt.m0 + rq + 16 * i;
-            mrow[i] = q.rowmap != nullptr ? q.rowmap[min(gr, M - 1)] : gr;
-        }
-        st.in = 0u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gr = pt.m0 + rq + 16 * i;
-            long base = -1;
-            if (pt.n0 + c4 < N) {
-                if (q.band <= 0) {
-                    if (gr < M) base = q.off + (long)mrow[i] * N;
-                } else if (gr < q.band_rows) {
-                    base = q.off + (long)gr * N;
-                } else if (gr >= q.band && gr < q.band + q.band_rows) {
-                    base = q.off2 + (long)(gr - q.band) * N;
-                }
-            }
-            if (base >= 0) st.in |= 1u << i;
-            st.o[i] = (int)(base >= 0 ? base + pt.n0 + c4 : q.off);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            st.p[i] = *reinterpret_cast<const float4*>(P + st.o[i]);
-            st.m[i] = *reinterpret_cast<const float4*>(M1 + st.o[i]);
-            st.v[i] = *reinterpret_cast<const float4*>(M2 + st.o[i]);
-        }
-    };
-    // S: gradient tile t is in Cs (behind a barrier): Adam, master / m / v / row-major shadow out, new values back into Cs
-    auto apply = [&](St& st, int t) {
-        const PersistTile pt = persist_decode(g, t);
-        const AdamGemmProb& q = g.p[pt.pi];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rq + 16 * i;
-            const bool in = (st.in >> i) & 1u;
-            const float4 gr4 = *reinterpret_cast<const float4*>(Cs + r * CLD + c4);
-            st.p[i].x = adam_one(st.p[i].x, gr4.x, st.m[i].x, st.v[i].x, a);
-            st.p[i].y = adam_one(st.p[i].y, gr4.y, st.m[i].y, st.v[i].y, a);
-            st.p[i].z = adam_one(st.p[i].z, gr4.z, st.m[i].z, st.v[i].z, a);
-            st.p[i].w = adam_one(st.p[i].w, gr4.w, st.m[i].w, st.v[i].w, a);
-            if (in) {
-                *reinterpret_cast<float4*>(P + st.o[i]) = st.p[i];
-                *reinterpret_cast<float4*>(M1 + st.o[i]) = st.m[i];
-                *reinterpret_cast<float4*>(M2 + st.o[i]) = st.v[i];
-                uint2 pk;
-                pk.x = (uint32_t)f2bf(st.p[i].x) | ((uint32_t)f2bf(st.p[i].y) << 16);
-                pk.y = (uint32_t)f2bf(st.p[i].z) | ((uint32_t)f2bf(st.p[i].w) << 16);
-                *reinterpret_cast<uint2*>(q.sh + (size_t)(pt.m0 + r) * q.ldd + pt.n0 + c4) = pk;
-            }
-            *reinterpret_cast<float4*>(Cs + r * CLD + c4) = in ? st.p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    // S: transposed shadow of tile t from the new values in Cs (behind a barrier)
-    auto shadow_t = [&](int t) {
-        const PersistTile pt = persist_decode(g, t);
-        const AdamGemmProb& q = g.p[pt.pi];
-        if (q.shT == nullptr) return;
-        const int r4 = (stid & 15) * 4, cq = stid >> 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = cq + 16 * i;
-            if (pt.m0 + r4 < q.M && pt.n0 + c < q.N) {
-                uint2 pk;
-                pk.x = (uint32_t)f2bf(Cs[(r4 + 0) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 1) * CLD + c]) << 16);
-                pk.y = (uint32_t)f2bf(Cs[(r4 + 2) * CLD + c]) | ((uint32_t)f2bf(Cs[(r4 + 3) * CLD + c]) << 16);
-                *reinterpret_cast<uint2*>(q.shT + (size_t)(pt.n0 + c) * q.ldT + pt.m0 + r4) = pk;
-            }
-        }
-    };
-    // G: product of tile t into Cs (four operand buffers: three k-tiles in flight behind counted waits -- with one workgroup per CU
-    // nothing else hides the DMA latency); the S waves run the same barrier sequence (nk k-step barriers + the one that ends run())
-    auto product = [&](int t) {
-        if (is_g) {
-            const PersistTile pt = persist_decode(g, t);
-            const AdamGemmProb& q = g.p[pt.pi];
-            typename G::Acc acc;
-            G::zero(acc);
-            G::run(q.A, q.lda, q.B, q.ldb, pt.m0, pt.n0, q.M, q.N, 0, g.K, smem, acc);
-            const int wm = wave >> 1, wn = wave & 1;
-#pragma unroll
-            for (int i = 0; i < G::FM; ++i)
-#pragma unroll
-                for (int j = 0; j < G::FN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        Cs[(wm * G::TM + i * 16 + (lane >> 4) * 4 + r) * CLD + wn * G::TN + j * 16 + (lane & 15)] = acc[i][j][r];
-        } else {
-            for (int kt = 0; kt <= nk; ++kt) __builtin_amdgcn_s_barrier();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                // gradient tile complete
-    };
-
-    // tiles of this workgroup: t0, t0 + G, ...; the S waves' two register sets alternate (written out: no dynamic indexing)
-    const int G_ = gridDim.x;
-    int t = blockIdx.x;
-    St sa, sb;
-    if (!is_g && t < total) request(sa, t);
-    while (t < total) {
-        // ---- tile t with set A; tile t + G requested into set B first
-        product(t);
-        if (!is_g) {
-            if (t + G_ < total) request(sb, t + G_);
-            apply(sa, t);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                // new values in Cs
-        if (!is_g) shadow_t(t);
-        t += G_;
-        if (t >= total) break;
-        // ---- tile t with set B; tile t + G requested into set A first
-        product(t);                                                  // (its last barrier orders the reads of shadow_t before the next Cs writes:
-        if (!is_g) {                                                 //  the S waves arrive at the k-step barriers only after shadow_t)
-            if (t + G_ < total) request(sa, t + G_);
-            apply(sb, t);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (!is_g) shadow_t(t);
-        t += G_;
-    }
-    if (flat_n4 > 0 && blockIdx.x == 0 && !is_g) {                   // the four bias vectors (see k_gemm_adam)
-        float4* P4 = reinterpret_cast<float4*>(P) + flat_lo4;
-        float4* G4 = reinterpret_cast<float4*>(Gflat) + flat_lo4;
-        float4* M14 = reinterpret_cast<float4*>(M1) + flat_lo4;
-        float4* M24 = reinterpret_cast<float4*>(M2) + flat_lo4;
-        for (long i = stid; i < flat_n4; i += 256) {
-            float4 pp = P4[i], gr = G4[i], mm = M14[i], vv = M24[i];
-            pp.x = adam_one(pp.x, gr.x, mm.x, vv.x, a);
-            pp.y = adam_one(pp.y, gr.y, mm.y, vv.y, a);
-            pp.z = adam_one(pp.z, gr.z, mm.z, vv.z, a);
-            pp.w = adam_one(pp.w, gr.w, mm.w, vv.w, a);
-            P4[i] = pp;
-            M14[i] = mm;
-            M24[i] = vv;
-            G4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    if (ticket_total != 0) {
-        __syncthreads();
-        if (threadIdx.x == 0) hl_take_ticket(step_count, tick_shards, ticket_total);
-    }
-    HL_STAMP_END(stamp);
-}
-
 // up to three independent products of the same depth K in ONE launch (the weight gradients that become computable at
 // the same moment of the backward pass: dW1, dWd, d[Wmu; Wlv]).  The two small ones are 8 workgroups each: as launches
 // of their own they cost a dependent ~10 us kernel (or a cross-queue graph edge) apiece, here they ride along.
@@ -667,8 +456,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk(const bf16_t* __rest
 template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                                 int ldb, float* __restrict__ slab, int ldn, int M, int N, int K,
-                                                                int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp,
-                                                                int nt_store) {
+                                                                int ksteps_per_split, int tiles_m, int tiles_n, int S, unsigned long long* stamp) {
     HL_STAMP_T0(stamp);
     using G = GemmDMA<BM, BN, WM, WN, NBUF>;
     __shared__ __attribute__((aligned(1024))) char smem[G::SMEM_BYTES];
@@ -691,14 +479,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_gemm_splitk_dma(const bf16_t* __
         const int r = idx / C4, c = (idx % C4) * 4;
         if (m0 + r < M && n0 + c < N) {
             const float4 v = make_float4(Cs[r * G::CLD + c], Cs[r * G::CLD + c + 1], Cs[r * G::CLD + c + 2], Cs[r * G::CLD + c + 3]);
-            if (n0 + c + 4 <= N) {
-                // nt: streaming (write-through) store -- the slab is read next by ANOTHER kernel, on whatever XCD its workgroups land:
-                // lines left dirty in this XCD's L2 only have to be written back at the kernel boundary
-                typedef __attribute__((ext_vector_type(4))) float f4v;
-                f4v vv = {v.x, v.y, v.z, v.w};
-                if (nt_store) __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(out + (size_t)(m0 + r) * ldn + n0 + c));
-                else *reinterpret_cast<float4*>(out + (size_t)(m0 + r) * ldn + n0 + c) = v;
-            }
+            if (n0 + c + 4 <= N) *reinterpret_cast<float4*>(out + (size_t)(m0 + r) * ldn + n0 + c) = v;
             else {
                 const float e[4] = {v.x, v.y, v.z, v.w};
                 for (int t = 0; t < 4 && n0 + c + t < N; ++t) out[(size_t)(m0 + r) * ldn + n0 + c + t] = e[t];
@@ -801,36 +582,12 @@ bool hl_gemm_adam_ok(int M, int N, int K, bool may_be_small) {
            (may_be_small || hl_wgrad_ksplit((long)((M + 63) / 64) * ((N + 63) / 64), K) == 1);
 }
 
-// tile shape of the fused gradient + optimiser launches on the LDS-DMA core: 0 = 64 x 64, 1 = 32 x 64, 2 = 64 x 32, 3 = 32 x 32
-// (HL_ADAM_TILE in the environment; the micro-benchmark sets the global)
-int g_hl_adam_tile = -1;
-static int hl_adam_tile() {
-    if (g_hl_adam_tile < 0) {
-        const char* e = getenv("HL_ADAM_TILE");
-        g_hl_adam_tile = (e != nullptr && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;
-    }
-    return g_hl_adam_tile;
-}
 int g_hl_adam_stagger = -1;
 static int hl_adam_stagger() {       // HL_ADAM_STAGGER=0 switches the phase stagger off (A/B)
     if (g_hl_adam_stagger < 0) { const char* e = getenv("HL_ADAM_STAGGER"); g_hl_adam_stagger = (e != nullptr && e[0] == '0') ? 0 : 1; }
     return g_hl_adam_stagger;
 }
-static void hl_adam_tile_shape(int K, int& bm, int& bn) {
-    bm = bn = 64;
-    if (K % 64 == 0 && hl_use_dma()) {
-        const int t = hl_adam_tile();
-        bm = (t & 1) ? 32 : 64;
-        bn = (t & 2) ? 32 : 64;
-    }
-}
-
-int g_hl_adam_persist = -1;
-static int hl_adam_persist() {       // HL_ADAM_PERSIST=1: the persistent wave-specialised kernel (k_gemm_adam_persist)
-    if (g_hl_adam_persist < 0) { const char* e = getenv("HL_ADAM_PERSIST"); g_hl_adam_persist = (e != nullptr && e[0] == '1') ? 1 : 0; }
-    return g_hl_adam_persist;
-}
-static int hl_persist_grid(int tiles) { return tiles < 256 ? (tiles + 7) / 8 * 8 : 256; }     // one 512-thread workgroup per CU (202 VGPRs), a multiple of 8
+static void hl_adam_tile_shape(int K, int& bm, int& bn) { bm = bn = 64; (void)K; }      // (32 x 64 / 64 x 32 / 32 x 32 tiles measured: all slower)
 
 // workgroups of the launch (what the completion tickets count)
 int hl_gemm_adam_grid(const AdamGemmGroup& g) {
@@ -838,7 +595,6 @@ int hl_gemm_adam_grid(const AdamGemmGroup& g) {
     hl_adam_tile_shape(g.K, bm, bn);
     int t = 0;
     for (int i = 0; i < g.n; ++i) t += ((g.p[i].M + bm - 1) / bm) * ((g.p[i].N + bn - 1) / bn);
-    if (hl_adam_persist() && g.K % 64 == 0 && bm == 64 && bn == 64 && hl_use_dma()) return hl_persist_grid(t);
     return t;
 }
 
@@ -847,7 +603,7 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
                         unsigned long long* tick_shards) {
     // tick_shards: this launch's shard counters (common.h hl_take_ticket; ticket_total then counts shard units over the step's
     // launches), or nullptr: one-level tickets (ticket_total = workgroups)
-    HL_REQUIRE(g.n >= 1 && g.n <= 4 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm_adam: n=%d K=%d", g.n, g.K);
+    HL_REQUIRE(g.n >= 1 && g.n <= 3 && g.K % 32 == 0, HLVAE_ESHAPE, "gemm_adam: n=%d K=%d", g.n, g.K);
     HL_REQUIRE(flat_lo % 4 == 0 && flat_n % 4 == 0 && flat_n >= 0 && (flat_n == 0 || Gflat != nullptr), HLVAE_ESHAPE,
                "gemm_adam: flat range [%ld, +%ld) must be 4-aligned", flat_lo, flat_n);
     int bm, bn;
@@ -867,21 +623,11 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
     }
     g.tiles_total = t;
     HL_PROF(label, s);
-    int grid = t;
-    unsigned long long* stamp = hl_stamp_slot((g.n == 1 || g.n == 4) ? HL_ST_ADAM_WY : HL_ST_ADAM_REST);
-    if (hl_adam_persist() && g.K % 64 == 0 && bm == 64 && bn == 64 && hl_use_dma()) {
-        grid = hl_persist_grid(t);
-        k_gemm_adam_persist<<<grid, HL_PERSIST_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4,
-                                                                flat_n / 4, stamp, tick_shards);
-        HL_LAUNCH_CHECK();
-        return 0;
-    }
+    const int grid = t;
+    unsigned long long* stamp = hl_stamp_slot(g.n == 1 ? HL_ST_ADAM_WY : HL_ST_ADAM_REST);
 #define HL_GA(BMv, BNv, MINWv) k_gemm_adam_dma<BMv, BNv, 2, MINWv><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp, hl_adam_stagger(), tick_shards)
     if (g.K % 64 == 0 && hl_use_dma()) {
-        if (bm == 64 && bn == 64) HL_GA(64, 64, 4);
-        else if (bm == 32 && bn == 64) HL_GA(32, 64, 6);
-        else if (bm == 64 && bn == 32) HL_GA(64, 32, 6);
-        else HL_GA(32, 32, 6);
+        HL_GA(64, 64, 4);
     } else if (g.K % 64 == 0)
         k_gemm_adam<64><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp, tick_shards);
     else
@@ -934,7 +680,7 @@ int hl_launch_gemm_splitk(const bf16_t* A, int lda, const bf16_t* B, int ldb, fl
     HL_PROF(label, s);
     unsigned long long* stamp = label[0] == 'e' ? hl_stamp_slot(HL_ST_ENC1) : (label[0] == 'd' && label[1] == 'U' && label[2] == '_' ? hl_stamp_slot(HL_ST_DU) : nullptr);
     if (hl_use_dma() && ldn % 4 == 0)
-        k_gemm_splitk_dma<64, 64, 2, 2, 3><<<tm * tn * S, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per, tm, tn, S, stamp, hl_slab_nt());
+        k_gemm_splitk_dma<64, 64, 2, 2, 3><<<tm * tn * S, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per, tm, tn, S, stamp);
     else
         k_gemm_splitk<64, 64, 64, 2, 2><<<tm * tn * S, HL_THREADS, 0, s>>>(A, lda, B, ldb, slab, ldn, M, N, K, per, tm, tn, S, stamp);
     HL_LAUNCH_CHECK();

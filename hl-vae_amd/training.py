@@ -331,10 +331,6 @@ class ELBOTrainer:
             self._pf_ref = feed_next
         g_mu = g_lv = None
         kl_w = 1.0 if self.kl == "normal" else 0.0
-        if self.kl == "gp" and not multi and os.environ.get("HL_GP_FLUSH", "1") != "0":
-            # the deferred side work (ELBO scalars, metrics, next batch's input stage) goes onto the library's side stream NOW: the
-            # prior's ~400 us of launches come between here and the backward pass that would otherwise queue it
-            _lib.check(lib.hlvae_flush(m._plan_handle, s), "flush")
         if self.kl == "gp":
             # the GP prior's own chains (bound, natural gradient, hyper-parameter gradients) keep running on its streams beside
             # the VAE's backward pass; gp.optimizer_step() below joins them

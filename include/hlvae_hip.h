@@ -436,9 +436,6 @@ int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* 
 void hlvae_prof_enable(int on);
 int  hlvae_prof_report(char* buf, int buflen);
 
-/* queue the deferred side work of this plan now (library side stream, behind the events it recorded) without joining it;
- * the next hlvae_backward* / hlvae_join joins.  Use when the caller has long work of its own between forward and backward. */
-int  hlvae_flush(const hlvae_plan* p, hlvae_stream s);
 /* forget the side work that hlvae_step_metrics / hlvae_decoder_fwd(want_grad = 2) / hlvae_feed_prefetch deferred and that no
  * hlvae_backward* / hlvae_join has queued yet (host bookkeeping only; used after a HIP-graph capture that failed mid-step) */
 int  hlvae_reset_pending(const hlvae_plan* p);

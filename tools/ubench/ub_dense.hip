@@ -27,13 +27,11 @@ static const char* VN[5] = {"round-2 tree 64x64", "", "", "", ""};
 static void set_variant(int) {}
 static int g_hl_gemm_dma = 0;
 #else
-static const int NV = 5;
+static const int NV = 3;
 extern int g_hl_gemm_dma;
-extern int g_hl_adam_tile;
 extern int g_hl_adam_stagger;
-extern int g_hl_adam_persist;
-static const char* VN[5] = {"old 64x64", "dma 64x64", "dma 64x64 stagger", "persistent", "dma 32x64 stagger"};
-static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_tile = v == 4 ? 1 : 0; g_hl_adam_stagger = v >= 2; g_hl_adam_persist = v == 3; }
+static const char* VN[5] = {"register-staged core", "LDS-DMA core", "LDS-DMA core, stagger", "", ""};
+static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_stagger = v >= 2; }
 #endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -127,8 +125,7 @@ int main(int argc, char** argv) {
             for (int cfg = 0; cfg < NCFG; ++cfg) {
                 const bool two_level = cfg >= 8;
                 const bool use_map = cfg & 1, use_tick = two_level || (cfg & 2), rotate = two_level ? !(cfg & 2) : !(cfg & 4);
-                for (int v = 0; v < (NV > 1 ? 4 : 1); ++v) {
-                    if (v == 1) continue;
+                for (int v = 0; v < NV; ++v) {
                     std::vector<float> tt;
                     for (int r = 0; r < reps; ++r) {
                         set = rotate ? (set + 1) % NSETS : 3;
