@@ -587,14 +587,9 @@ static int hl_adam_stagger() {       // HL_ADAM_STAGGER=0 switches the phase sta
     if (g_hl_adam_stagger < 0) { const char* e = getenv("HL_ADAM_STAGGER"); g_hl_adam_stagger = (e != nullptr && e[0] == '0') ? 0 : 1; }
     return g_hl_adam_stagger;
 }
-// tile of the fused gradient + optimiser launches: 64 x 64, or 32 rows x 128 columns (HL_ADAM_WIDE=1: 512-byte instead of 256-byte
-// row segments of master / m / v per tile row; 32 x 64, 64 x 32 and 32 x 32 were measured and are slower)
-int g_hl_adam_wide = -1;
-static void hl_adam_tile_shape(int K, int& bm, int& bn) {
-    if (g_hl_adam_wide < 0) { const char* e = getenv("HL_ADAM_WIDE"); g_hl_adam_wide = (e != nullptr && e[0] == '1') ? 1 : 0; }
-    bm = bn = 64;
-    if (g_hl_adam_wide && K % 64 == 0 && hl_use_dma()) { bm = 32; bn = 128; }
-}
+// tile of the fused gradient + optimiser launches: 64 x 64 (32 x 64, 64 x 32, 32 x 32 and -- round 3, with 512-byte row segments
+// of master / m / v -- 32 x 128 were measured: none is faster alone, 32 x 128 is 7 us slower inside the step)
+static void hl_adam_tile_shape(int K, int& bm, int& bn) { (void)K; bm = bn = 64; }
 
 // workgroups of the launch (what the completion tickets count)
 int hl_gemm_adam_grid(const AdamGemmGroup& g) {
@@ -634,7 +629,7 @@ int hl_launch_gemm_adam(AdamGemmGroup g, float* P, float* M1, float* M2, int64_t
     unsigned long long* stamp = hl_stamp_slot(g.n == 1 ? HL_ST_ADAM_WY : HL_ST_ADAM_REST);
 #define HL_GA(BMv, BNv, MINWv) k_gemm_adam_dma<BMv, BNv, 2, MINWv><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp, hl_adam_stagger(), tick_shards)
     if (g.K % 64 == 0 && hl_use_dma()) {
-        if (bm == 32) HL_GA(32, 128, 4); else HL_GA(64, 64, 4);
+        HL_GA(64, 64, 4);
     } else if (g.K % 64 == 0)
         k_gemm_adam<64><<<grid, HL_THREADS, 0, s>>>(g, P, M1, M2, step_count, lr, b1, b2, eps, gscale, ticket_total, Gflat, flat_lo / 4, flat_n / 4, stamp, tick_shards);
     else

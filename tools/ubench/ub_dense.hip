@@ -27,12 +27,11 @@ static const char* VN[5] = {"round-2 tree 64x64", "", "", "", ""};
 static void set_variant(int) {}
 static int g_hl_gemm_dma = 0;
 #else
-static const int NV = 4;
+static const int NV = 3;
 extern int g_hl_gemm_dma;
 extern int g_hl_adam_stagger;
-extern int g_hl_adam_wide;
-static const char* VN[5] = {"register-staged core", "LDS-DMA core", "LDS-DMA core, stagger", "LDS-DMA 32x128 stagger", ""};
-static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_stagger = v >= 2; g_hl_adam_wide = v == 3; }
+static const char* VN[5] = {"register-staged core", "LDS-DMA core", "LDS-DMA core, stagger", "", ""};
+static void set_variant(int v) { g_hl_gemm_dma = v > 0; g_hl_adam_stagger = v >= 2; }
 #endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
