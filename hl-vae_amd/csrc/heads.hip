@@ -458,7 +458,7 @@ __device__ __forceinline__ int acc_dest(const hlvae_var& var, int n) {
 
 // DMA: the U x Wy^T tile runs on the LDS-DMA core (gemm_dma.h, round 3: no staging registers, no ds_write pass, swizzled
 // conflict-free fragment reads, two 20 KB buffers instead of two 23 KB ones); false: the register-staged core of rounds 1-2
-template <int YD, int BM, int KMAX, bool DMA = true>
+template <int YD, int BM, int KMAX, int CORE = 2>
 __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) void k_y_heads(
     const bf16_t* __restrict__ U, int ldu, const bf16_t* __restrict__ Wy, int K, const hlvae_var* __restrict__ vars,
     const float* __restrict__ P, float* __restrict__ hgpart, long o_by, const float* __restrict__ norm, int n_stat,
@@ -473,7 +473,9 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     // ysrc != nullptr: convolutional decoder -- the tile of y_grouped comes from the second ConvTranspose (csrc/conv.hip,
     // bias included) instead of the y_layer GEMM; d Y leaves in row-major layout only and d by is not ours
     constexpr int BN = 16 * YD;
-    using Gm = typename std::conditional<DMA, GemmDMA<BM, BN, 4, 1, 2, BN + 4>, GemmNT<BM, BN, 64, 4, 1, 3, BN + 4>>::type;
+    // CORE 2: B through LDS-DMA (four stages), A fragments in registers; 1: [A; B] through LDS-DMA (two stages); 0: register-staged
+    using Gm = typename std::conditional<CORE == 2, GemmDMAB<BM, BN, (BN > 80 ? 3 : 4), BN + 4>,
+                                         typename std::conditional<CORE == 1, GemmDMA<BM, BN, 4, 1, 2, BN + 4>, GemmNT<BM, BN, 64, 4, 1, 3, BN + 4>>::type>::type;
     constexpr int CLD = Gm::CLD;
     constexpr int RPT = BM / 16;                                  // rows per thread
     constexpr int NHEAD = HeadAcc<YD, KMAX>::N;                   // head-parameter gradient accumulators of a variable
@@ -533,12 +535,7 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
     // latency, now overlapped with the tiles' instead of exposed ahead of the GEMM: 3.4 k of 43 k clocks per wave).  The values
     // stay in registers for the first three k-steps only and are parked then (keeping them through the loop spilled 29 VGPRs).
     float pre[PS];
-    auto park = [&]() {
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            xs[i * HL_THREADS + tid] = xv[i];
-            ms[i * HL_THREADS + tid] = (m0 + HL_ROW(rg, i) < B && d < D) ? mv[i] : (uint8_t)0;
-        }
+    auto load_params = [&]() {
         if (tid < 16 && d < D) {
             const int K1 = var.ncls - 1;
             const bool cont = var.kind == HLVAE_REAL || var.kind == HLVAE_POS;
@@ -565,17 +562,32 @@ __global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) vo
             for (int i = 0; i < PS; ++i) pscr[v * PS + i] = pre[i];
         }
     };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            xs[i * HL_THREADS + tid] = xv[i];
+            ms[i * HL_THREADS + tid] = (m0 + HL_ROW(rg, i) < B && d < D) ? mv[i] : (uint8_t)0;
+        }
+        // CORE 2: the parameter loads were issued ahead of the GEMM (right behind the targets': the arena offsets arrive in the
+        // same cache line as var.pad) and are parked here too -- one straight-line k-step, so the compiler's wait for them is
+        // counted; CORE 0 / 1: issued here, parked one k-step later
+        if constexpr (CORE == 2) park_params(); else load_params();
+    };
+    auto park_late = [&]() {
+        if constexpr (CORE != 2) park_params();
+    };
+    if constexpr (CORE == 2) load_params();
     HL_CLK(1);
     if (!conv) {
         typename Gm::Acc accm;
         Gm::zero(accm);
-        Gm::run(U, ldu, Wy, ldu, m0, n0, Bp, NY, 0, K, smem, accm, park, park_params);
+        Gm::run(U, ldu, Wy, ldu, m0, n0, Bp, NY, 0, K, smem, accm, park, park_late);
         HL_CLK(2);
         Gm::to_lds(accm, smem);
         HL_CLK(3);
     } else {
         park();
-        park_params();
+        park_late();
         for (int idx = threadIdx.x; idx < BM * BN; idx += HL_THREADS) {
             const int r = idx / BN, c = idx % BN;
             Cs[r * CLD + c] = (m0 + r < B && n0 + c < NY) ? ysrc[(size_t)(m0 + r) * ldys + n0 + c] : 0.f;
@@ -1011,7 +1023,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
         const int grid = NT * (Bp / 64);
         long long* clk = hl_heads_clk_buffer(grid);
 #define HL_LAUNCH_HEADS(KMv) HL_LAUNCH_HEADS_Y(5, 64, KMv)
-#define HL_LAUNCH_HEADS_Y(YDv, BMv, KMv) HL_LAUNCH_HEADS_V(YDv, BMv, KMv, true)
+#define HL_LAUNCH_HEADS_Y(YDv, BMv, KMv) HL_LAUNCH_HEADS_V(YDv, BMv, KMv, 1)
 #define HL_LAUNCH_HEADS_V(YDv, BMv, KMv, DMAv)                                                                         \
         k_y_heads<YDv, BMv, KMv, DMAv><<<grid, HL_THREADS, 0, s>>>(ws->u, d.hdp, ws->wys, d.hdp, p->vars_sorted_dev, ws->P, ws->hgpart, d.o_by,  \
                                                           ws->norm, d.n_stat, ws->xt, ws->m8, d.D, g_elem, g_scale, ws->dy, \
@@ -1019,10 +1031,16 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
                                                           ws->rowpart, pf, d.Theta, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY, clk, d.Theta != d.X, hl_stamp_slot(HL_ST_HEADS))
         if (d.y_dim == 3) HL_LAUNCH_HEADS_Y(3, 64, 8);          // other y_dim (config/hlvae_config_file.txt: y_dim): all class counts up to 8
         else if (d.y_dim == 8) HL_LAUNCH_HEADS_Y(8, 64, 8);
-        else if (p->kmax <= 3) HL_LAUNCH_HEADS(3);
-        else if (p->kmax <= 5) {          // (the D4 / tabular instance keeps the register-staged form too: HL_GEMM_CORE=nt, A/B on one box)
-            static const bool nt = [] { const char* e = getenv("HL_GEMM_CORE"); return e != nullptr && e[0] == 'n'; }();
-            if (nt) HL_LAUNCH_HEADS_V(5, 64, 5, false); else HL_LAUNCH_HEADS(5);
+        else if (p->kmax <= 3) { if (d.hdp >= 256) HL_LAUNCH_HEADS_V(5, 64, 3, 2); else HL_LAUNCH_HEADS_V(5, 64, 3, 1); }
+        else if (p->kmax <= 5) {          // (the D4 / tabular instance keeps the older cores too, for A/B runs on one box:
+            static const int core_env = [] {  //  HL_GEMM_CORE=nt -> register-staged, HL_HEADS_CORE=1 -> [A; B] through LDS-DMA)
+                const char* e = getenv("HL_GEMM_CORE");
+                if (e != nullptr && e[0] == 'n') return 0;
+                e = getenv("HL_HEADS_CORE");
+                return (e != nullptr && e[0] == '1') ? 1 : 2;
+            }();
+            const int core = (core_env == 2 && d.hdp < 256) ? 1 : core_env;      // CORE 2 wants >= 4 k-tiles
+            if (core == 0) HL_LAUNCH_HEADS_V(5, 64, 5, 0); else if (core == 1) HL_LAUNCH_HEADS_V(5, 64, 5, 1); else HL_LAUNCH_HEADS_V(5, 64, 5, 2);
         }
         else if (p->kmax <= 8) HL_LAUNCH_HEADS(8);
         else HL_LAUNCH_HEADS(16);                                // 9..16 classes: one instance
