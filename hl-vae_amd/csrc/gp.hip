@@ -27,45 +27,74 @@
 // ------------------------------------------------------------------------------------------------------------
 // covariance terms.  Hyper-parameters of one latent dimension are hoisted into registers once per thread.
 // ------------------------------------------------------------------------------------------------------------
-struct GpHyp {
-    double sc[HLVAE_GP_MAX_TERMS];
-    double il2[HLVAE_GP_MAX_TERMS][GP_MAX_RBF];
+// (templates on the kernel's shape, round 3: NT = terms, NR = RBF factors per term.  The generic 8 x 2 form costs a lane 24
+//  hyper-parameter and 24 accumulator doubles per kernel -- k_gp_subject_bwd, with two kernels, sat at 204 VGPRs; BASELINE
+//  configs[4]'s kernels have <= 3 terms of <= 1 RBF factor and run the <4, 1> instances.)
+template <int NT = HLVAE_GP_MAX_TERMS, int NR = GP_MAX_RBF>
+struct GpHypT {
+    double sc[NT];
+    double il2[NT][NR];
 };
-struct GpAcc {                                              // per-lane gradient accumulators of one additive kernel
-    double ts[HLVAE_GP_MAX_TERMS];                          // d / d scale      (x scale)
-    double tl[HLVAE_GP_MAX_TERMS][GP_MAX_RBF];              // d / d lengthscale (x lengthscale)
+template <int NT = HLVAE_GP_MAX_TERMS, int NR = GP_MAX_RBF>
+struct GpAccT {                                             // per-lane gradient accumulators of one additive kernel
+    double ts[NT];                                          // d / d scale      (x scale)
+    double tl[NT][NR];                                      // d / d lengthscale (x lengthscale)
 };
+typedef GpHypT<> GpHyp;
+typedef GpAccT<> GpAcc;
 
+// does the <4, 1> instance cover this kernel?
+static bool gp_kernel_small(const hlvae_gp_kernel* k) {
+    if (k->n_terms > 4) return false;
+    for (int t = 0; t < k->n_terms; ++t) {
+        int r = 0;
+        for (int f = 0; f < k->n_factors[t]; ++f) r += k->kind[t][f] == HLVAE_GP_RBF;
+        if (r > 1) return false;
+    }
+    return true;
+}
+
+template <int NT, int NR>
 __device__ __forceinline__ void gp_hoist(const hlvae_gp_kernel& k, const double* __restrict__ hyp, int n_slots, int L, int l,
-                                         GpHyp& h) {
+                                         GpHypT<NT, NR>& h) {
     const double* pos = hyp;
     const double* il2 = hyp + (size_t)2 * n_slots * L;
 #pragma unroll
-    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+    for (int t = 0; t < NT; ++t) {
         h.sc[t] = 0.0;
-        h.il2[t][0] = h.il2[t][1] = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) h.il2[t][r] = 0.0;
         if (t < k.n_terms) {
             h.sc[t] = pos[(size_t)k.scale_slot[t] * L + l];
             int r = 0;
             for (int f = 0; f < k.n_factors[t]; ++f)
                 if (k.kind[t][f] == HLVAE_GP_RBF) {
                     const double v = il2[(size_t)k.ls_slot[t][f] * L + l];
-                    if (r == 0) h.il2[t][0] = v; else h.il2[t][1] = v;
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr)
+                        if (rr == r) h.il2[t][rr] = v;
                     ++r;
                 }
         }
     }
 }
-__device__ __forceinline__ void gp_acc_zero(GpAcc& a) {
+template <int NT, int NR>
+__device__ __forceinline__ void gp_acc_zero(GpAccT<NT, NR>& a) {
 #pragma unroll
-    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) a.ts[t] = a.tl[t][0] = a.tl[t][1] = 0.0;
+    for (int t = 0; t < NT; ++t) {
+        a.ts[t] = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) a.tl[t][r] = 0.0;
+    }
 }
 
 // term t (compile-time index after unrolling) between covariate rows xa and xb: value with its scale, 0 when an
-// indicator factor is off; d0/d1 = differences of the (up to two) RBF factors, e0/e1 = d^2 / ls^2
-__device__ __forceinline__ double gp_term(const hlvae_gp_kernel& k, int t, double sc, double il20, double il21,
-                                          const double* xa, const double* xb, double& d0, double& d1, double& e0, double& e1) {
-    d0 = d1 = 0.0;
+// indicator factor is off; d[r] = differences of the (up to NR) RBF factors, e[r] = d^2 / ls^2
+template <int NR>
+__device__ __forceinline__ double gp_term(const hlvae_gp_kernel& k, int t, double sc, const double (&il2)[NR], const double* xa,
+                                          const double* xb, double (&d)[NR], double (&e)[NR]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) d[r] = 0.0;
     int r = 0;
     bool on = true;
     for (int f = 0; f < k.n_factors[t]; ++f) {
@@ -74,50 +103,62 @@ __device__ __forceinline__ double gp_term(const hlvae_gp_kernel& k, int t, doubl
         if (kind == HLVAE_GP_CAT) on = on && (a == b);                    // GP_model.py:40-41
         else if (kind == HLVAE_GP_BIN) on = on && (a + b == 2.0);         // :32-33
         else {
-            if (r == 0) d0 = a - b; else d1 = a - b;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+                if (rr == r) d[rr] = a - b;
             ++r;
         }
     }
-    e0 = d0 * d0 * il20;
-    e1 = d1 * d1 * il21;
-    if (!on) return 0.0;
-    return r == 0 ? sc : sc * exp(-0.5 * (e0 + e1));                      // :64-69 (product of RBFs = exp of the sum)
-}
-__device__ __forceinline__ double gp_value(const hlvae_gp_kernel& k, const GpHyp& h, const double* xa, const double* xb) {
-    double s = 0.0, d0, d1, e0, e1;
+    double es = 0.0;
 #pragma unroll
-    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+    for (int rr = 0; rr < NR; ++rr) {
+        e[rr] = d[rr] * d[rr] * il2[rr];
+        es += e[rr];
+    }
+    if (!on) return 0.0;
+    return r == 0 ? sc : sc * exp(-0.5 * es);                             // :64-69 (product of RBFs = exp of the sum)
+}
+template <int NT, int NR>
+__device__ __forceinline__ double gp_value(const hlvae_gp_kernel& k, const GpHypT<NT, NR>& h, const double* xa, const double* xb) {
+    double s = 0.0, d[NR], e[NR];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
         if (t >= k.n_terms) break;
-        s += gp_term(k, t, h.sc[t], h.il2[t][0], h.il2[t][1], xa, xb, d0, d1, e0, e1);
+        s += gp_term<NR>(k, t, h.sc[t], h.il2[t], xa, xb, d, e);
     }
     return s;
 }
 // accumulate g * d k / d (hyper-parameters) of one pair
-__device__ __forceinline__ void gp_pair_grad(const hlvae_gp_kernel& k, const GpHyp& h, const double* xa, const double* xb,
-                                             double g, GpAcc& a) {
-    double d0, d1, e0, e1;
+template <int NT, int NR>
+__device__ __forceinline__ void gp_pair_grad(const hlvae_gp_kernel& k, const GpHypT<NT, NR>& h, const double* xa, const double* xb,
+                                             double g, GpAccT<NT, NR>& a) {
+    double d[NR], e[NR];
 #pragma unroll
-    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+    for (int t = 0; t < NT; ++t) {
         if (t >= k.n_terms) break;
-        const double tv = gp_term(k, t, h.sc[t], h.il2[t][0], h.il2[t][1], xa, xb, d0, d1, e0, e1);
+        const double tv = gp_term<NR>(k, t, h.sc[t], h.il2[t], xa, xb, d, e);
         const double gt = g * tv;
         a.ts[t] += gt;
-        a.tl[t][0] += gt * e0;
-        a.tl[t][1] += gt * e1;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) a.tl[t][r] += gt * e[r];
     }
 }
 // wave reduction of the accumulators, lane 0 adds (x d pos / d raw / pos) into the block's LDS rows gacc[slot]
-__device__ __forceinline__ void gp_flush(const hlvae_gp_kernel& k, const GpAcc& a, const double* __restrict__ dpos_l, int L,
+template <int NT, int NR>
+__device__ __forceinline__ void gp_flush(const hlvae_gp_kernel& k, const GpAccT<NT, NR>& a, const double* __restrict__ dpos_l, int L,
                                          double* gacc, int lane) {
 #pragma unroll
-    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+    for (int t = 0; t < NT; ++t) {
         if (t >= k.n_terms) break;
         const double s = wave_sum_d(a.ts[t]);
         if (lane == 0 && s != 0.0) atomicAdd(&gacc[k.scale_slot[t]], s * dpos_l[(size_t)k.scale_slot[t] * L]);
         int r = 0;
         for (int f = 0; f < k.n_factors[t]; ++f)
             if (k.kind[t][f] == HLVAE_GP_RBF) {
-                const double v = wave_sum_d(r == 0 ? a.tl[t][0] : a.tl[t][1]);
+                double v = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) v = rr == r ? a.tl[t][rr] : v;
+                v = wave_sum_d(v);
                 if (lane == 0 && v != 0.0) atomicAdd(&gacc[k.ls_slot[t][f]], v * dpos_l[(size_t)k.ls_slot[t][f] * L]);
                 ++r;
             }
@@ -140,6 +181,7 @@ __global__ void k_gp_transform(const double* __restrict__ raw, int n, double* __
 // 31 MB of K0xz at configs[4]); thread (column j = tid & 127, row phase tid >> 7) keeps x2[j] in registers and walks its rows, so
 // a wave's stores are 64 consecutive doubles of one output row.
 #define GP_KM_ROWS 32
+template <int NT, int NR>
 __global__ __launch_bounds__(256) void k_gp_kernel_matrix(hlvae_gp_kernel k, const double* __restrict__ hyp, int n_slots, int L,
                                                           int Q, const double* __restrict__ x1, int n1, int per_latent1,
                                                           const double* __restrict__ x2, int n2, int per_latent2,
@@ -151,7 +193,7 @@ __global__ __launch_bounds__(256) void k_gp_kernel_matrix(hlvae_gp_kernel k, con
     const double* x2l = x2 + (size_t)(per_latent2 ? l : 0) * n2 * Q;
     for (int e = tid; e < nrow * Q; e += 256) xs[(e / Q) * GP_XS + e % Q] = x1l[(size_t)row0 * Q + e];
     for (int e = tid; e < n2 * Q; e += 256) zs[(e / Q) * GP_XS + e % Q] = x2l[e];
-    GpHyp h;
+    GpHypT<NT, NR> h;
     gp_hoist(k, hyp, n_slots, L, l, h);
     __syncthreads();
     const int j = tid & 127, ph = tid >> 7;
@@ -282,6 +324,7 @@ __global__ __launch_bounds__(256) void k_gp_spd_inv(const double* __restrict__ A
 // ------------------------------------------------------------------------------------------------------------
 #define GP_TS (GP_TMAX + 1)
 
+template <int NT, int NR>
 __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     hlvae_gp_kernel k0, hlvae_gp_kernel k1, const double* __restrict__ hyp, int n_slots, int L, int Q,
     const double* __restrict__ x, const double* __restrict__ noise, const int32_t* __restrict__ idx, int T,
@@ -328,7 +371,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         vsh[tid] = wsh[tid] = 0.0;
         mus[tid] = (mu != nullptr && tid < T && rows[tid] >= 0) ? (double)mu[(size_t)rows[tid] * L + l] : 0.0;
     }
-    GpHyp h0, h1;
+    GpHypT<NT, NR> h0, h1;
     gp_hoist(k0, hyp, n_slots, L, l, h0);
     gp_hoist(k1, hyp, n_slots, L, l, h1);
     __syncthreads();
@@ -440,6 +483,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
 
 // gradient of the bound w.r.t. B_st and K0_st of one (subject, latent), chained into the hyper-parameters:
 //   G_K0 = c/2 iB ;   G_B = c/2 [ iB - v v^T - iB diag(e^lv) iB - iB K0 iB + Y V^T ],  Y = V (iK - Q)
+template <int NT, int NR>
 __global__ __launch_bounds__(256) void k_gp_subject_bwd(
     hlvae_gp_kernel k0, hlvae_gp_kernel k1, const double* __restrict__ hyp, int n_slots, int L, int Q,
     const double* __restrict__ x, const int32_t* __restrict__ idx, int T, int Bn, int M, const double* __restrict__ iB_in,
@@ -449,8 +493,10 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
     const int MS = M + 1;                                         // padded: lanes walk different rows at the same m
     double* vs = reinterpret_cast<double*>(dsm);                  // V_s [T][MS]
     double* ys = vs + (size_t)T * MS;                             // Y_s [T][MS]
+    const int TS = T + 1;                                         // iB, w [T][TS]: sized for the actual T (with V_s / Y_s 49 KB at
+    double* ib = ys + (size_t)T * MS;                             // T = 20, M = 120 -> three workgroups per CU instead of two)
+    double* w = ib + (size_t)T * TS;
     __shared__ double xs[GP_TMAX * GP_XS];
-    __shared__ double ib[GP_TMAX * GP_TS], w[GP_TMAX * GP_TS];
     __shared__ int rows[GP_TMAX];
     __shared__ double vv[GP_TMAX], ee[GP_TMAX];
     __shared__ double gacc[32];                                   // per-row gradient accumulators of this block
@@ -497,8 +543,8 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
             const int i = ti + 16 * ii, j = tj + 16 * jj;
             if (i < T && j < T) {
                 const size_t o = (((size_t)s * L + l) * T + i) * T + j;
-                ib[i * GP_TS + j] = iB_in[o];
-                w[i * GP_TS + j] = K0_in[o] + (i == j ? ee[i] : 0.0);
+                ib[i * TS + j] = iB_in[o];
+                w[i * TS + j] = K0_in[o] + (i == j ? ee[i] : 0.0);
             }
         }
     __syncthreads();
@@ -510,7 +556,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
             const int i = ti + 16 * ii, j = tj + 16 * jj;
             double acc = 0.0;
             if (i < T && j < T)
-                for (int k = 0; k < T; ++k) acc += ib[i * GP_TS + k] * w[k * GP_TS + j];
+                for (int k = 0; k < T; ++k) acc += ib[i * TS + k] * w[k * TS + j];
             tmp[ii][jj] = acc;
         }
     __syncthreads();
@@ -519,13 +565,13 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int i = ti + 16 * ii, j = tj + 16 * jj;
-            if (i < T && j < T) w[i * GP_TS + j] = tmp[ii][jj];
+            if (i < T && j < T) w[i * TS + j] = tmp[ii][jj];
         }
     __syncthreads();
-    GpHyp h0, h1;
+    GpHypT<NT, NR> h0, h1;
     gp_hoist(k0, hyp, n_slots, L, l, h0);
     gp_hoist(k1, hyp, n_slots, L, l, h1);
-    GpAcc a0, a1;
+    GpAccT<NT, NR> a0, a1;
     gp_acc_zero(a0);
     gp_acc_zero(a1);
     // the T x T pairs dealt round-robin to the 256 threads (T = 20: at most 2 pairs per thread; the 16 x 16 + 2 x 2 blocking
@@ -539,7 +585,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
         const double sym = i == j ? 1.0 : 2.0;
         if (rows[i] >= 0 && rows[j] >= 0) {
             double acc = 0.0;                                                 // (iB w iB)[i][j]
-            for (int k = 0; k < T; ++k) acc += w[i * GP_TS + k] * ib[k * GP_TS + j];
+            for (int k = 0; k < T; ++k) acc += w[i * TS + k] * ib[k * TS + j];
             double y0 = 0.0, y1 = 0.0;                                        // (Y V^T)[i][j], two chains
             int m = 0;
             for (; m + 1 < M; m += 2) {
@@ -548,7 +594,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
             }
             if (m < M) y0 += ys[i * MS + m] * vs[j * MS + m];
             const double yv = y0 + y1;
-            const double ibv = ib[i * GP_TS + j];
+            const double ibv = ib[i * TS + j];
             const double g1 = sym * 0.5 * c * (ibv - vv[i] * vv[j] - acc + yv);     // dL / dB_st
             const double g0 = sym * 0.5 * c * ibv;                                  // dL / dK0_st
             gp_pair_grad(k1, h1, xs + i * GP_XS, xs + j * GP_XS, g1, a1);
@@ -567,18 +613,32 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
 // drives the hyper-parameters, all of it the points (which sit in both argument positions).
 // grid (ceil(n2 / 64), row chunks of 64, L), block 256 = 4 waves x 64 columns: a lane owns one column j and walks 16
 // rows; covariates of the row chunk and of the 64 columns are staged in LDS.
-#define GP_PG_ROWS 64
+// Round 3: specialised on the kernel's shape -- NT = terms (<= 4 or <= 8), NR = RBF factors per term (1 or 2) -- and on the rows a
+// lane walks (ROWS / 4).  The generic form carried 40 fp64 accumulators + 24 hyper-parameters per lane for 8 terms x 2 RBF
+// factors (232 VGPRs: two waves per SIMD, and the K0zz launch -- 128 workgroups of 16 dependent pairs per lane -- ran at one
+// wave per SIMD for 50 us); configs[4]'s K0 has 3 terms of one RBF factor each: 92 VGPRs.  The lane's own column covariates sit
+// in registers per (term, factor) instead of being re-read from LDS for every pair.
+template <int NT, int NR, int ROWS>
 __global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const double* __restrict__ hyp, int n_slots, int L,
                                                        int Q, const double* __restrict__ x1, int n1, int per_latent1,
                                                        const double* __restrict__ x2, int n2, int both_args,
                                                        const double* __restrict__ G, double* __restrict__ gprm,
                                                        double* __restrict__ gx2) {
+    constexpr int RPL = ROWS / 4;                                 // rows per lane
     __shared__ double gacc[32];
-    __shared__ double xs[GP_PG_ROWS * GP_XS], xbs[64 * GP_XS];
+    __shared__ double xs[ROWS * GP_XS], xbs[64 * GP_XS];
     __shared__ double zred[4][64][GP_XS];
     const int tid = threadIdx.x, lane = tid & 63, sub = tid >> 6;
     const int j = blockIdx.x * 64 + lane, l = blockIdx.z;
-    const int row0 = blockIdx.y * GP_PG_ROWS, nrow = min(GP_PG_ROWS, n1 - row0);
+    const int row0 = blockIdx.y * ROWS, nrow = min(ROWS, n1 - row0);
+    const int jc = min(j, n2 - 1);
+    const int i_lo = sub * RPL;
+    double gv[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {                               // all gradient loads of this lane in flight before anything else
+        const int i = min(i_lo + r, nrow - 1);
+        gv[r] = G[((size_t)l * n1 + row0 + i) * n2 + jc];
+    }
     if (tid < 32) gacc[tid] = 0.0;
     for (int e = tid; e < nrow * Q; e += 256)
         xs[(e / Q) * GP_XS + e % Q] = x1[((size_t)(per_latent1 ? l : 0) * n1 + row0) * Q + e];
@@ -587,55 +647,106 @@ __global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const 
         xbs[(e / Q) * GP_XS + e % Q] = col < n2 ? x2[((size_t)l * n2 + col) * Q + e % Q] : 0.0;
     }
     for (int q = 0; q < GP_XS; ++q) zred[sub][lane][q] = 0.0;
-    GpHyp h;
-    gp_hoist(k, hyp, n_slots, L, l, h);
-    GpAcc a;
-    gp_acc_zero(a);
-    double tz[HLVAE_GP_MAX_TERMS][GP_MAX_RBF];
+    // hyper-parameters and the (uniform) shape of every term: RBF dims rd[t][.] (-1: none), indicator dims through k
+    double sc[NT], il2[NT][NR];
+    int rd[NT][NR];
+    const double* pos = hyp;
+    const double* il2p = hyp + (size_t)2 * n_slots * L;
 #pragma unroll
-    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) tz[t][0] = tz[t][1] = 0.0;
-    __syncthreads();
-    const int i_lo = sub * (GP_PG_ROWS / 4);
-    const int jc = min(j, n2 - 1);
-    const double gs = both_args ? 0.5 : 1.0;
-    double gv[GP_PG_ROWS / 4];
+    for (int t = 0; t < NT; ++t) {
+        sc[t] = 0.0;
 #pragma unroll
-    for (int r = 0; r < GP_PG_ROWS / 4; ++r) {                    // all loads of this lane in flight before the arithmetic
-        const int i = min(i_lo + r, nrow - 1);
-        gv[r] = G[((size_t)l * n1 + row0 + i) * n2 + jc];
+        for (int r = 0; r < NR; ++r) { il2[t][r] = 0.0; rd[t][r] = -1; }
+        if (t < k.n_terms) {
+            sc[t] = pos[(size_t)k.scale_slot[t] * L + l];
+            int r = 0;
+            for (int f = 0; f < k.n_factors[t]; ++f)
+                if (k.kind[t][f] == HLVAE_GP_RBF) {
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr)
+                        if (rr == r) { il2[t][rr] = il2p[(size_t)k.ls_slot[t][f] * L + l]; rd[t][rr] = k.dim[t][f]; }
+                    ++r;
+                }
+        }
     }
-    const double* xb = xbs + lane * GP_XS;
+    double ts[NT], tl[NT][NR], tz[NT][NR];
 #pragma unroll
-    for (int r = 0; r < GP_PG_ROWS / 4; ++r) {
+    for (int t = 0; t < NT; ++t) {
+        ts[t] = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) tl[t][r] = tz[t][r] = 0.0;
+    }
+    __syncthreads();
+    // this lane's column: RBF coordinates per (term, factor) and the whole covariate row for the indicator factors, in registers
+    double zb[NT][NR], xb[GP_XS - 1];
+#pragma unroll
+    for (int q = 0; q < GP_XS - 1; ++q) xb[q] = xbs[lane * GP_XS + q];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) zb[t][r] = rd[t][r] >= 0 ? xbs[lane * GP_XS + rd[t][r]] : 0.0;
+    const double gs = both_args ? 0.5 : 1.0;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
         const int i = i_lo + r;
         if (i >= nrow || j >= n2) continue;
         const double* xa = xs + i * GP_XS;
         const double gsym = gv[r], g = gs * gsym;
-        double d0, d1, e0, e1;
 #pragma unroll
-        for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+        for (int t = 0; t < NT; ++t) {
             if (t >= k.n_terms) break;
-            const double tv = gp_term(k, t, h.sc[t], h.il2[t][0], h.il2[t][1], xa, xb, d0, d1, e0, e1);
+            bool on = true;
+            for (int f = 0; f < k.n_factors[t]; ++f) {            // indicator factors (uniform loop; the lane's side from registers)
+                const int kind = k.kind[t][f];
+                if (kind == HLVAE_GP_RBF) continue;
+                const int dim = k.dim[t][f];
+                double b = xb[0];
+#pragma unroll
+                for (int q = 1; q < GP_XS - 1; ++q) b = dim == q ? xb[q] : b;
+                const double a = xa[dim];
+                on = on && (kind == HLVAE_GP_CAT ? (a == b) : (a + b == 2.0));       // GP_model.py:40-41, :32-33
+            }
+            double d[NR], e[NR], es = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                d[rr] = rd[t][rr] >= 0 ? xa[rd[t][rr]] - zb[t][rr] : 0.0;
+                e[rr] = d[rr] * d[rr] * il2[t][rr];
+                es += e[rr];
+            }
+            const double tv = !on ? 0.0 : (rd[t][0] < 0 ? sc[t] : sc[t] * exp(-0.5 * es));   // :64-69
             const double gt = g * tv, gz = gsym * tv;
-            a.ts[t] += gt;
-            a.tl[t][0] += gt * e0;
-            a.tl[t][1] += gt * e1;
-            tz[t][0] += gz * d0 * h.il2[t][0];                    // d k / d x2[dim] = k (xa - xb) / ls^2
-            tz[t][1] += gz * d1 * h.il2[t][1];
+            ts[t] += gt;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                tl[t][rr] += gt * e[rr];
+                tz[t][rr] += gz * d[rr] * il2[t][rr];             // d k / d x2[dim] = k (xa - xb) / ls^2
+            }
         }
     }
-    gp_flush(k, a, hyp + (size_t)n_slots * L + l, L, gacc, lane);
-    // inducing points: per-lane LDS row indexed by covariate, summed over the 4 row sub-chunks
+    // hyper-parameters: wave sums, lane 0 adds (x d pos / d raw) into the block's LDS rows
+    const double* dpos_l = hyp + (size_t)n_slots * L + l;
 #pragma unroll
-    for (int t = 0; t < HLVAE_GP_MAX_TERMS; ++t) {
+    for (int t = 0; t < NT; ++t) {
         if (t >= k.n_terms) break;
+        const double s0 = wave_sum_d(ts[t]);
+        if (lane == 0 && s0 != 0.0) atomicAdd(&gacc[k.scale_slot[t]], s0 * dpos_l[(size_t)k.scale_slot[t] * L]);
         int r = 0;
         for (int f = 0; f < k.n_factors[t]; ++f)
             if (k.kind[t][f] == HLVAE_GP_RBF) {
-                zred[sub][lane][k.dim[t][f]] += r == 0 ? tz[t][0] : tz[t][1];
+                double v = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) v = rr == r ? tl[t][rr] : v;
+                v = wave_sum_d(v);
+                if (lane == 0 && v != 0.0) atomicAdd(&gacc[k.ls_slot[t][f]], v * dpos_l[(size_t)k.ls_slot[t][f] * L]);
                 ++r;
             }
     }
+    // inducing points: per-lane LDS row indexed by covariate, summed over the 4 row sub-chunks
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+            if (rd[t][rr] >= 0) zred[sub][lane][rd[t][rr]] += tz[t][rr];
     __syncthreads();
     if (tid < n_slots && gacc[tid] != 0.0) atomicAdd(gprm + (size_t)tid * L + l, gacc[tid]);
     if (gx2 != nullptr && sub == 0 && j < n2) {
@@ -1113,8 +1224,12 @@ int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* hyp, int n_sl
     HL_REQUIRE(hyp && x1 && x2 && out && L > 0 && n1 > 0 && n2 > 0, HLVAE_EINVAL, "gp_kernel_matrix: bad arguments");
     HL_REQUIRE(n2 <= GP_MMAX && Q <= 8, HLVAE_ESHAPE, "gp_kernel_matrix: n2=%d (max %d columns), Q=%d (max 8)", n2, GP_MMAX, Q);
     HL_PROF("gp_kernel_matrix", (hipStream_t)s);
-    k_gp_kernel_matrix<<<dim3((n1 + GP_KM_ROWS - 1) / GP_KM_ROWS, L), 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1,
-                                                                                              x2, n2, per_latent2, jitter, out);
+    const dim3 grid((n1 + GP_KM_ROWS - 1) / GP_KM_ROWS, L);
+    if (gp_kernel_small(k))
+        k_gp_kernel_matrix<4, 1><<<grid, 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2, per_latent2, jitter, out);
+    else
+        k_gp_kernel_matrix<HLVAE_GP_MAX_TERMS, GP_MAX_RBF><<<grid, 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2,
+                                                                                           per_latent2, jitter, out);
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -1140,8 +1255,11 @@ int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, c
                    (u_acc == nullptr || mu != nullptr), HLVAE_EINVAL,
                "gp_subject_fwd: resid or (iKm, mu); u_acc / p1_acc both or none, with mu");
     HL_PROF("gp_subject_fwd", (hipStream_t)s);
-    k_gp_subject_fwd<<<dim3(S, L), 256, (size_t)T * M * sizeof(double), (hipStream_t)s>>>(*k0, *k1, hyp, n_slots, L, Q, x, noise, idx, T, Kxz, B, M, resid,
-                                                           lv, c, iB, K0s, V, v, part, g_mu, g_lv, iKm, mu, u_acc, p1_acc);
+#define GP_SF(NTv, NRv)                                                                                                         \
+    k_gp_subject_fwd<NTv, NRv><<<dim3(S, L), 256, (size_t)T * M * sizeof(double), (hipStream_t)s>>>(                               \
+        *k0, *k1, hyp, n_slots, L, Q, x, noise, idx, T, Kxz, B, M, resid, lv, c, iB, K0s, V, v, part, g_mu, g_lv, iKm, mu, u_acc, p1_acc)
+    if (gp_kernel_small(k0) && gp_kernel_small(k1)) GP_SF(4, 1); else GP_SF(HLVAE_GP_MAX_TERMS, GP_MAX_RBF);
+#undef GP_SF
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -1153,16 +1271,21 @@ int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, c
     if (int rc = gp_check_kernel(k0, n_slots, Q)) return rc;
     if (int rc = gp_check_kernel(k1, n_slots, Q)) return rc;
     HL_REQUIRE(T >= 1 && T <= GP_TMAX && S >= 1 && M <= GP_MMAX, HLVAE_ESHAPE, "gp_subject_bwd: T=%d M=%d", T, M);
-    const size_t smem = (size_t)2 * T * (M + 1) * sizeof(double);
-    static size_t attr_max = 32 * 1024;
-    if (smem > attr_max) {
-        HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_subject_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)smem));
-        attr_max = smem;
+    const size_t smem = ((size_t)2 * T * (M + 1) + (size_t)2 * T * (T + 1)) * sizeof(double);
+    const bool small = gp_kernel_small(k0) && gp_kernel_small(k1);
+    static size_t attr_max[2] = {32 * 1024, 32 * 1024};
+    if (smem > attr_max[small]) {
+        HL_CHECK(hipFuncSetAttribute(small ? reinterpret_cast<const void*>(&k_gp_subject_bwd<4, 1>)
+                                           : reinterpret_cast<const void*>(&k_gp_subject_bwd<HLVAE_GP_MAX_TERMS, GP_MAX_RBF>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_max[small] = smem;
     }
     HL_PROF("gp_subject_bwd", (hipStream_t)s);
-    k_gp_subject_bwd<<<dim3(S, L), 256, smem, (hipStream_t)s>>>(*k0, *k1, hyp, n_slots, L, Q, x, idx, T, B, M, iB, K0s, V, v, Y,
-                                                              lv, c, gprm);
+#define GP_SB(NTv, NRv)                                                                                                         \
+    k_gp_subject_bwd<NTv, NRv><<<dim3(S, L), 256, smem, (hipStream_t)s>>>(*k0, *k1, hyp, n_slots, L, Q, x, idx, T, B, M, iB, K0s, V, v, Y, \
+                                                                        lv, c, gprm)
+    if (small) GP_SB(4, 1); else GP_SB(HLVAE_GP_MAX_TERMS, GP_MAX_RBF);
+#undef GP_SB
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -1173,9 +1296,15 @@ int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots
     if (int rc = gp_check_kernel(k, n_slots, Q)) return rc;
     HL_REQUIRE(!both_args || n1 == n2, HLVAE_ESHAPE, "gp_param_grad: both_args needs a square matrix");
     HL_PROF("gp_param_grad", (hipStream_t)s);
-    dim3 grid((n2 + 63) / 64, (n1 + GP_PG_ROWS - 1) / GP_PG_ROWS, L);
-    k_gp_param_grad<<<grid, 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2, both_args, G, gprm,
-                                                     gx2);
+    const bool small = gp_kernel_small(k);
+    // rows per workgroup: 64 (a lane walks 16) when that still fills the machine, else 16 (K0zz: 128 -> 512 workgroups)
+    const bool tall = (long)((n2 + 63) / 64) * ((n1 + 63) / 64) * L >= 512;
+#define GP_PG(NTv, NRv, ROWSv)                                                                                             \
+    k_gp_param_grad<NTv, NRv, ROWSv><<<dim3((n2 + 63) / 64, (n1 + ROWSv - 1) / ROWSv, L), 256, 0, (hipStream_t)s>>>(        \
+        *k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2, both_args, G, gprm, gx2)
+    if (small) { if (tall) GP_PG(4, 1, 64); else GP_PG(4, 1, 16); }
+    else { if (tall) GP_PG(HLVAE_GP_MAX_TERMS, GP_MAX_RBF, 32); else GP_PG(HLVAE_GP_MAX_TERMS, GP_MAX_RBF, 16); }   // (64 rows: 256 VGPRs)
+#undef GP_PG
     HL_LAUNCH_CHECK();
     return 0;
 }
