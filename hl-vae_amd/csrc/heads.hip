@@ -1031,7 +1031,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
                                                           ws->rowpart, pf, d.Theta, xh, B, want_grad, d.conv ? ws->yv : nullptr, d.NY, clk, d.Theta != d.X, hl_stamp_slot(HL_ST_HEADS))
         if (d.y_dim == 3) HL_LAUNCH_HEADS_Y(3, 64, 8);          // other y_dim (config/hlvae_config_file.txt: y_dim): all class counts up to 8
         else if (d.y_dim == 8) HL_LAUNCH_HEADS_Y(8, 64, 8);
-        else if (p->kmax <= 3) { if (d.hdp >= 256) HL_LAUNCH_HEADS_V(5, 64, 3, 2); else HL_LAUNCH_HEADS_V(5, 64, 3, 1); }
+        else if (p->kmax <= 3) { if (d.hdp % 256 == 0) HL_LAUNCH_HEADS_V(5, 64, 3, 2); else HL_LAUNCH_HEADS_V(5, 64, 3, 1); }
         else if (p->kmax <= 5) {          // (the D4 / tabular instance keeps the older cores too, for A/B runs on one box:
             static const int core_env = [] {  //  HL_GEMM_CORE=nt -> register-staged, HL_HEADS_CORE=1 -> [A; B] through LDS-DMA)
                 const char* e = getenv("HL_GEMM_CORE");
@@ -1039,7 +1039,7 @@ int hl_launch_y_heads(const hlvae_plan* p, const hlvae_ws* ws, const float* g_el
                 e = getenv("HL_HEADS_CORE");
                 return (e != nullptr && e[0] == '1') ? 1 : 2;
             }();
-            const int core = (core_env == 2 && d.hdp < 256) ? 1 : core_env;      // CORE 2 wants >= 4 k-tiles
+            const int core = (core_env == 2 && d.hdp % 256 != 0) ? 1 : core_env;  // CORE 2: whole groups of four k-tiles
             if (core == 0) HL_LAUNCH_HEADS_V(5, 64, 5, 0); else if (core == 1) HL_LAUNCH_HEADS_V(5, 64, 5, 1); else HL_LAUNCH_HEADS_V(5, 64, 5, 2);
         }
         else if (p->kmax <= 8) HL_LAUNCH_HEADS(8);

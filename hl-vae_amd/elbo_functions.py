@@ -325,6 +325,7 @@ class GPPriorHIP:
         self._grad_m = self._grad_H = self._iH = self._tmp = None
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         self._prep, self._prep_stream, self._tail_pending = None, None, False
+        self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
             for t in (self._theta, self.m, self._KH):
                 dp.broadcast_(t)
@@ -436,36 +437,81 @@ class GPPriorHIP:
             self.fail.zero_()
             raise RuntimeError("GPPriorHIP: a covariance (K0zz, H, iH_new or a subject block) is not positive definite")
 
-    def prepare(self, labels, rows=None, groups=None):
+    def prepare(self, labels, rows=None, groups=None, ahead=False):
         """Everything of the bound that depends on the prior's own state and on the batch's COVARIATES only -- transformed
         hyper-parameters, K0xz, (the factorisations when none were left behind), iK m, H iK, iK - iK H iK, the cleared
         accumulators -- queued on a stream of the prior's, forked from the caller's here.  Called at the top of a training step
         (ELBOTrainer) it runs UNDER the VAE's forward pass (encoder, fused middle, head kernel: ~75 us at 1024 rows) instead of
         between it and the per-subject kernel (~80 us of the step's critical path, round-3 timeline); ``kl_and_grads`` joins it.
         labels [N, Q] covariates; rows (int32 device tensor): the batch's rows of ``labels`` (the gather runs on the side stream
-        too); groups: the subject structure, as for kl_and_grads."""
+        too); groups: the subject structure, as for kl_and_grads.
+        ahead: the caller asserts that ``compute_ahead`` ran for exactly this batch behind the last optimiser step (the same
+        contract as a pre-packed input batch): its gathered covariates and K0xz are taken as they are."""
         dev = labels.device
         main = torch.cuda.current_stream(dev)
         if self._prep_stream is None:
             self._prep_stream = torch.cuda.Stream(device=dev)
         sP = self._prep_stream
         sP.wait_stream(main)
+        B = labels.shape[0] if rows is None else rows.shape[0]
+        # (groups from the sampler only: the host-side grouping cache is keyed by the covariate tensor, and the ahead buffer is reused)
+        use_ahead = (ahead and rows is not None and groups is not None and self._ahead == B and B in self._ahead_bufs
+                     and self._fact_key == (self._theta._version, self._KH._version))
+        if use_ahead:
+            sP.wait_stream(self._ahead_stream)
         with torch.cuda.stream(sP):
-            x = labels if rows is None else labels.index_select(0, rows.long())
-            x = x.contiguous()
+            if use_ahead:
+                x, Kxz = self._ahead_bufs[B]
+            else:
+                x = labels if rows is None else labels.index_select(0, rows.long())
+                x, Kxz = x.contiguous(), None
             idx = groups if groups is not None else self._group(x)
-            st_ = self._prepare_state(x, idx.shape[0], idx.shape[1], x.shape[0], dev)
+            st_ = self._prepare_state(x, idx.shape[0], idx.shape[1], x.shape[0], dev, Kxz=Kxz)
         self._prep = (x, idx) + st_
         return x
 
-    def _prepare_state(self, x, S, T, B, dev):
-        """the state-only launches (current stream); returns (buf, hyp, Kxz, iKm, HiK, N1)"""
+    def compute_ahead(self, labels, rows):
+        """Covariate gather + K0xz of a FOLLOWING batch on a stream of their own, forked from the caller's here.  Called by
+        ``optimizer_step(next_batch=...)`` right behind the hyper-parameter transform: K0xz of the next batch needs the updated
+        hyper-parameters and inducing points but not the batched inversion, so its 31 MB kernel matrix (55 us inside the step at
+        configs[4]) runs BESIDE the 82 us inversion instead of behind it (round-3 timeline: the state update -> K0xz ->
+        iK-products chain is the step's loop-carried critical path).  ``prepare(..., ahead=True)`` picks the buffers up."""
+        dev = labels.device
+        main = torch.cuda.current_stream(dev)
+        if self._ahead_stream is None:
+            self._ahead_stream = torch.cuda.Stream(device=dev)
+        sK = self._ahead_stream
+        sK.wait_stream(main)
+        B = rows.shape[0]
+        ab = self._ahead_bufs.get(B)
+        if ab is None:          # (never evicted: captured graphs hold the addresses, as for _step_buffers)
+            ab = (torch.empty(B, labels.shape[1], dtype=torch.float64, device=dev),
+                  torch.empty(self.L, B, self.M, dtype=torch.float64, device=dev))
+            self._ahead_bufs[B] = ab
+        with torch.cuda.stream(sK):
+            torch.index_select(labels, 0, rows.long(), out=ab[0])
+            self.kernel_matrix(self.k0, ab[0], self.zt_list, out=ab[1])
+        self._ahead = B
+
+    def prime_ahead(self, labels, rows):
+        """``compute_ahead`` outside a training step (before the first step of a pipelined sequence / the first replay of a
+        captured chain): transforms the hyper-parameters first"""
+        self.join()
+        self._transform()
+        self.compute_ahead(labels, rows)
+
+    def _prepare_state(self, x, S, T, B, dev, Kxz=None):
+        """the state-only launches (current stream); returns (buf, hyp, Kxz, iKm, HiK, N1).  Kxz given: computed ahead, behind the
+        transform of the last optimiser step (the planes in self._hyp are current)"""
         L, M = self.L, self.M
         k0, z = self.k0, self.zt_list
         buf = self._step_buffers(B, S, T, dev)
         mm = self._mm
-        hyp = self._transform()
-        Kxz = self.kernel_matrix(k0, x, z, out=buf["Kxz"])
+        if Kxz is None:
+            hyp = self._transform()
+            Kxz = self.kernel_matrix(k0, x, z, out=buf["Kxz"])
+        else:
+            hyp = self._hyp
         if self._fact_key != (self._theta._version, self._KH._version):
             # no factorisation left behind by the previous optimiser step (first step, or parameters touched since): K0zz
             # (written next to H) and H inverted straight into their homes
@@ -662,8 +708,9 @@ class GPPriorHIP:
             b[:, rt] = K1 @ mu_tilde[:, rp]
         return (a + b).squeeze(2).t().contiguous()                                       # :188
 
-    def optimizer_step(self, defer=False):
-        """Adam on [hyper-parameters | inducing points] (HLVAE_main.py:277-278; one fused kernel, device-side step counter), then
+    def optimizer_step(self, defer=False, next_batch=None):
+        """next_batch = (labels, rows) of the FOLLOWING step: its K0xz is computed beside the batched inversion (compute_ahead).
+        Adam on [hyper-parameters | inducing points] (HLVAE_main.py:277-278; one fused kernel, device-side step counter), then
         the natural-gradient update of (m, H), training.py:130-137: iH_new = iH + lr (gH + gH^T) in place, ONE batched inversion
         of [iH_new | K0zz of the parameters Adam has just produced] -> [H_new | iK] straight into their homes (the next step
         starts with both factorisations and log-determinants in hand), m_new = H_new (iH m - lr (grad_m - 2 gH m))."""
@@ -681,11 +728,11 @@ class GPPriorHIP:
                 self._prep_stream.wait_stream(s_)
             self._pending = False
             with torch.cuda.stream(self._prep_stream):
-                self._state_update()
+                self._state_update(next_batch)
             self._tail_pending = True
             return
         self.join()
-        self._state_update()
+        self._state_update(next_batch)
 
     def join_tail(self):
         """the caller's stream waits for a deferred state update (optimizer_step(defer=True))"""
@@ -693,8 +740,9 @@ class GPPriorHIP:
             torch.cuda.current_stream(self.zt_list.device).wait_stream(self._prep_stream)
             self._tail_pending = False
 
-    def _state_update(self):
+    def _state_update(self, next_batch=None):
         lib, st, L, M = _lib.load(), self._stream(), self.L, self.M
+        self._ahead = None
         _lib.check(lib.hlvae_gp_adam(_lib.ptr(self._theta), _lib.ptr(self._gtheta), _lib.ptr(self._adam_m),
                                      _lib.ptr(self._adam_v), self._theta.numel(), _lib.ptr(self._adam_step),
                                      _C.c_double(self.lr), _C.c_double(0.9), _C.c_double(0.999), _C.c_double(1e-8), st), "gp_adam")
@@ -702,6 +750,8 @@ class GPPriorHIP:
                    "gp_natgrad_apply")                                       # iH_new, in place in _KH2[:L]
         self._iH = None
         self._transform()
+        if next_batch is not None:
+            self.compute_ahead(*next_batch)
         self.kernel_matrix(self.k0, self.zt_list, self.zt_list, jitter=self.eps, out=self._KH2[L:])
         self._spd_inv(self._KH2, self._HiK, self._ld2, n_neg=L, logdet_neg=self._ldH)      # log det H_new = - log det iH_new
         self._bmv(self.H, self._tmp, self.m)                                 # m_new = H_new tmp

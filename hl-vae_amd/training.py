@@ -238,6 +238,14 @@ class ELBOTrainer:
         B = rows.shape[0]
         m._ensure_device_state(B)
         self._feed_stage(ds, rows, B)
+        if self._gp_ahead():
+            self.gp.prime_ahead(ds.labels, rows)
+
+    def _gp_ahead(self):
+        """GP prior: the next batch's K0xz computed beside the state update's inversion (GPPriorHIP.compute_ahead; HL_GP_AHEAD=0
+        switches it off)"""
+        return self.kl == "gp" and hasattr(self.gp, "compute_ahead") and os.environ.get("HL_GP_AHEAD", "1") != "0" \
+            and os.environ.get("HL_GP_PREPARE", "1") != "0"
 
     def step_rows(self, ds, rows: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None, groups=None,
                   prefetch_rows: Optional[torch.Tensor] = None, prepacked: bool = False):
@@ -267,7 +275,7 @@ class ELBOTrainer:
         if self.kl == "gp":
             if hasattr(self.gp, "prepare") and os.environ.get("HL_GP_PREPARE", "1") != "0":
                 # the prior's state-only launches (and the covariate gather) run on a stream of its own under the VAE's forward pass
-                train_x = self.gp.prepare(ds.labels, rows, groups=groups)
+                train_x = self.gp.prepare(ds.labels, rows, groups=groups, ahead=prepacked and self._gp_ahead())
             else:
                 train_x = ds.labels.index_select(0, rows.long())
         self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None,
@@ -403,10 +411,11 @@ class ELBOTrainer:
         m._fwd_token += 1
         m._grad_region_clean = True
         if self.kl == "gp":
+            nb = {"next_batch": (feed_next[0].labels, feed_next[1])} if (feed_next is not None and self._gp_ahead()) else {}
             if self._gp_defer and hasattr(self.gp, "join_tail"):
-                self.gp.optimizer_step(defer=True)      # (inside a captured chain: the state update runs beside the next step's forward pass)
+                self.gp.optimizer_step(defer=True, **nb)      # (inside a captured chain: the state update runs beside the next step's forward pass)
             else:
-                self.gp.optimizer_step()
+                self.gp.optimizer_step(**nb)
         if prefetch is not None:                 # join; the prefetched batch's buffers become the front set
             torch.cuda.current_stream(m.device).wait_stream(self._pf_stream)
             m._swap_input_buffers()
