@@ -493,6 +493,12 @@ class GPPriorHIP:
             self.kernel_matrix(self.k0, ab[0], self.zt_list, out=ab[1])
         self._ahead = B
 
+    def join_ahead(self):
+        """the caller's stream waits for a compute_ahead nobody has consumed yet (end of a captured chain: every forked stream
+        must be back on the capturing one)"""
+        if self._ahead_stream is not None and self._ahead is not None:
+            torch.cuda.current_stream(self.zt_list.device).wait_stream(self._ahead_stream)
+
     def prime_ahead(self, labels, rows):
         """``compute_ahead`` outside a training step (before the first step of a pipelined sequence / the first replay of a
         captured chain): transforms the hyper-parameters first"""

@@ -499,6 +499,8 @@ class ELBOTrainer:
                     self.opt.finish_pending()          # nothing may stay in flight across the end of a graph
                 if self._gp_defer:
                     self.gp.join_tail()
+                if self._gp_ahead():
+                    self.gp.join_ahead()
         finally:
             self._wy_dbuf = False
             self._gp_defer = False

@@ -22,6 +22,6 @@ for it in range(3):
     torch.cuda.synchronize()
     t = model._ws_t
     d = model._dims
-    out = {k: hashlib.sha1(t[k].cpu().numpy().tobytes()).hexdigest()[:12] for k in ("dy", "dyT", "log_p_x", "xhat")}
+    out = {k: hashlib.sha1((t[k].view(torch.int16) if t[k].dtype == torch.bfloat16 else t[k]).cpu().numpy().tobytes()).hexdigest()[:12] for k in ("dy", "dyT", "log_p_x", "xhat")}
     out["G"] = hashlib.sha1(t["G"][int(d.atomic_region):int(d.arena_size)].cpu().numpy().tobytes()).hexdigest()[:12]
     print(f"core={os.environ.get('HL_HEADS_CORE', '2')} rows={B} step {it}: nll {float(tr.scalars()['nll_sum']):.6f}", out)
