@@ -311,114 +311,15 @@ __global__ __launch_bounds__(256) void k_gp_spd_inv(const double* __restrict__ A
     }
 }
 
-// Round 3 form of the sweep: 512 threads = a 32 x 16 grid, lane (ti, tj) owns the 4 x 8 elements (ti + 32 ii, tj + 16 jj) -- two
-// waves per SIMD, so one wave's LDS round trip (publish -> barrier -> read back) runs under the other's 32 FMAs -- and the
-// reciprocal of the NEXT pivot is taken off the per-pivot chain: the lane that owns element (k + 1, k + 1) updates it first and
-// starts its reciprocal (v_rcp_f64 + two Newton steps, a ~100-clock dependent chain) beside the block update, then publishes it
-// with the next pivot's row; nobody computes a reciprocal behind the barrier any more.
-template <int KC>
-__device__ __forceinline__ void gj_pivots512(double (&a)[4][8], double* row, double* col, double* pkb, double* pv, double& pk_mine,
-                                             int N, int ti, int tj) {
-    constexpr int KR = KC >> 1, PH = (KC & 1) * 16;              // row block / row phase of this group of 16 pivots
-    constexpr int KCn = KC < 7 ? KC + 1 : 7, KRn = KCn >> 1;     // blocks of pivot k + 1 when it starts the next group
-    for (int kr = 0; kr < 16; ++kr) {
-        const int k = KC * 16 + kr;
-        if (k >= N) return;
-        double* rw = row + (k & 1) * GP_MMAX;
-        double* cl = col + (k & 1) * GP_MMAX;
-        const bool ik = ti == PH + kr, jk = tj == kr;
-        if (ik) {
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) rw[tj + 16 * jj] = a[KR][jj];
-        }
-        if (jk) {
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) cl[ti + 32 * ii] = a[ii][KC];
-        }
-        if (ik && jk) { pkb[k & 1] = pk_mine; pv[k] = a[KR][KC]; }
-        __syncthreads();
-        const double pk = pkb[k & 1];
-        double cr[4], rc[8], cz[4], rz[8];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) cz[ii] = cr[ii] = cl[ti + 32 * ii];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) rz[jj] = rc[jj] = rw[tj + 16 * jj] * pk;
-        if (ik) cz[KR] = 0.0;                              // the generic update leaves pivot row and column alone
-        if (jk) rz[KC] = 0.0;
-        // element (k + 1, k + 1) first (meaningful in its owner lane only), its reciprocal beside the block update
-        const bool same = kr < 15;
-        const double an = same ? a[KR][KC] : a[KRn][KCn];
-        const double czn = same ? cz[KR] : cz[KRn], rzn = same ? rz[KC] : rz[KCn];
-        pk_mine = gp_rcp(fma(-czn, rzn, an));
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) a[ii][jj] = fma(-cz[ii], rz[jj], a[ii][jj]);
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) a[KR][jj] = ik ? rc[jj] : a[KR][jj];            // pivot row:    a[k][j] / p
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) a[ii][KC] = jk ? -cr[ii] * pk : a[ii][KC];      // pivot column: -a[i][k] / p
-        if (ik && jk) a[KR][KC] = pk;                                                  // pivot:        1 / p
-    }
-}
-
-__global__ __launch_bounds__(512) void k_gp_spd_inv512(const double* __restrict__ A, int N, double* __restrict__ inv,
-                                                       double* __restrict__ logdet, int* __restrict__ fail, int n_neg,
-                                                       double* __restrict__ logdet_neg) {
-    __shared__ double row[2 * GP_MMAX], col[2 * GP_MMAX];
-    __shared__ double pv[GP_MMAX], pkb[2];
-    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-    const double* src = A + (size_t)blockIdx.x * N * N;
-    double a[4][8];
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int i = ti + 32 * ii, j = tj + 16 * jj;
-            a[ii][jj] = (i < N && j < N) ? src[(size_t)i * N + j] : (i == j ? 1.0 : 0.0);
-        }
-    double pk_mine = gp_rcp(a[0][0]);                      // (the owner of element (0, 0) is the lane that publishes it)
-    gj_pivots512<0>(a, row, col, pkb, pv, pk_mine, N, ti, tj);
-    gj_pivots512<1>(a, row, col, pkb, pv, pk_mine, N, ti, tj);
-    gj_pivots512<2>(a, row, col, pkb, pv, pk_mine, N, ti, tj);
-    gj_pivots512<3>(a, row, col, pkb, pv, pk_mine, N, ti, tj);
-    gj_pivots512<4>(a, row, col, pkb, pv, pk_mine, N, ti, tj);
-    gj_pivots512<5>(a, row, col, pkb, pv, pk_mine, N, ti, tj);
-    gj_pivots512<6>(a, row, col, pkb, pv, pk_mine, N, ti, tj);
-    gj_pivots512<7>(a, row, col, pkb, pv, pk_mine, N, ti, tj);
-    double* dst = inv + (size_t)blockIdx.x * N * N;
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int i = ti + 32 * ii, j = tj + 16 * jj;
-            if (i < N && j < N) dst[(size_t)i * N + j] = a[ii][jj];
-        }
-    __syncthreads();
-    if (tid < 64) {                                        // log-determinant = sum of log pivots
-        double ld = 0.0;
-        bool bad = false;
-        for (int k = tid; k < N; k += 64) {
-            const double p = pv[k];
-            bad |= !(p > 0.0);
-            ld += log(p);
-        }
-        ld = wave_sum_d(ld);
-        if (bad && fail != nullptr) atomicExch(fail, 1);
-        if (tid == 0) {
-            logdet[blockIdx.x] = ld;
-            if ((int)blockIdx.x < n_neg) logdet_neg[blockIdx.x] = -ld;       // log det of the INVERSE (H_new from iH_new)
-        }
-    }
-}
-
 // (Round 3 built a blocked form of this sweep -- four pivots per phase: P^-1 of the 4 x 4 pivot block in every lane, the scaled
 //  pivot rows published by their owners, a rank-4 update of the 8 x 8 register block, 30 phases of two barriers instead of 120
 //  pivots -- and dropped it: 105 us against 84 us for this kernel on [iH_new | K0zz] (64 matrices of 120 x 120), and 2.6e-5
 //  instead of 5e-7 on the natural-gradient terms of the ill-conditioned (1e8) config-5 matrices.  The redundant 4 x 4 inversion
 //  is four DEPENDENT reciprocal chains per phase, and the rank-4 update reads 64 LDS doubles per lane where the rank-1 form reads
 //  16: the phase costs 3500 clocks against 4 x 1400.  fp64 MFMA would not help either: v_mfma_f64_16x16x4 runs at the vector
-//  FMA rate on MI355X.  What bounds this kernel is the per-pivot chain publish -> barrier -> reciprocal -> broadcast.)
+//  FMA rate on MI355X.  A 512-thread form -- 4 x 8 elements per lane, two waves per SIMD, the NEXT pivot's reciprocal computed by
+//  its owner beside the block update and published with the row -- measured 86.6 us against 84.5: the sweep's ~200 instructions
+//  per pivot are per WAVE (row scaling, selects, LDS traffic), halving the block only halves the 64 FMAs among them.)
 // ------------------------------------------------------------------------------------------------------------
 // per (subject, latent) block.  T <= 32 rows per subject (padded), M <= 128 inducing points, 256 threads as a
 // 16 x 16 grid: lane (ti, tj) owns the 2 x 2 elements (ti + 16 ii, tj + 16 jj) of the T x T blocks.
@@ -1307,11 +1208,6 @@ static int gp_check_kernel(const hlvae_gp_kernel* k, int n_slots, int Q) {
     return 0;
 }
 
-static bool gp_inv512() {          // HL_GP_INV=256: the 256-thread form of the batched inverse (A/B)
-    static const bool v = [] { const char* e = getenv("HL_GP_INV"); return !(e != nullptr && e[0] == '2'); }();
-    return v;
-}
-
 extern "C" {
 
 int hlvae_gp_transform(const double* raw, int n_slots, int L, double* hyp, hlvae_stream s) {
@@ -1343,8 +1239,7 @@ int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* hyp, int n_sl
 int hlvae_gp_chol_inv(const double* A, int n, int N, double* inv, double* logdet, int* fail, hlvae_stream s) {
     HL_REQUIRE(A && inv && logdet && n > 0 && N > 0 && N <= GP_MMAX, HLVAE_EINVAL, "gp_chol_inv: N=%d (max %d)", N, GP_MMAX);
     HL_PROF("gp_spd_inv", (hipStream_t)s);
-    if (gp_inv512()) k_gp_spd_inv512<<<n, 512, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, 0, nullptr);
-    else k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, 0, nullptr);
+    k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, 0, nullptr);
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -1481,8 +1376,7 @@ int hlvae_gp_spd_inv2(const double* A, int n, int N, double* inv, double* logdet
     HL_REQUIRE(A && inv && logdet && n > 0 && N > 0 && N <= GP_MMAX && n_neg >= 0 && n_neg <= n && (n_neg == 0 || logdet_neg),
                HLVAE_EINVAL, "gp_spd_inv2: N=%d (max %d) n=%d n_neg=%d", N, GP_MMAX, n, n_neg);
     HL_PROF("gp_spd_inv", (hipStream_t)s);
-    if (gp_inv512()) k_gp_spd_inv512<<<n, 512, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, n_neg, logdet_neg);
-    else k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, n_neg, logdet_neg);
+    k_gp_spd_inv<<<n, 256, 0, (hipStream_t)s>>>(A, N, inv, logdet, fail, n_neg, logdet_neg);
     HL_LAUNCH_CHECK();
     return 0;
 }

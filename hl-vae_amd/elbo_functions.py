@@ -326,6 +326,7 @@ class GPPriorHIP:
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         self._prep, self._prep_stream, self._tail_pending = None, None, False
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
+        self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
             for t in (self._theta, self.m, self._KH):
                 dp.broadcast_(t)
@@ -401,7 +402,7 @@ class GPPriorHIP:
         if self._mm is None:
             L, M = self.L, self.M
             f64 = dict(dtype=torch.float64, device=dev)
-            self._mm = {k: torch.empty(L, M, M, **f64) for k in ("HiK", "N1", "T1", "Bm", "HiKW", "Rs", "G_Kzz", "grad_H")}
+            self._mm = {k: torch.empty(L, M, M, **f64) for k in ("HiK", "N1", "T1", "T1b", "Bm", "HiKW", "Rs", "G_Kzz", "grad_H")}
             self._mm.update({k: torch.empty(L, M, 1, **f64) for k in ("iKm", "grad_m", "tmp")})
         return buf
 
@@ -622,6 +623,8 @@ class GPPriorHIP:
                        "gp_bound")
             if self.dp is not None:
                 self.dp.allreduce_(self._xchg)                               # W, P1, u, bound of the GLOBAL batch
+            evW = torch.cuda.Event()
+            evW.record(sA)                                                   # W, P1, u of the global batch are final
             # natural-gradient terms (elbo_functions.py:279-283)
             T1 = self._bmm_into(iK, W, mm["T1"])
             Bm = self._bmm_into(T1, iK, mm["Bm"], D=iK)                      # iK W iK + iK
@@ -629,14 +632,20 @@ class GPPriorHIP:
             _lib.check(lib.hlvae_gp_natgrad(_lib.ptr(Bm), _lib.ptr(iK), _lib.ptr(iH), _lib.ptr(self.m), _lib.ptr(P1),
                                             _C.c_double(self.ng_lr), M, L, _lib.ptr(self._grad_m), _lib.ptr(self._grad_H),
                                             _lib.ptr(self._tmp), st), "gp_natgrad")
+        # K0zz's gradient needs W but none of the natural-gradient products: it goes BEHIND chain C (round 3; both were one
+        # serial chain of ten launches on sA that ended 115 us after chain C -- HL_GP_SPLIT=0 restores that order)
+        with torch.cuda.stream(sC if self._split_kzz else sA):
+            st = self._stream()
+            if self._split_kzz:
+                sC.wait_event(evW)
             HiKW = self._bmm_into(HiK, W, mm["HiKW"])
             # R + R^T with R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T): K0zz's gradient is needed symmetrised.
             # It is built from global sums only, i.e. replicated: each rank contributes 1 / world of it
             Rs = mm["Rs"]
             _lib.check(lib.hlvae_gp_rsym(_lib.ptr(u), _lib.ptr(self.m), _lib.ptr(W), _lib.ptr(HiKW), _lib.ptr(self.H), _C.c_double(c), M, L,
                                          _lib.ptr(Rs), st), "gp_rsym")
-            T1 = self._bmm_into(iK, Rs, mm["T1"])
-            G_Kzz_s = self._bmm_into(T1, iK, mm["G_Kzz"], D=iK, alpha=-1.0 / world, beta=1.0 / world)   # (G + G^T), G = -(iK R iK) + iK / 2
+            T1b = self._bmm_into(iK, Rs, mm["T1b"])
+            G_Kzz_s = self._bmm_into(T1b, iK, mm["G_Kzz"], D=iK, alpha=-1.0 / world, beta=1.0 / world)   # (G + G^T), G = -(iK R iK) + iK / 2
             _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
                                                _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
         self._pending = True
