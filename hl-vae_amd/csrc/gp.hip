@@ -1065,6 +1065,123 @@ __global__ __launch_bounds__(256) void k_gp_rsym(const double* __restrict__ u, c
     out[e] = c * (ui * mj + mi * uj - W[e] + X[e] + X[o + (size_t)j * N + i]) + H[e] + mi * mj;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The M x M algebra of a step behind W = sum_s Ks^T iB Ks as ONE launch (round 3).  Per latent it is two independent chains of
+// dependent products (elbo_functions.py:279-283 and the K0zz gradient of kl_and_grads):
+//     X:  T1 = iK W  ->  Bm = T1 iK + iK  ->  grad_m, grad_H, tmp                      (k_gp_natgrad, k_gp_natgrad_h)
+//     Z:  HiKW = (H iK) W  ->  Rs = R + R^T  ->  T1b = iK Rs  ->  G = a (T1b iK) + b iK    (k_gp_rsym)
+// As 5 k_gp_bmm + 3 element-wise launches on one stream they were the tail of the GP step's longest chain: every launch is 512
+// workgroups x 61 KB of LDS that cannot share a CU with the VAE's optimiser launches running beside them (4 x 40 KB), and took
+// 60-85 us instead of 12.  Here one workgroup of 1024 threads per (latent, chain) walks its chain: 64 workgroups, no LDS for the
+// products -- a wave owns a 32 x 32 block of the output and reads its fragments of both operands straight from L2 (the whole
+// working set of a latent is < 1 MB) -- so nothing it needs can be taken away by a co-running launch.
+// Fragments of v_mfma_f64_16x16x4_f64 over a block of 16 k: step s of the block uses k = kb + 4 (lane >> 4) + s on BOTH sides,
+// so a lane's four A values are 32 contiguous bytes of its row (two 16-byte loads, every 128-byte row segment used whole) and
+// its B values four loads of 128-byte row segments.  N % 4 == 0.
+__device__ __forceinline__ void gp_mm_wg(const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ D,
+                                         double* __restrict__ C, int N, double alpha, double beta, int wave, int lane) {
+    const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, q = lane & 15;
+    f64x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const int row0 = 32 * wr + q, col0 = 32 * wc + q;
+    const bool rok[2] = {row0 < N, row0 + 16 < N}, cok[2] = {col0 < N, col0 + 16 < N};
+    const double* ap[2] = {A + (size_t)min(row0, N - 1) * N, A + (size_t)min(row0 + 16, N - 1) * N};
+    const double* bp[2] = {B + min(col0, N - 1), B + min(col0 + 16, N - 1)};
+    for (int kb = 0; kb < N; kb += 16) {
+        const int k0 = kb + 4 * g;
+        const bool kok = k0 < N;                                   // (N % 4 == 0: the lane's four k are in or out together)
+        const int kc = kok ? k0 : 0;
+        f64x4_t a[2];
+        double b[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f64x4_t*>(ap[i] + kc);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) b[j][s_] = bp[j][(size_t)(kc + s_) * N];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (!(kok && rok[i])) a[i] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (!(kok && cok[j])) { b[j][0] = b[j][1] = b[j][2] = b[j][3] = 0.0; }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][s_], b[j][s_], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 32 * wr + 16 * i + g + 4 * r, col = 32 * wc + 16 * j + q;
+                if (row < N && col < N) {
+                    double v = alpha * acc[i][j][r];
+                    if (D != nullptr) v += beta * D[(size_t)row * N + col];
+                    C[(size_t)row * N + col] = v;
+                }
+            }
+}
+
+struct GpChainArgs {
+    const double *iK, *W, *HiK, *H, *iH, *m, *P1, *u;
+    double *T1, *Bm, *grad_m, *grad_H, *tmp, *HiKW, *Rs, *T1b, *G;
+    double lr, c, g_alpha, g_beta;
+    int N;
+};
+__global__ __launch_bounds__(1024) void k_gp_chain(GpChainArgs a) {
+    __shared__ double ms[GP_MMAX], ps[GP_MMAX];
+    const int l = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t o = (size_t)l * N * N, ov = (size_t)l * N;
+    if (blockIdx.y == 0) {                                        // ---- chain X
+        gp_mm_wg(a.iK + o, a.W + o, nullptr, a.T1 + o, N, 1.0, 0.0, wave, lane);
+        if (tid < N) { ms[tid] = a.m[ov + tid]; ps[tid] = a.P1[ov + tid]; }
+        __syncthreads();                                          // T1 complete (stores acknowledged), visible to the workgroup
+        gp_mm_wg(a.T1 + o, a.iK + o, a.iK + o, a.Bm + o, N, 1.0, 1.0, wave, lane);
+        __syncthreads();
+        const int sub = tid & 7;                                  // k_gp_natgrad: eight lanes per matrix row
+        for (int i = tid >> 3; i < N; i += 128) {
+            double bm = 0.0, kp = 0.0, hm = 0.0;
+            for (int j = sub; j < N; j += 8) {
+                bm += a.Bm[o + (size_t)i * N + j] * ms[j];
+                kp += a.iK[o + (size_t)i * N + j] * ps[j];
+                hm += a.iH[o + (size_t)i * N + j] * ms[j];
+            }
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) {
+                bm += __shfl_xor(bm, off, 64);
+                kp += __shfl_xor(kp, off, 64);
+                hm += __shfl_xor(hm, off, 64);
+            }
+            if (sub == 0) {
+                const double gm = bm - kp, ghm = 0.5 * (bm - hm);
+                a.grad_m[ov + i] = gm;
+                a.tmp[ov + i] = hm - a.lr * (gm - 2.0 * ghm);
+            }
+        }
+        for (int e = tid; e < N * N; e += 1024) a.grad_H[o + e] = 0.5 * (a.Bm[o + e] - a.iH[o + e]);       // k_gp_natgrad_h
+    } else {                                                      // ---- chain Z
+        gp_mm_wg(a.HiK + o, a.W + o, nullptr, a.HiKW + o, N, 1.0, 0.0, wave, lane);
+        __syncthreads();
+        for (int e = tid; e < N * N; e += 1024) {                 // k_gp_rsym
+            const int i = e / N, j = e - i * N;
+            const double ui = a.u[ov + i], uj = a.u[ov + j], mi = a.m[ov + i], mj = a.m[ov + j];
+            a.Rs[o + e] = a.c * (ui * mj + mi * uj - a.W[o + e] + a.HiKW[o + e] + a.HiKW[o + (size_t)j * N + i]) + a.H[o + e] + mi * mj;
+        }
+        __syncthreads();
+        gp_mm_wg(a.iK + o, a.Rs + o, nullptr, a.T1b + o, N, 1.0, 0.0, wave, lane);
+        __syncthreads();
+        gp_mm_wg(a.T1b + o, a.iK + o, a.iK + o, a.G + o, N, a.g_alpha, a.g_beta, wave, lane);
+    }
+}
+
 // out[l][m] = sum_b A[l][b][m] x[l][b]: the two matrix^T-vector products of the bound (Kxz^T v, V^T mu).  As batched GEMMs with
 // one column the library reads the 15.7 MB operand at 0.5 TB/s (32 us each).  One workgroup per (latent, row chunk) streams its
 // part of the slab: thread = (column m, one of 1024 / 128 row groups), partials folded through LDS.  With ONE workgroup per
@@ -1354,6 +1471,21 @@ int hlvae_gp_rsym(const double* u, const double* m, const double* W, const doubl
     const int n = batch * N * N;
     HL_PROF("gp_rsym", (hipStream_t)s);
     k_gp_rsym<<<(n + 255) / 256, 256, 0, (hipStream_t)s>>>(u, m, W, X, H, c, N, n, out);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_chain(const double* iK, const double* W, const double* HiK, const double* H, const double* iH, const double* m,
+                   const double* P1, const double* u, double lr, double c, double g_alpha, double g_beta, int N, int batch,
+                   double* T1, double* Bm, double* grad_m, double* grad_H, double* tmp, double* HiKW, double* Rs, double* T1b,
+                   double* G, hlvae_stream s) {
+    HL_REQUIRE(iK && W && HiK && H && iH && m && P1 && u && T1 && Bm && grad_m && grad_H && tmp && HiKW && Rs && T1b && G, HLVAE_EINVAL,
+               "gp_chain: null argument");
+    HL_REQUIRE(N >= 4 && N <= GP_MMAX && N % 4 == 0 && batch >= 1, HLVAE_ESHAPE, "gp_chain: N=%d (a multiple of 4, at most %d)", N, GP_MMAX);
+    HL_REQUIRE(T1 != T1b && T1 != Bm && HiKW != Rs, HLVAE_EINVAL, "gp_chain: the intermediates must be distinct buffers");
+    GpChainArgs a{iK, W, HiK, H, iH, m, P1, u, T1, Bm, grad_m, grad_H, tmp, HiKW, Rs, T1b, G, lr, c, g_alpha, g_beta, N};
+    HL_PROF("gp_chain", (hipStream_t)s);
+    k_gp_chain<<<dim3(batch, 2), 1024, 0, (hipStream_t)s>>>(a);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -326,6 +326,7 @@ class GPPriorHIP:
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         self._prep, self._prep_stream, self._tail_pending = None, None, False
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
+        self._chain = _os.environ.get("HL_GP_CHAIN", "1") != "0"          # the M x M algebra behind W as one launch (k_gp_chain)
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
             for t in (self._theta, self.m, self._KH):
@@ -623,31 +624,42 @@ class GPPriorHIP:
                        "gp_bound")
             if self.dp is not None:
                 self.dp.allreduce_(self._xchg)                               # W, P1, u, bound of the GLOBAL batch
-            evW = torch.cuda.Event()
-            evW.record(sA)                                                   # W, P1, u of the global batch are final
-            # natural-gradient terms (elbo_functions.py:279-283)
-            T1 = self._bmm_into(iK, W, mm["T1"])
-            Bm = self._bmm_into(T1, iK, mm["Bm"], D=iK)                      # iK W iK + iK
             self._grad_m, self._grad_H, self._tmp = mm["grad_m"], mm["grad_H"], mm["tmp"]
-            _lib.check(lib.hlvae_gp_natgrad(_lib.ptr(Bm), _lib.ptr(iK), _lib.ptr(iH), _lib.ptr(self.m), _lib.ptr(P1),
-                                            _C.c_double(self.ng_lr), M, L, _lib.ptr(self._grad_m), _lib.ptr(self._grad_H),
-                                            _lib.ptr(self._tmp), st), "gp_natgrad")
-        # K0zz's gradient needs W but none of the natural-gradient products: it goes BEHIND chain C (round 3; both were one
-        # serial chain of ten launches on sA that ended 115 us after chain C -- HL_GP_SPLIT=0 restores that order)
-        with torch.cuda.stream(sC if self._split_kzz else sA):
-            st = self._stream()
-            if self._split_kzz:
-                sC.wait_event(evW)
-            HiKW = self._bmm_into(HiK, W, mm["HiKW"])
-            # R + R^T with R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T): K0zz's gradient is needed symmetrised.
-            # It is built from global sums only, i.e. replicated: each rank contributes 1 / world of it
-            Rs = mm["Rs"]
-            _lib.check(lib.hlvae_gp_rsym(_lib.ptr(u), _lib.ptr(self.m), _lib.ptr(W), _lib.ptr(HiKW), _lib.ptr(self.H), _C.c_double(c), M, L,
-                                         _lib.ptr(Rs), st), "gp_rsym")
-            T1b = self._bmm_into(iK, Rs, mm["T1b"])
-            G_Kzz_s = self._bmm_into(T1b, iK, mm["G_Kzz"], D=iK, alpha=-1.0 / world, beta=1.0 / world)   # (G + G^T), G = -(iK R iK) + iK / 2
-            _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
-                                               _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
+            Rs, G_Kzz_s = mm["Rs"], mm["G_Kzz"]
+            if self._chain and M % 4 == 0:
+                # the M x M algebra behind W as ONE launch (csrc/gp.hip k_gp_chain, round 3): natural-gradient terms
+                # (elbo_functions.py:279-283) and the symmetrised K0zz gradient (G + G^T), G = -(iK R iK) + iK / 2,
+                # R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T) -- built from global sums only, i.e. replicated:
+                # each rank contributes 1 / world of it
+                _lib.check(lib.hlvae_gp_chain(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(HiK), _lib.ptr(self.H), _lib.ptr(iH), _lib.ptr(self.m),
+                                              _lib.ptr(P1), _lib.ptr(u), _C.c_double(self.ng_lr), _C.c_double(c),
+                                              _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(mm["T1"]),
+                                              _lib.ptr(mm["Bm"]), _lib.ptr(self._grad_m), _lib.ptr(self._grad_H), _lib.ptr(self._tmp),
+                                              _lib.ptr(mm["HiKW"]), _lib.ptr(Rs), _lib.ptr(mm["T1b"]), _lib.ptr(G_Kzz_s), st), "gp_chain")
+                _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
+                                                   _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
+            else:
+                evW = torch.cuda.Event()
+                evW.record(sA)                                               # W, P1, u of the global batch are final
+                T1 = self._bmm_into(iK, W, mm["T1"])
+                Bm = self._bmm_into(T1, iK, mm["Bm"], D=iK)                  # iK W iK + iK
+                _lib.check(lib.hlvae_gp_natgrad(_lib.ptr(Bm), _lib.ptr(iK), _lib.ptr(iH), _lib.ptr(self.m), _lib.ptr(P1),
+                                                _C.c_double(self.ng_lr), M, L, _lib.ptr(self._grad_m), _lib.ptr(self._grad_H),
+                                                _lib.ptr(self._tmp), st), "gp_natgrad")
+        if not (self._chain and M % 4 == 0):
+            # separate launches (HL_GP_CHAIN=0): K0zz's gradient needs W but none of the natural-gradient products; it goes BEHIND
+            # chain C (HL_GP_SPLIT=0: behind the natural-gradient launches on chain A, the round-2 order)
+            with torch.cuda.stream(sC if self._split_kzz else sA):
+                st = self._stream()
+                if self._split_kzz:
+                    sC.wait_event(evW)
+                HiKW = self._bmm_into(HiK, W, mm["HiKW"])
+                _lib.check(lib.hlvae_gp_rsym(_lib.ptr(u), _lib.ptr(self.m), _lib.ptr(W), _lib.ptr(HiKW), _lib.ptr(self.H), _C.c_double(c), M, L,
+                                             _lib.ptr(Rs), st), "gp_rsym")
+                T1b = self._bmm_into(iK, Rs, mm["T1b"])
+                self._bmm_into(T1b, iK, G_Kzz_s, D=iK, alpha=-1.0 / world, beta=1.0 / world)
+                _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
+                                                   _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
         self._pending = True
         if join:
             self.join()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 32
+#define HLVAE_ABI_VERSION 33
 #define HLVAE_STAT_CHUNKS 16
 /* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
 #define HLVAE_HEAD_ACC 95
@@ -424,6 +424,16 @@ int hlvae_gp_gkxz(const double* Y, const double* v, const double* w, double c, i
  * symmetrised gradient term of K0zz in one pass */
 int hlvae_gp_rsym(const double* u, const double* m, const double* W, const double* X, const double* H, double c, int N, int batch,
                   double* out, hlvae_stream s);
+/* The N x N algebra of a GP-prior step behind W (reference elbo_functions.py:279-283: natural-gradient terms; the gradient of the
+ * bound w.r.t. K0zz) as ONE launch, two independent chains per latent (N % 4 == 0, N <= 128; all matrices [batch][N][N], vectors
+ * [batch][N]; the intermediates T1, Bm, HiKW, Rs, T1b are distinct caller buffers):
+ *   T1 = iK W;  Bm = T1 iK + iK;  grad_m = Bm m - iK P1;  grad_H = (Bm - iH) / 2;  tmp = iH m - lr (grad_m - 2 grad_H m)
+ *   HiKW = HiK W;  Rs = c (u m^T + m u^T - W + HiKW + HiKW^T) + H + m m^T;  T1b = iK Rs;  G = g_alpha (T1b iK) + g_beta iK
+ * replaces hlvae_gp_bmm x 5, hlvae_gp_natgrad and hlvae_gp_rsym on that path (same arithmetic, fp64 matrix cores). */
+int hlvae_gp_chain(const double* iK, const double* W, const double* HiK, const double* H, const double* iH, const double* m,
+                   const double* P1, const double* u, double lr, double c, double g_alpha, double g_beta, int N, int batch,
+                   double* T1, double* Bm, double* grad_m, double* grad_H, double* tmp, double* HiKW, double* Rs, double* T1b,
+                   double* G, hlvae_stream s);
 /* torch.optim.Adam step (HLVAE_main.py:277-278) on a flat fp64 arena (hyper-parameters + inducing points, n <= ~1e5);
  * step: device int64[2] = {completed steps, 0}, advanced by the kernel; the consumed gradients are zeroed. */
 int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,
