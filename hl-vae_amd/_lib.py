@@ -117,7 +117,7 @@ _SIGS = {
                                        _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp,
                                        _vp]),
     "hlvae_gp_param_grad": (C.c_int, [C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp,
-                                      C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+                                      C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp]),
     "hlvae_gp_transform": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_spd_inv2": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "hlvae_gp_gemm": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, C.c_int64, _vp, C.c_int, C.c_int64, _vp, C.c_int,

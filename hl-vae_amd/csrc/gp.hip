@@ -625,7 +625,10 @@ __global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const 
                                                        int Q, const double* __restrict__ x1, int n1, int per_latent1,
                                                        const double* __restrict__ x2, int n2, int both_args,
                                                        const double* __restrict__ G, double* __restrict__ gprm,
-                                                       double* __restrict__ gx2) {
+                                                       double* __restrict__ gx2, const double* __restrict__ vrow,
+                                                       const double* __restrict__ wcol, double cg) {
+    // vrow != nullptr: G holds Y = V (iK - Q) and the gradient w.r.t. K0xz is formed here, g = cg (v_i w_j - Y_ij) (what
+    // k_gp_gkxz wrote out as a 31 MB matrix for this kernel to read back: one launch and 62 MB less on chain C)
     constexpr int RPL = ROWS / 4;                                 // rows per lane
     __shared__ double gacc[32];
     __shared__ double xs[ROWS * GP_XS], xbs[64 * GP_XS];
@@ -640,6 +643,11 @@ __global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const 
     for (int r = 0; r < RPL; ++r) {                               // all gradient loads of this lane in flight before anything else
         const int i = min(i_lo + r, nrow - 1);
         gv[r] = G[((size_t)l * n1 + row0 + i) * n2 + jc];
+    }
+    if (vrow != nullptr) {
+        const double wj = wcol[(size_t)l * n2 + jc];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) gv[r] = cg * (vrow[(size_t)l * n1 + row0 + min(i_lo + r, nrow - 1)] * wj - gv[r]);
     }
     if (tid < 32) gacc[tid] = 0.0;
     for (int e = tid; e < nrow * Q; e += 256)
@@ -1072,56 +1080,75 @@ __global__ __launch_bounds__(256) void k_gp_rsym(const double* __restrict__ u, c
 //     Z:  HiKW = (H iK) W  ->  Rs = R + R^T  ->  T1b = iK Rs  ->  G = a (T1b iK) + b iK    (k_gp_rsym)
 // As 5 k_gp_bmm + 3 element-wise launches on one stream they were the tail of the GP step's longest chain: every launch is 512
 // workgroups x 61 KB of LDS that cannot share a CU with the VAE's optimiser launches running beside them (4 x 40 KB), and took
-// 60-85 us instead of 12.  Here one workgroup of 1024 threads per (latent, chain) walks its chain: 64 workgroups, no LDS for the
-// products -- a wave owns a 32 x 32 block of the output and reads its fragments of both operands straight from L2 (the whole
+// 60-85 us instead of 12.  Here one workgroup of 512 threads per (latent, chain) walks its chain: 64 workgroups, no LDS for the
+// products -- a wave owns a 32 x 64 block of the output and reads its fragments of both operands straight from L2 (the whole
 // working set of a latent is < 1 MB) -- so nothing it needs can be taken away by a co-running launch.
 // Fragments of v_mfma_f64_16x16x4_f64 over a block of 16 k: step s of the block uses k = kb + 4 (lane >> 4) + s on BOTH sides,
 // so a lane's four A values are 32 contiguous bytes of its row (two 16-byte loads, every 128-byte row segment used whole) and
 // its B values four loads of 128-byte row segments.  N % 4 == 0.
+#define GP_CHAIN_THREADS 512
 __device__ __forceinline__ void gp_mm_wg(const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ D,
                                          double* __restrict__ C, int N, double alpha, double beta, int wave, int lane) {
-    const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, q = lane & 15;
-    f64x4_t acc[2][2];
+    // 8 waves: wave (wr, wc) owns rows 32 wr .. + 31, columns 64 wc .. + 63 of the 128 x 128 padded output: 2 x 4 fragments
+    const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, q = lane & 15;
+    f64x4_t acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
-    const int row0 = 32 * wr + q, col0 = 32 * wc + q;
-    const bool rok[2] = {row0 < N, row0 + 16 < N}, cok[2] = {col0 < N, col0 + 16 < N};
-    const double* ap[2] = {A + (size_t)min(row0, N - 1) * N, A + (size_t)min(row0 + 16, N - 1) * N};
-    const double* bp[2] = {B + min(col0, N - 1), B + min(col0 + 16, N - 1)};
-    for (int kb = 0; kb < N; kb += 16) {
+        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const int row0 = 32 * wr + q, col0 = 64 * wc + q;
+    bool rok[2], cok[4];
+    const double *ap[2], *bp[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { rok[i] = row0 + 16 * i < N; ap[i] = A + (size_t)min(row0 + 16 * i, N - 1) * N; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cok[j] = col0 + 16 * j < N; bp[j] = B + min(col0 + 16 * j, N - 1); }
+    // operands of block kb + 16 are requested before the 32 MFMAs of block kb (two register sets): a wave's loads ride under
+    // its own products as well as under the other wave of its SIMD
+    auto load = [&](int kb, f64x4_t (&a)[2], double (&b)[4][4]) {
         const int k0 = kb + 4 * g;
         const bool kok = k0 < N;                                   // (N % 4 == 0: the lane's four k are in or out together)
         const int kc = kok ? k0 : 0;
-        f64x4_t a[2];
-        double b[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f64x4_t*>(ap[i] + kc);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) b[j][s_] = bp[j][(size_t)(kc + s_) * N];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (!(kok && rok[i])) a[i] = f64x4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
             if (!(kok && cok[j])) { b[j][0] = b[j][1] = b[j][2] = b[j][3] = 0.0; }
+    };
+    auto mma = [&](const f64x4_t (&a)[2], const double (&b)[4][4]) {
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][s_], b[j][s_], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][s_], b[j][s_], acc[i][j], 0, 0, 0);
+    };
+    f64x4_t a0[2], a1[2];
+    double b0[4][4], b1[4][4];
+    load(0, a0, b0);
+    for (int kb = 0; kb < N; kb += 32) {
+        const bool more = kb + 16 < N;
+        if (more) load(kb + 16, a1, b1);
+        mma(a0, b0);
+        if (more) {
+            if (kb + 32 < N) load(kb + 32, a0, b0);
+            mma(a1, b1);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 32 * wr + 16 * i + g + 4 * r, col = 32 * wc + 16 * j + q;
+                const int row = 32 * wr + 16 * i + g + 4 * r, col = 64 * wc + 16 * j + q;
                 if (row < N && col < N) {
                     double v = alpha * acc[i][j][r];
                     if (D != nullptr) v += beta * D[(size_t)row * N + col];
@@ -1136,7 +1163,7 @@ struct GpChainArgs {
     double lr, c, g_alpha, g_beta;
     int N;
 };
-__global__ __launch_bounds__(1024) void k_gp_chain(GpChainArgs a) {
+__global__ __launch_bounds__(GP_CHAIN_THREADS) void k_gp_chain(GpChainArgs a) {
     __shared__ double ms[GP_MMAX], ps[GP_MMAX];
     const int l = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t o = (size_t)l * N * N, ov = (size_t)l * N;
@@ -1147,7 +1174,7 @@ __global__ __launch_bounds__(1024) void k_gp_chain(GpChainArgs a) {
         gp_mm_wg(a.T1 + o, a.iK + o, a.iK + o, a.Bm + o, N, 1.0, 1.0, wave, lane);
         __syncthreads();
         const int sub = tid & 7;                                  // k_gp_natgrad: eight lanes per matrix row
-        for (int i = tid >> 3; i < N; i += 128) {
+        for (int i = tid >> 3; i < N; i += GP_CHAIN_THREADS / 8) {
             double bm = 0.0, kp = 0.0, hm = 0.0;
             for (int j = sub; j < N; j += 8) {
                 bm += a.Bm[o + (size_t)i * N + j] * ms[j];
@@ -1166,11 +1193,11 @@ __global__ __launch_bounds__(1024) void k_gp_chain(GpChainArgs a) {
                 a.tmp[ov + i] = hm - a.lr * (gm - 2.0 * ghm);
             }
         }
-        for (int e = tid; e < N * N; e += 1024) a.grad_H[o + e] = 0.5 * (a.Bm[o + e] - a.iH[o + e]);       // k_gp_natgrad_h
+        for (int e = tid; e < N * N; e += GP_CHAIN_THREADS) a.grad_H[o + e] = 0.5 * (a.Bm[o + e] - a.iH[o + e]);       // k_gp_natgrad_h
     } else {                                                      // ---- chain Z
         gp_mm_wg(a.HiK + o, a.W + o, nullptr, a.HiKW + o, N, 1.0, 0.0, wave, lane);
         __syncthreads();
-        for (int e = tid; e < N * N; e += 1024) {                 // k_gp_rsym
+        for (int e = tid; e < N * N; e += GP_CHAIN_THREADS) {                 // k_gp_rsym
             const int i = e / N, j = e - i * N;
             const double ui = a.u[ov + i], uj = a.u[ov + j], mi = a.m[ov + i], mj = a.m[ov + j];
             a.Rs[o + e] = a.c * (ui * mj + mi * uj - a.W[o + e] + a.HiKW[o + e] + a.HiKW[o + (size_t)j * N + i]) + a.H[o + e] + mi * mj;
@@ -1411,16 +1438,17 @@ int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, c
 
 int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots, int L, int Q, const double* x1, int n1,
                         int per_latent1, const double* x2, int n2, int both_args, const double* G, double* gprm, double* gx2,
-                        hlvae_stream s) {
+                        const double* v, const double* w, double c, hlvae_stream s) {
     if (int rc = gp_check_kernel(k, n_slots, Q)) return rc;
     HL_REQUIRE(!both_args || n1 == n2, HLVAE_ESHAPE, "gp_param_grad: both_args needs a square matrix");
+    HL_REQUIRE((v == nullptr) == (w == nullptr), HLVAE_EINVAL, "gp_param_grad: v and w both or none");
     HL_PROF("gp_param_grad", (hipStream_t)s);
     const bool small = gp_kernel_small(k);
     // rows per workgroup: 64 (a lane walks 16) when that still fills the machine, else 16 (K0zz: 128 -> 512 workgroups)
     const bool tall = (long)((n2 + 63) / 64) * ((n1 + 63) / 64) * L >= 512;
 #define GP_PG(NTv, NRv, ROWSv)                                                                                             \
     k_gp_param_grad<NTv, NRv, ROWSv><<<dim3((n2 + 63) / 64, (n1 + ROWSv - 1) / ROWSv, L), 256, 0, (hipStream_t)s>>>(        \
-        *k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2, both_args, G, gprm, gx2)
+        *k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2, both_args, G, gprm, gx2, v, w, c)
     if (small) { if (tall) GP_PG(4, 1, 64); else GP_PG(4, 1, 16); }
     else { if (tall) GP_PG(HLVAE_GP_MAX_TERMS, GP_MAX_RBF, 32); else GP_PG(HLVAE_GP_MAX_TERMS, GP_MAX_RBF, 16); }   // (64 rows: 256 VGPRs)
 #undef GP_PG
@@ -1485,7 +1513,7 @@ int hlvae_gp_chain(const double* iK, const double* W, const double* HiK, const d
     HL_REQUIRE(T1 != T1b && T1 != Bm && HiKW != Rs, HLVAE_EINVAL, "gp_chain: the intermediates must be distinct buffers");
     GpChainArgs a{iK, W, HiK, H, iH, m, P1, u, T1, Bm, grad_m, grad_H, tmp, HiKW, Rs, T1b, G, lr, c, g_alpha, g_beta, N};
     HL_PROF("gp_chain", (hipStream_t)s);
-    k_gp_chain<<<dim3(batch, 2), 1024, 0, (hipStream_t)s>>>(a);
+    k_gp_chain<<<dim3(batch, 2), GP_CHAIN_THREADS, 0, (hipStream_t)s>>>(a);
     HL_LAUNCH_CHECK();
     return 0;
 }

@@ -326,6 +326,7 @@ class GPPriorHIP:
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         self._prep, self._prep_stream, self._tail_pending = None, None, False
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
+        self._balance = _os.environ.get("HL_GP_BALANCE", "1") != "0"      # chain rule through K0xz on chain A (kl_and_grads)
         self._chain = _os.environ.get("HL_GP_CHAIN", "1") != "0"          # the M x M algebra behind W as one launch (k_gp_chain)
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
@@ -601,13 +602,21 @@ class GPPriorHIP:
         sC.wait_stream(main)
         world = 1 if self.dp is None else self.dp.world
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
+        balance = self._balance and self._chain and M % 4 == 0
         with torch.cuda.stream(sC):      # chain C: gradient w.r.t. K0xz and the subject blocks
             st = self._stream()
             Y = self._gemm(V, False, N1, buf["Y"], B, M, M)                  # V (iK - Q)   [L,B,M]  (local rows)
-            G_Kxz = buf["G_Kxz"]                                             # c [ v (iK m)^T + V (Q - iK) ]
-            _lib.check(lib.hlvae_gp_gkxz(_lib.ptr(Y), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), L, B, M, _lib.ptr(G_Kxz), st), "gp_gkxz")
-            _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
-                                               _lib.ptr(G_Kxz), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kxz)")
+            if balance:
+                # round 3: with the M x M algebra in one launch chain A is the short one -- the chain rule through K0xz moves over
+                # there (it forms G_Kxz = c [ v (iK m)^T - Y ] on the fly: no k_gp_gkxz launch, no 31 MB matrix written and read back)
+                evY = torch.cuda.Event()
+                evY.record(sC)
+            else:
+                G_Kxz = buf["G_Kxz"]                                         # c [ v (iK m)^T + V (Q - iK) ]
+                _lib.check(lib.hlvae_gp_gkxz(_lib.ptr(Y), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), L, B, M, _lib.ptr(G_Kxz), st), "gp_gkxz")
+                _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
+                                                   _lib.ptr(G_Kxz), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
+                           "gp_param_grad(Kxz)")
             _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
                                                 S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y),
                                                 _lib.ptr(log_v), _C.c_double(c), _lib.ptr(gprm), st), "gp_subject_bwd")
@@ -637,7 +646,13 @@ class GPPriorHIP:
                                               _lib.ptr(mm["Bm"]), _lib.ptr(self._grad_m), _lib.ptr(self._grad_H), _lib.ptr(self._tmp),
                                               _lib.ptr(mm["HiKW"]), _lib.ptr(Rs), _lib.ptr(mm["T1b"]), _lib.ptr(G_Kzz_s), st), "gp_chain")
                 _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
-                                                   _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
+                                                   _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
+                           "gp_param_grad(Kzz)")
+                if balance:
+                    sA.wait_event(evY)
+                    _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
+                                                       _lib.ptr(Y), _lib.ptr(gprm), _lib.ptr(gz), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), st),
+                               "gp_param_grad(Kxz)")
             else:
                 evW = torch.cuda.Event()
                 evW.record(sA)                                               # W, P1, u of the global batch are final
@@ -659,7 +674,8 @@ class GPPriorHIP:
                 T1b = self._bmm_into(iK, Rs, mm["T1b"])
                 self._bmm_into(T1b, iK, G_Kzz_s, D=iK, alpha=-1.0 / world, beta=1.0 / world)
                 _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
-                                                   _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), st), "gp_param_grad(Kzz)")
+                                                   _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
+                           "gp_param_grad(Kzz)")
         self._pending = True
         if join:
             self.join()

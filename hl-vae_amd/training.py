@@ -275,7 +275,7 @@ class ELBOTrainer:
         if self.kl == "gp":
             if hasattr(self.gp, "prepare") and os.environ.get("HL_GP_PREPARE", "1") != "0":
                 # the prior's state-only launches (and the covariate gather) run on a stream of its own under the VAE's forward pass
-                train_x = self.gp.prepare(ds.labels, rows, groups=groups, ahead=prepacked and self._gp_ahead())
+                train_x = self.gp.prepare(ds.labels, rows, groups=groups, ahead=prepacked and self._gp_ahead() and not self._gp_defer)
             else:
                 train_x = ds.labels.index_select(0, rows.long())
         self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None,
@@ -411,7 +411,8 @@ class ELBOTrainer:
         m._fwd_token += 1
         m._grad_region_clean = True
         if self.kl == "gp":
-            nb = {"next_batch": (feed_next[0].labels, feed_next[1])} if (feed_next is not None and self._gp_ahead()) else {}
+            # (not together with the deferred state update, an experiment that stays off: HL_GP_DEFER)
+            nb = {"next_batch": (feed_next[0].labels, feed_next[1])} if (feed_next is not None and self._gp_ahead() and not self._gp_defer) else {}
             if self._gp_defer and hasattr(self.gp, "join_tail"):
                 self.gp.optimizer_step(defer=True, **nb)      # (inside a captured chain: the state update runs beside the next step's forward pass)
             else:

@@ -372,10 +372,12 @@ int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, c
                          hlvae_stream s);
 /* chain rule from G [L][n1][n2] = dL/dK(x1_i, x2_j) into gprm [n_slots][L] and gx2 [L][n2][Q] (points of the second
  * argument, always per latent).  both_args != 0: x1 == x2 (K0zz) and G must arrive symmetrised (G + G^T): the points
- * sit in both argument positions. */
+ * sit in both argument positions.
+ * v, w != NULL (v [L][n1], w [L][n2]): G holds Y and the gradient is formed on the fly, G_ij := c (v_i w_j - Y_ij)
+ * (the gradient of the bound w.r.t. K0xz, what hlvae_gp_gkxz writes out as a matrix). */
 int hlvae_gp_param_grad(const hlvae_gp_kernel* k, const double* hyp, int n_slots, int L, int Q, const double* x1, int n1,
                         int per_latent1, const double* x2, int n2, int both_args, const double* G, double* gprm, double* gx2,
-                        hlvae_stream s);
+                        const double* v, const double* w, double c, hlvae_stream s);
 /* hlvae_gp_chol_inv that also writes -logdet of the first n_neg matrices to logdet_neg[0 .. n_neg): the end-of-step inversion of
  * [iH_new | K0zz] yields [H_new | iK] and needs log det H_new = -log det iH_new (training.py:131-135) */
 int hlvae_gp_spd_inv2(const double* A, int n, int N, double* inv, double* logdet, int n_neg, double* logdet_neg, int* fail,
