@@ -1098,23 +1098,25 @@ __device__ __forceinline__ void gp_mm_wg(const double* __restrict__ A, const dou
         for (int j = 0; j < 4; ++j) acc[i][j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
     const int row0 = 32 * wr + q, col0 = 64 * wc + q;
     bool rok[2], cok[4];
-    const double *ap[2], *bp[4];
+    // 32-bit element offsets from the (uniform) operand pointers: A[offa[i] + kb], B[offb[j] + (kb + s) N] -- no 64-bit address
+    // arithmetic per load (the first form's v_mad_u64_u32 chains made hipcc drain vmcnt(0) at the top of every block)
+    unsigned offa[2], offb[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { rok[i] = row0 + 16 * i < N; ap[i] = A + (size_t)min(row0 + 16 * i, N - 1) * N; }
+    for (int i = 0; i < 2; ++i) { rok[i] = row0 + 16 * i < N; offa[i] = (unsigned)(min(row0 + 16 * i, N - 1) * N + 4 * g); }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { cok[j] = col0 + 16 * j < N; bp[j] = B + min(col0 + 16 * j, N - 1); }
+    for (int j = 0; j < 4; ++j) { cok[j] = col0 + 16 * j < N; offb[j] = (unsigned)(4 * g * N + min(col0 + 16 * j, N - 1)); }
     // operands of block kb + 16 are requested before the 32 MFMAs of block kb (two register sets): a wave's loads ride under
     // its own products as well as under the other wave of its SIMD
     auto load = [&](int kb, f64x4_t (&a)[2], double (&b)[4][4]) {
-        const int k0 = kb + 4 * g;
-        const bool kok = k0 < N;                                   // (N % 4 == 0: the lane's four k are in or out together)
-        const int kc = kok ? k0 : 0;
+        const bool kok = kb + 4 * g < N;                           // (N % 4 == 0: the lane's four k are in or out together)
+        const double* Ak = A + kb;                                 // (uniform)
+        const double* Bk = B + (size_t)kb * N;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f64x4_t*>(ap[i] + kc);
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f64x4_t*>(Ak + (kok ? offa[i] : 0u));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) b[j][s_] = bp[j][(size_t)(kc + s_) * N];
+            for (int s_ = 0; s_ < 4; ++s_) b[j][s_] = Bk[(kok ? offb[j] : 0u) + (unsigned)(s_ * N)];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (!(kok && rok[i])) a[i] = f64x4_t{0.0, 0.0, 0.0, 0.0};
