@@ -1086,54 +1086,55 @@ __global__ __launch_bounds__(256) void k_gp_rsym(const double* __restrict__ u, c
 // Fragments of v_mfma_f64_16x16x4_f64 over a block of 16 k: step s of the block uses k = kb + 4 (lane >> 4) + s on BOTH sides,
 // so a lane's four A values are 32 contiguous bytes of its row (two 16-byte loads, every 128-byte row segment used whole) and
 // its B values four loads of 128-byte row segments.  N % 4 == 0.
-#define GP_CHAIN_THREADS 512
+template <int FJ>   // 16-column fragments per wave: 4 (8 waves, 32 x 64 blocks) or 2 (16 waves, 32 x 32 blocks)
 __device__ __forceinline__ void gp_mm_wg(const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ D,
                                          double* __restrict__ C, int N, double alpha, double beta, int wave, int lane) {
-    // 8 waves: wave (wr, wc) owns rows 32 wr .. + 31, columns 64 wc .. + 63 of the 128 x 128 padded output: 2 x 4 fragments
-    const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, q = lane & 15;
-    f64x4_t acc[2][4];
+    // wave (wr, wc) owns rows 32 wr .. + 31, columns 16 FJ wc .. of the 128 x 128 padded output: 2 x FJ fragments
+    constexpr int NWC = 8 / FJ;
+    const int wr = wave / NWC, wc = wave % NWC, g = lane >> 4, q = lane & 15;
+    f64x4_t acc[2][FJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
-    const int row0 = 32 * wr + q, col0 = 64 * wc + q;
-    bool rok[2], cok[4];
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+    const int row0 = 32 * wr + q, col0 = 16 * FJ * wc + q;
+    bool rok[2], cok[FJ];
     // 32-bit element offsets from the (uniform) operand pointers: A[offa[i] + kb], B[offb[j] + (kb + s) N] -- no 64-bit address
     // arithmetic per load (the first form's v_mad_u64_u32 chains made hipcc drain vmcnt(0) at the top of every block)
-    unsigned offa[2], offb[4];
+    unsigned offa[2], offb[FJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { rok[i] = row0 + 16 * i < N; offa[i] = (unsigned)(min(row0 + 16 * i, N - 1) * N + 4 * g); }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { cok[j] = col0 + 16 * j < N; offb[j] = (unsigned)(4 * g * N + min(col0 + 16 * j, N - 1)); }
+    for (int j = 0; j < FJ; ++j) { cok[j] = col0 + 16 * j < N; offb[j] = (unsigned)(4 * g * N + min(col0 + 16 * j, N - 1)); }
     // operands of block kb + 16 are requested before the 32 MFMAs of block kb (two register sets): a wave's loads ride under
     // its own products as well as under the other wave of its SIMD
-    auto load = [&](int kb, f64x4_t (&a)[2], double (&b)[4][4]) {
+    auto load = [&](int kb, f64x4_t (&a)[2], double (&b)[FJ][4]) {
         const bool kok = kb + 4 * g < N;                           // (N % 4 == 0: the lane's four k are in or out together)
         const double* Ak = A + kb;                                 // (uniform)
         const double* Bk = B + (size_t)kb * N;
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f64x4_t*>(Ak + (kok ? offa[i] : 0u));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < FJ; ++j)
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) b[j][s_] = Bk[(kok ? offb[j] : 0u) + (unsigned)(s_ * N)];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (!(kok && rok[i])) a[i] = f64x4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < FJ; ++j)
             if (!(kok && cok[j])) { b[j][0] = b[j][1] = b[j][2] = b[j][3] = 0.0; }
     };
-    auto mma = [&](const f64x4_t (&a)[2], const double (&b)[4][4]) {
+    auto mma = [&](const f64x4_t (&a)[2], const double (&b)[FJ][4]) {
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][s_], b[j][s_], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][s_], b[j][s_], acc[i][j], 0, 0, 0);
     };
     f64x4_t a0[2], a1[2];
-    double b0[4][4], b1[4][4];
+    double b0[FJ][4], b1[FJ][4];
     load(0, a0, b0);
     for (int kb = 0; kb < N; kb += 32) {
         const bool more = kb + 16 < N;
@@ -1147,10 +1148,10 @@ __device__ __forceinline__ void gp_mm_wg(const double* __restrict__ A, const dou
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < FJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 32 * wr + 16 * i + g + 4 * r, col = 64 * wc + 16 * j + q;
+                const int row = 32 * wr + 16 * i + g + 4 * r, col = 16 * FJ * wc + 16 * j + q;
                 if (row < N && col < N) {
                     double v = alpha * acc[i][j][r];
                     if (D != nullptr) v += beta * D[(size_t)row * N + col];
@@ -1165,18 +1166,20 @@ struct GpChainArgs {
     double lr, c, g_alpha, g_beta;
     int N;
 };
-__global__ __launch_bounds__(GP_CHAIN_THREADS) void k_gp_chain(GpChainArgs a) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_gp_chain(GpChainArgs a) {
+    constexpr int FJ = THREADS == 512 ? 4 : 2;
     __shared__ double ms[GP_MMAX], ps[GP_MMAX];
     const int l = blockIdx.x, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t o = (size_t)l * N * N, ov = (size_t)l * N;
     if (blockIdx.y == 0) {                                        // ---- chain X
-        gp_mm_wg(a.iK + o, a.W + o, nullptr, a.T1 + o, N, 1.0, 0.0, wave, lane);
+        gp_mm_wg<FJ>(a.iK + o, a.W + o, nullptr, a.T1 + o, N, 1.0, 0.0, wave, lane);
         if (tid < N) { ms[tid] = a.m[ov + tid]; ps[tid] = a.P1[ov + tid]; }
         __syncthreads();                                          // T1 complete (stores acknowledged), visible to the workgroup
-        gp_mm_wg(a.T1 + o, a.iK + o, a.iK + o, a.Bm + o, N, 1.0, 1.0, wave, lane);
+        gp_mm_wg<FJ>(a.T1 + o, a.iK + o, a.iK + o, a.Bm + o, N, 1.0, 1.0, wave, lane);
         __syncthreads();
         const int sub = tid & 7;                                  // k_gp_natgrad: eight lanes per matrix row
-        for (int i = tid >> 3; i < N; i += GP_CHAIN_THREADS / 8) {
+        for (int i = tid >> 3; i < N; i += THREADS / 8) {
             double bm = 0.0, kp = 0.0, hm = 0.0;
             for (int j = sub; j < N; j += 8) {
                 bm += a.Bm[o + (size_t)i * N + j] * ms[j];
@@ -1195,19 +1198,19 @@ __global__ __launch_bounds__(GP_CHAIN_THREADS) void k_gp_chain(GpChainArgs a) {
                 a.tmp[ov + i] = hm - a.lr * (gm - 2.0 * ghm);
             }
         }
-        for (int e = tid; e < N * N; e += GP_CHAIN_THREADS) a.grad_H[o + e] = 0.5 * (a.Bm[o + e] - a.iH[o + e]);       // k_gp_natgrad_h
+        for (int e = tid; e < N * N; e += THREADS) a.grad_H[o + e] = 0.5 * (a.Bm[o + e] - a.iH[o + e]);       // k_gp_natgrad_h
     } else {                                                      // ---- chain Z
-        gp_mm_wg(a.HiK + o, a.W + o, nullptr, a.HiKW + o, N, 1.0, 0.0, wave, lane);
+        gp_mm_wg<FJ>(a.HiK + o, a.W + o, nullptr, a.HiKW + o, N, 1.0, 0.0, wave, lane);
         __syncthreads();
-        for (int e = tid; e < N * N; e += GP_CHAIN_THREADS) {                 // k_gp_rsym
+        for (int e = tid; e < N * N; e += THREADS) {                 // k_gp_rsym
             const int i = e / N, j = e - i * N;
             const double ui = a.u[ov + i], uj = a.u[ov + j], mi = a.m[ov + i], mj = a.m[ov + j];
             a.Rs[o + e] = a.c * (ui * mj + mi * uj - a.W[o + e] + a.HiKW[o + e] + a.HiKW[o + (size_t)j * N + i]) + a.H[o + e] + mi * mj;
         }
         __syncthreads();
-        gp_mm_wg(a.iK + o, a.Rs + o, nullptr, a.T1b + o, N, 1.0, 0.0, wave, lane);
+        gp_mm_wg<FJ>(a.iK + o, a.Rs + o, nullptr, a.T1b + o, N, 1.0, 0.0, wave, lane);
         __syncthreads();
-        gp_mm_wg(a.T1b + o, a.iK + o, a.iK + o, a.G + o, N, a.g_alpha, a.g_beta, wave, lane);
+        gp_mm_wg<FJ>(a.T1b + o, a.iK + o, a.iK + o, a.G + o, N, a.g_alpha, a.g_beta, wave, lane);
     }
 }
 
@@ -1515,7 +1518,9 @@ int hlvae_gp_chain(const double* iK, const double* W, const double* HiK, const d
     HL_REQUIRE(T1 != T1b && T1 != Bm && HiKW != Rs, HLVAE_EINVAL, "gp_chain: the intermediates must be distinct buffers");
     GpChainArgs a{iK, W, HiK, H, iH, m, P1, u, T1, Bm, grad_m, grad_H, tmp, HiKW, Rs, T1b, G, lr, c, g_alpha, g_beta, N};
     HL_PROF("gp_chain", (hipStream_t)s);
-    k_gp_chain<<<dim3(batch, 2), GP_CHAIN_THREADS, 0, (hipStream_t)s>>>(a);
+    static const bool wide = [] { const char* e = getenv("HL_GP_CHAIN_THREADS"); return e != nullptr && e[0] == '1'; }();   // =1024: A/B
+    if (wide) k_gp_chain<1024><<<dim3(batch, 2), 1024, 0, (hipStream_t)s>>>(a);
+    else k_gp_chain<512><<<dim3(batch, 2), 512, 0, (hipStream_t)s>>>(a);
     HL_LAUNCH_CHECK();
     return 0;
 }

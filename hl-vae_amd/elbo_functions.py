@@ -326,7 +326,7 @@ class GPPriorHIP:
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         self._prep, self._prep_stream, self._tail_pending = None, None, False
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
-        self._balance = _os.environ.get("HL_GP_BALANCE", "1") != "0"      # chain rule through K0xz on chain A (kl_and_grads)
+        self._balance = int(_os.environ.get("HL_GP_BALANCE", "1"))        # where the chain rule through K0xz runs (kl_and_grads)
         self._chain = _os.environ.get("HL_GP_CHAIN", "1") != "0"          # the M x M algebra behind W as one launch (k_gp_chain)
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
@@ -602,15 +602,18 @@ class GPPriorHIP:
         sC.wait_stream(main)
         world = 1 if self.dp is None else self.dp.world
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
-        balance = self._balance and self._chain and M % 4 == 0
+        balance = self._balance if (self._chain and M % 4 == 0) else 0
         with torch.cuda.stream(sC):      # chain C: gradient w.r.t. K0xz and the subject blocks
             st = self._stream()
             Y = self._gemm(V, False, N1, buf["Y"], B, M, M)                  # V (iK - Q)   [L,B,M]  (local rows)
-            if balance:
-                # round 3: with the M x M algebra in one launch chain A is the short one -- the chain rule through K0xz moves over
-                # there (it forms G_Kxz = c [ v (iK m)^T - Y ] on the fly: no k_gp_gkxz launch, no 31 MB matrix written and read back)
+            if balance == 1:
+                # round 3: the chain rule through K0xz forms G_Kxz = c [ v (iK m)^T - Y ] on the fly (no k_gp_gkxz launch, no 31 MB
+                # matrix written and read back) and may run on chain A behind the M x M algebra (HL_GP_BALANCE=1) or here behind
+                # the per-subject kernel (=2)
                 evY = torch.cuda.Event()
                 evY.record(sC)
+            elif balance == 2:
+                pass
             else:
                 G_Kxz = buf["G_Kxz"]                                         # c [ v (iK m)^T + V (Q - iK) ]
                 _lib.check(lib.hlvae_gp_gkxz(_lib.ptr(Y), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), L, B, M, _lib.ptr(G_Kxz), st), "gp_gkxz")
@@ -620,6 +623,10 @@ class GPPriorHIP:
             _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
                                                 S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y),
                                                 _lib.ptr(log_v), _C.c_double(c), _lib.ptr(gprm), st), "gp_subject_bwd")
+            if balance == 2:
+                _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
+                                                   _lib.ptr(Y), _lib.ptr(gprm), _lib.ptr(gz), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), st),
+                           "gp_param_grad(Kxz)")
         with torch.cuda.stream(sA):      # chain A: the sums over subjects, the bound, natural gradient, gradient w.r.t. K0zz
             st = self._stream()
             self._gemm(Kxz, True, V, W, M, M, B)                             # sum_s Ks^T iB Ks = Kxz^T V   [L,M,M]
@@ -648,7 +655,7 @@ class GPPriorHIP:
                 _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
                                                    _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
                            "gp_param_grad(Kzz)")
-                if balance:
+                if balance == 1:
                     sA.wait_event(evY)
                     _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
                                                        _lib.ptr(Y), _lib.ptr(gprm), _lib.ptr(gz), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), st),
