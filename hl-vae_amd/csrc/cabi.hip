@@ -247,6 +247,7 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     p->tick_dev = nullptr;
     p->kmax = 2;
     p->pend_flags = 0;
+    p->defer_join = 0;
     for (int i = 0; i < d.D; ++i)
         if ((vars[i].kind == HLVAE_CAT || vars[i].kind == HLVAE_ORDINAL) && vars[i].ncls > p->kmax) p->kmax = vars[i].ncls;
     for (auto& st : p->side) st = nullptr;
@@ -534,6 +535,12 @@ int hlvae_join(const hlvae_plan* p, hlvae_stream s) {
     return 0;
 }
 
+int hlvae_set_defer_join(const hlvae_plan* p, int on) {
+    HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
+    p->defer_join = on ? 1 : 0;
+    return 0;
+}
+
 int hlvae_reset_pending(const hlvae_plan* p) {
     HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
     p->pend_flags = 0;          // deferred side work recorded against a capture that failed: dropped
@@ -715,7 +722,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
             if ((rc = hl_flush_deferred(p, s1, true, HL_PEND_DEFERRED, false, small_batch))) return rc;
         }
         HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
-        return hlvae_join(p, s);
+        return p->defer_join ? 0 : hlvae_join(p, s);
     }
     // d W1 below is the LAST encoder Linear's gradient; its input is Xn or the output of the layers before it
     const bf16_t* w1_inT = d.n_xe > 0 ? ws->xe[d.n_xe - 1].aT : ws->xnT;
@@ -806,7 +813,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     // skip_wy (data-parallel host): the deferred side chain (metrics, next batch's input stage) stays un-joined -- the host's
     // reduce-scatters and optimiser launches that follow do not need it (they were starting 17 us late behind the input stage);
     // it calls hlvae_join at the end of its step
-    if (skip_wy && opt == nullptr) return 0;
+    if ((skip_wy && opt == nullptr) || p->defer_join) return 0;
     return hlvae_join(p, s);
 }
 

@@ -136,6 +136,7 @@ struct hlvae_plan {
     // deferred side work: hlvae_step_metrics and hlvae_decoder_fwd(want_grad = 2) only record their dependency (ev[5]); the
     // launches are queued on a side stream by the next hlvae_backward* / hlvae_join (cabi.hip: hl_flush_deferred)
     mutable int pend_flags;        // HL_PEND_*
+    mutable int defer_join;        // hlvae_set_defer_join: hlvae_backward* return without joining the deferred side chain
     mutable hlvae_ws pend_ws, pend_fin_ws;
     mutable int pend_B, pend_fin_B;
     mutable float* pend_err;

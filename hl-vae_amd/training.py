@@ -345,6 +345,7 @@ class ELBOTrainer:
             kw = {"join": False} if hasattr(self.gp, "join") else {}
             g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch, groups=groups, **kw)
         fused_opt = self.dp is None
+        late_join = False
         if fused_opt:
             # backward and optimiser in one call: y_layer's Adam update runs under the rest of the backward pass
             o = self.opt
@@ -352,11 +353,19 @@ class ELBOTrainer:
             if dbuf:
                 m._set_wy_double_buffer(True)
                 ws = C.byref(m._ws)
+            # GP prior: its state update (Adam, kernel matrix, the 85 us batched inversion) does not depend on the VAE's deferred side
+            # chain (metrics, the next batch's input stage) -- that chain is joined BEHIND it (round-3 trace: the side chain shared a
+            # hardware queue with the prior's chain C and ended 45 us after both GP chains; the state update waited for it)
+            late_join = self.kl == "gp" and hasattr(self.gp, "join") and os.environ.get("HL_GP_LATE_JOIN", "1") != "0"
+            if late_join:
+                _lib.check(lib.hlvae_set_defer_join(m._plan_handle, 1), "set_defer_join")
             try:
                 _lib.check(lib.hlvae_backward_adam(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), B, _lib.ptr(o.m1),
                                                    _lib.ptr(o.m2), _lib.ptr(o.step_count), C.c_float(o.lr), C.c_float(o.betas[0]),
                                                    C.c_float(o.betas[1]), C.c_float(o.eps), C.c_float(1.0), s), "backward_adam")
             finally:
+                if late_join:
+                    lib.hlvae_set_defer_join(m._plan_handle, 0)
                 if dbuf:
                     m._set_wy_double_buffer(False)       # (also when the call failed: later eager steps must not write the spare pair)
             if dbuf:
@@ -417,6 +426,8 @@ class ELBOTrainer:
                 self.gp.optimizer_step(defer=True, **nb)      # (inside a captured chain: the state update runs beside the next step's forward pass)
             else:
                 self.gp.optimizer_step(**nb)
+            if late_join:
+                _lib.check(lib.hlvae_join(m._plan_handle, s), "join")
         if prefetch is not None:                 # join; the prefetched batch's buffers become the front set
             torch.cuda.current_stream(m.device).wait_stream(self._pf_stream)
             m._swap_input_buffers()

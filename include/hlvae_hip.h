@@ -266,6 +266,10 @@ int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* er
  * hlvae_backward* / hlvae_join on this plan (ws and err must stay valid until then), and `err` is ordered before later
  * work on a stream only after that stream called hlvae_backward* or hlvae_join. */
 int hlvae_join(const hlvae_plan* p, hlvae_stream s);
+/* on != 0: hlvae_backward / hlvae_backward_adam return WITHOUT joining the deferred side chain (metrics, next batch's input stage);
+ * the host queues what does not depend on it (the GP prior's state update) and calls hlvae_join itself.  Un-joined work is
+ * joined by the plan's next forward call at the latest. */
+int hlvae_set_defer_join(const hlvae_plan* p, int on);
 
 /* rescale ws->dy by a per-element upstream gradient after the fact (autograd path) */
 int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, int B, hlvae_stream s);
