@@ -326,6 +326,35 @@ __global__ __launch_bounds__(256) void k_gp_spd_inv(const double* __restrict__ A
 // ------------------------------------------------------------------------------------------------------------
 #define GP_TS (GP_TMAX + 1)
 
+// T x T (T <= 32) Gauss-Jordan inverse inside ONE wave, the matrix in registers: lane j holds column j (col[i] = a[i][j]); a pivot's
+// row is every lane's own register k, its column comes from lane k by v_readlane (a scalar operand of the FMAs) -- no LDS, no
+// barrier.  Round 3: the 256-thread form above (2 x 2 elements per lane, pivot row / column through LDS, one barrier per pivot)
+// spent ~1400 clocks per pivot on a 20 x 20 matrix, 12 of the ~18 us a workgroup of k_gp_subject_fwd lives; this one ~250.
+__device__ __forceinline__ double gp_readlane_d(double v, int l) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ void gj_wave(double (&col)[GP_TMAX], int T, int lane, double* pv) {
+#pragma unroll
+    for (int k = 0; k < GP_TMAX; ++k) {
+        if (k < T) {                                                  // (uniform)
+            const double piv = gp_readlane_d(col[k], k);
+            const double pk = gp_rcp(piv);
+            if (lane == 0) pv[k] = piv;
+            const double rowk = col[k] * pk;                          // a[k][j] / p
+#pragma unroll
+            for (int i = 0; i < GP_TMAX; ++i) {
+                if (i != k && i < T) {
+                    const double c = gp_readlane_d(col[i], k);        // a[i][k]
+                    col[i] = lane == k ? -c * pk : fma(-c, rowk, col[i]);
+                }
+            }
+            col[k] = lane == k ? pk : rowk;
+        }
+    }
+}
+
 template <int NT, int NR>
 __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     hlvae_gp_kernel k0, hlvae_gp_kernel k1, const double* __restrict__ hyp, int n_slots, int L, int Q,
@@ -403,20 +432,20 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         kzs[i * GP_TS + j] = kz; kzs[j * GP_TS + i] = kz;
     }
     __syncthreads();
-    double a[2][2], k0v[2][2];
+    // inverse of B_st: wave 0, the matrix in its registers (gj_wave); the other waves wait at the barrier
+    if (tid < 64) {
+        double col[GP_TMAX];
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+        for (int i = 0; i < GP_TMAX; ++i) col[i] = (i < T && tid < T) ? ib[i * GP_TS + tid] : (i == tid ? 1.0 : 0.0);
+        gj_wave(col, T, tid, pv);
+        if (tid < T) {
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int i = ti + 16 * ii, j = tj + 16 * jj;
-            const bool in = i < T && j < T;
-            a[ii][jj] = in ? ib[i * GP_TS + j] : (i == j ? 1.0 : 0.0);
-            k0v[ii][jj] = in ? kzs[i * GP_TS + j] : 0.0;
+            for (int i = 0; i < GP_TMAX; ++i)
+                if (i < T) ib[i * GP_TS + tid] = (rows[i] >= 0 && rows[tid] >= 0) ? col[i] : 0.0;    // masked to the valid block
         }
-    __syncthreads();                                              // ib is reused for the inverse below
-    gj_pivots<2, 0>(a, gjrow, gjcol, pv, T, ti, tj);
-    gj_pivots<2, 1>(a, gjrow, gjcol, pv, T, ti, tj);
-    // mask the inverse to the valid block, write iB and K0_st
+    }
+    __syncthreads();
+    // write iB and K0_st
     double d1 = 0.0;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
@@ -424,16 +453,13 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         for (int jj = 0; jj < 2; ++jj) {
             const int i = ti + 16 * ii, j = tj + 16 * jj;
             if (i < T && j < T) {
-                const bool ok = rows[i] >= 0 && rows[j] >= 0;
-                const double v = ok ? a[ii][jj] : 0.0;
-                ib[i * GP_TS + j] = v;
+                const double v = ib[i * GP_TS + j], k0e = kzs[i * GP_TS + j];
                 const size_t o = (((size_t)s * L + l) * T + i) * T + j;
                 iB_out[o] = v;
-                K0_out[o] = k0v[ii][jj];
-                d1 += v * k0v[ii][jj];                            // sum(iB * K0_st)  (:259)
+                K0_out[o] = k0e;
+                d1 += v * k0e;                                    // sum(iB * K0_st)  (:259)
             }
         }
-    __syncthreads();
     // v = iB a, A = a.v, Bt = sum diag(iB) e^lv, g_mu, g_lv
     double pa = 0.0, pb = 0.0, pc = 0.0;
     if (tid < T) {

@@ -326,7 +326,7 @@ class GPPriorHIP:
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         self._prep, self._prep_stream, self._tail_pending = None, None, False
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
-        self._balance = int(_os.environ.get("HL_GP_BALANCE", "1"))        # where the chain rule through K0xz runs (kl_and_grads)
+        self._balance = int(_os.environ.get("HL_GP_BALANCE", "2"))        # where the chain rule through K0xz runs (kl_and_grads)
         self._chain = _os.environ.get("HL_GP_CHAIN", "1") != "0"          # the M x M algebra behind W as one launch (k_gp_chain)
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
