@@ -326,6 +326,7 @@ class GPPriorHIP:
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         self._prep, self._prep_stream, self._tail_pending = None, None, False
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
+        self._serial = _os.environ.get("HL_GP_SERIAL", "0") == "1"
         self._balance = int(_os.environ.get("HL_GP_BALANCE", "2"))        # where the chain rule through K0xz runs (kl_and_grads)
         self._chain = _os.environ.get("HL_GP_CHAIN", "1") != "0"          # the M x M algebra behind W as one launch (k_gp_chain)
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
@@ -453,7 +454,7 @@ class GPPriorHIP:
         dev = labels.device
         main = torch.cuda.current_stream(dev)
         if self._prep_stream is None:
-            self._prep_stream = torch.cuda.Stream(device=dev)
+            self._prep_stream = torch.cuda.current_stream(dev) if self._serial else torch.cuda.Stream(device=dev)
         sP = self._prep_stream
         sP.wait_stream(main)
         B = labels.shape[0] if rows is None else rows.shape[0]
@@ -482,7 +483,7 @@ class GPPriorHIP:
         dev = labels.device
         main = torch.cuda.current_stream(dev)
         if self._ahead_stream is None:
-            self._ahead_stream = torch.cuda.Stream(device=dev)
+            self._ahead_stream = torch.cuda.current_stream(dev) if self._serial else torch.cuda.Stream(device=dev)
         sK = self._ahead_stream
         sK.wait_stream(main)
         B = rows.shape[0]
@@ -689,6 +690,10 @@ class GPPriorHIP:
         return g_mu, g_lv
 
     def _streams(self, dev):
+        if self._serial:            # HL_GP_SERIAL=1 (profiling): every launch on the caller's stream, each kernel runs alone
+            cur = torch.cuda.current_stream(dev)
+            self._side = (cur, cur)
+            return self._side
         if self._side is None:
             self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         return self._side
@@ -773,7 +778,7 @@ class GPPriorHIP:
             # join_tail() (end of a captured chain, check(), state readers) makes the caller's stream wait.
             dev = self.zt_list.device
             if self._prep_stream is None:
-                self._prep_stream = torch.cuda.Stream(device=dev)
+                self._prep_stream = torch.cuda.current_stream(dev) if self._serial else torch.cuda.Stream(device=dev)
             for s_ in self._side:
                 self._prep_stream.wait_stream(s_)
             self._pending = False

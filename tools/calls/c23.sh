@@ -6,3 +6,6 @@ for cfg in "a 1 1" "b 2 1" "c 2 0" "a 1 1" "b 2 1" "c 2 0"; do
   python tools/calls/show.py gpurun_out/r3_c23_$1.json "gp balance=$2 late_join=$3" | head -1 | cut -c1-330
 done
 bash tools/trace_step.sh r3g_cfg4 --workload d4 --rows 50000 --batch 1024 --kl gp 2>&1 | tail -45
+echo "=== serial (alone) GP kernel times"
+HL_GP_SERIAL=1 python bench.py --no-cpu-baseline --no-also --no-graph --no-in-step --workload d4 --rows 50000 --batch 1024 --kl gp --steps 50 --warmup 10 > gpurun_out/r3_c23_serial.json 2> gpurun_out/r3_c23_serial.log || tail -5 gpurun_out/r3_c23_serial.log
+python tools/calls/show.py gpurun_out/r3_c23_serial.json "gp serial" | head -1 | cut -c1-900
