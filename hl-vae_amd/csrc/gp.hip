@@ -24,6 +24,19 @@
 #define GP_MAX_RBF 2                                        // RBF factors per term (validated by the launchers)
 #define GP_XS 9                                             // padded covariate row in LDS
 
+// clock64() phase profile of the per-subject kernels (tools/gp_phases.py): thread 0 of a workgroup stamps the phases into a
+// buffer when one is installed (hlvae_debug_gp_clk); one scalar load per workgroup otherwise
+#define GP_CLK_PH 10
+#define GP_CLK_WG 2048
+__device__ long long* g_gpclk = nullptr;
+#define GP_CLK(kernel, ph)                                                                                                  \
+    do {                                                                                                                     \
+        if (clkp != nullptr && threadIdx.x == 0) {                                                                          \
+            const int wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                                             \
+            if (wg_ < GP_CLK_WG) clkp[((kernel) * GP_CLK_WG + wg_) * GP_CLK_PH + (ph)] = clock64();                       \
+        }                                                                                                                    \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------------------
 // covariance terms.  Hyper-parameters of one latent dimension are hoisted into registers once per thread.
 // ------------------------------------------------------------------------------------------------------------
@@ -326,35 +339,9 @@ __global__ __launch_bounds__(256) void k_gp_spd_inv(const double* __restrict__ A
 // ------------------------------------------------------------------------------------------------------------
 #define GP_TS (GP_TMAX + 1)
 
-// T x T (T <= 32) Gauss-Jordan inverse inside ONE wave, the matrix in registers: lane j holds column j (col[i] = a[i][j]); a pivot's
-// row is every lane's own register k, its column comes from lane k by v_readlane (a scalar operand of the FMAs) -- no LDS, no
-// barrier.  Round 3: the 256-thread form above (2 x 2 elements per lane, pivot row / column through LDS, one barrier per pivot)
-// spent ~1400 clocks per pivot on a 20 x 20 matrix, 12 of the ~18 us a workgroup of k_gp_subject_fwd lives; this one ~250.
-__device__ __forceinline__ double gp_readlane_d(double v, int l) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ void gj_wave(double (&col)[GP_TMAX], int T, int lane, double* pv) {
-#pragma unroll
-    for (int k = 0; k < GP_TMAX; ++k) {
-        if (k < T) {                                                  // (uniform)
-            const double piv = gp_readlane_d(col[k], k);
-            const double pk = gp_rcp(piv);
-            if (lane == 0) pv[k] = piv;
-            const double rowk = col[k] * pk;                          // a[k][j] / p
-#pragma unroll
-            for (int i = 0; i < GP_TMAX; ++i) {
-                if (i != k && i < T) {
-                    const double c = gp_readlane_d(col[i], k);        // a[i][k]
-                    col[i] = lane == k ? -c * pk : fma(-c, rowk, col[i]);
-                }
-            }
-            col[k] = lane == k ? pk : rowk;
-        }
-    }
-}
-
+// (Round 3 tried the T x T inverse inside ONE wave -- lane j holds column j in registers, the pivot column arrives by v_readlane as a
+//  scalar operand of the FMAs, no LDS, no barrier: k_gp_subject_fwd 74 -> 92 us alone.  Three waves idle while one issues ~3 k dependent
+//  readlane / FMA pairs; the 256-thread form with its 20 barriers is the faster one for 20 x 20.)
 template <int NT, int NR>
 __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     hlvae_gp_kernel k0, hlvae_gp_kernel k1, const double* __restrict__ hyp, int n_slots, int L, int Q,
@@ -378,6 +365,8 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     __shared__ int rows[GP_TMAX];
     __shared__ double red[3][4];
     const int s = blockIdx.x, l = blockIdx.y, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    long long* clkp = g_gpclk;
+    GP_CLK(0, 0);
     if (tid < GP_TMAX) rows[tid] = tid < T ? idx[(size_t)s * T + tid] : -1;
     __syncthreads();
     for (int e = tid; e < T * Q; e += 256) {
@@ -402,6 +391,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         vsh[tid] = wsh[tid] = 0.0;
         mus[tid] = (mu != nullptr && tid < T && rows[tid] >= 0) ? (double)mu[(size_t)rows[tid] * L + l] : 0.0;
     }
+    GP_CLK(0, 1);      // staging issued
     GpHypT<NT, NR> h0, h1;
     gp_hoist(k0, hyp, n_slots, L, l, h0);
     gp_hoist(k1, hyp, n_slots, L, l, h1);
@@ -416,6 +406,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         sa += __shfl_xor(sa, 1, 64);
         if (sub == 0 && t < T) rs[t] = rows[t] >= 0 ? sa - mus[t] : 0.0;
     }
+    GP_CLK(0, 2);      // staged + residual
     const double nz = noise[l];
     // covariance entries: the kernels are symmetric, so the T (T + 1) / 2 = 210 pairs i <= j are evaluated once, one per
     // thread, into LDS (in the 2 x 2 register blocking of the Gauss-Jordan below 16 threads would evaluate 4 pairs each)
@@ -432,20 +423,22 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         kzs[i * GP_TS + j] = kz; kzs[j * GP_TS + i] = kz;
     }
     __syncthreads();
-    // inverse of B_st: wave 0, the matrix in its registers (gj_wave); the other waves wait at the barrier
-    if (tid < 64) {
-        double col[GP_TMAX];
+    GP_CLK(0, 3);      // covariance pairs
+    double a[2][2], k0v[2][2];
 #pragma unroll
-        for (int i = 0; i < GP_TMAX; ++i) col[i] = (i < T && tid < T) ? ib[i * GP_TS + tid] : (i == tid ? 1.0 : 0.0);
-        gj_wave(col, T, tid, pv);
-        if (tid < T) {
+    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int i = 0; i < GP_TMAX; ++i)
-                if (i < T) ib[i * GP_TS + tid] = (rows[i] >= 0 && rows[tid] >= 0) ? col[i] : 0.0;    // masked to the valid block
+        for (int jj = 0; jj < 2; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            const bool in = i < T && j < T;
+            a[ii][jj] = in ? ib[i * GP_TS + j] : (i == j ? 1.0 : 0.0);
+            k0v[ii][jj] = in ? kzs[i * GP_TS + j] : 0.0;
         }
-    }
-    __syncthreads();
-    // write iB and K0_st
+    __syncthreads();                                              // ib is reused for the inverse below
+    gj_pivots<2, 0>(a, gjrow, gjcol, pv, T, ti, tj);
+    gj_pivots<2, 1>(a, gjrow, gjcol, pv, T, ti, tj);
+    GP_CLK(0, 4);      // Gauss-Jordan
+    // mask the inverse to the valid block, write iB and K0_st
     double d1 = 0.0;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
@@ -453,13 +446,17 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         for (int jj = 0; jj < 2; ++jj) {
             const int i = ti + 16 * ii, j = tj + 16 * jj;
             if (i < T && j < T) {
-                const double v = ib[i * GP_TS + j], k0e = kzs[i * GP_TS + j];
+                const bool ok = rows[i] >= 0 && rows[j] >= 0;
+                const double v = ok ? a[ii][jj] : 0.0;
+                ib[i * GP_TS + j] = v;
                 const size_t o = (((size_t)s * L + l) * T + i) * T + j;
                 iB_out[o] = v;
-                K0_out[o] = k0e;
-                d1 += v * k0e;                                    // sum(iB * K0_st)  (:259)
+                K0_out[o] = k0v[ii][jj];
+                d1 += v * k0v[ii][jj];                            // sum(iB * K0_st)  (:259)
             }
         }
+    __syncthreads();
+    GP_CLK(0, 5);      // iB, K0 written
     // v = iB a, A = a.v, Bt = sum diag(iB) e^lv, g_mu, g_lv
     double pa = 0.0, pb = 0.0, pc = 0.0;
     if (tid < T) {
@@ -478,6 +475,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         }
         pc = log(pv[tid]);                                        // log det B_st = sum of log pivots (:258)
     }
+    GP_CLK(0, 6);      // v, g_mu, g_lv
     // V = iB Ks  [T][M] -> V_out[l][row][:]
     for (int e = tid; e < T * M; e += 256) {
         const int i = e / M, mcol = e - i * M;
@@ -486,6 +484,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         for (int j = 0; j < T; ++j) acc += ib[i * GP_TS + j] * ks[j * M + mcol];
         V_out[((size_t)l * Bn + rows[i]) * M + mcol] = acc;
     }
+    GP_CLK(0, 7);      // V = iB Ks
     // block reduction of the partial sums
     pa = wave_sum_d(pa); pb = wave_sum_d(pb); d1 = wave_sum_d(d1); pc = wave_sum_d(pc);
     if ((tid & 63) == 0) { red[0][tid >> 6] = pa; red[1][tid >> 6] = pb; red[2][tid >> 6] = d1; }
@@ -500,6 +499,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         atomicAdd(u_acc + (size_t)l * M + tid, su);
         atomicAdd(p1_acc + (size_t)l * M + tid, sp);
     }
+    GP_CLK(0, 8);      // u / P1 atomics
     if (tid == 0) {
         double* p = part + ((size_t)s * L + l) * 4;
         p[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
@@ -529,6 +529,8 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
     __shared__ double vv[GP_TMAX], ee[GP_TMAX];
     __shared__ double gacc[32];                                   // per-row gradient accumulators of this block
     const int s = blockIdx.x, l = blockIdx.y, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    long long* clkp = g_gpclk;
+    GP_CLK(1, 0);
     if (tid < GP_TMAX) rows[tid] = tid < T ? idx[(size_t)s * T + tid] : -1;
     if (tid < 32) gacc[tid] = 0.0;
     __syncthreads();
@@ -563,6 +565,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
         ee[tid] = r >= 0 ? exp((double)lv[(size_t)r * L + l]) : 0.0;
     }
     __syncthreads();
+    GP_CLK(1, 1);      // V_s, Y_s staged
     // w = diag(e) + K0
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
@@ -596,6 +599,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
             if (i < T && j < T) w[i * TS + j] = tmp[ii][jj];
         }
     __syncthreads();
+    GP_CLK(1, 2);      // iB w
     GpHypT<NT, NR> h0, h1;
     gp_hoist(k0, hyp, n_slots, L, l, h0);
     gp_hoist(k1, hyp, n_slots, L, l, h1);
@@ -622,6 +626,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
             }
             if (m < M) y0 += ys[i * MS + m] * vs[j * MS + m];
             const double yv = y0 + y1;
+            if (p == 0) GP_CLK(1, 5);  // (thread 0: its dots done)
             const double ibv = ib[i * TS + j];
             const double g1 = sym * 0.5 * c * (ibv - vv[i] * vv[j] - acc + yv);     // dL / dB_st
             const double g0 = sym * 0.5 * c * ibv;                                  // dL / dK0_st
@@ -629,9 +634,11 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
             gp_pair_grad(k0, h0, xs + i * GP_XS, xs + j * GP_XS, g0, a0);
         }
     }
+    GP_CLK(1, 3);      // pair loop
     const double* dpos_l = hyp + (size_t)n_slots * L + l;
     gp_flush(k1, a1, dpos_l, L, gacc, tid & 63);
     gp_flush(k0, a0, dpos_l, L, gacc, tid & 63);
+    GP_CLK(1, 4);      // flush
     __syncthreads();
     if (tid < n_slots && gacc[tid] != 0.0) atomicAdd(gprm + (size_t)tid * L + l, gacc[tid]);
 }
@@ -1531,6 +1538,24 @@ int hlvae_gp_rsym(const double* u, const double* m, const double* W, const doubl
     HL_PROF("gp_rsym", (hipStream_t)s);
     k_gp_rsym<<<(n + 255) / 256, 256, 0, (hipStream_t)s>>>(u, m, W, X, H, c, N, n, out);
     HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_debug_gp_clk(long long* host, int install) {
+    // install != 0: allocate + install the stamp buffer; else copy it to host [2][GP_CLK_WG][GP_CLK_PH] and uninstall
+    static long long* buf = nullptr;
+    const size_t n = (size_t)2 * GP_CLK_WG * GP_CLK_PH;
+    if (install) {
+        if (!buf) HL_CHECK(hipMalloc(&buf, n * sizeof(long long)));
+        HL_CHECK(hipMemset(buf, 0, n * sizeof(long long)));
+        HL_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gpclk), &buf, sizeof(buf)));
+        return 0;
+    }
+    HL_REQUIRE(buf && host, HLVAE_EINVAL, "gp_clk: not installed");
+    HL_CHECK(hipDeviceSynchronize());
+    HL_CHECK(hipMemcpy(host, buf, n * sizeof(long long), hipMemcpyDeviceToHost));
+    long long* nul = nullptr;
+    HL_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gpclk), &nul, sizeof(nul)));
     return 0;
 }
 
