@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include "common.h"
 
+typedef __attribute__((ext_vector_type(4))) double f64x4_t;     // one v_mfma_f64_16x16x4_f64 accumulator fragment
 #define GP_TMAX 32
 #define GP_MMAX 128
 #define GP_MAX_RBF 2                                        // RBF factors per term (validated by the launchers)
@@ -476,13 +477,33 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         pc = log(pv[tid]);                                        // log det B_st = sum of log pivots (:258)
     }
     GP_CLK(0, 6);      // v, g_mu, g_lv
-    // V = iB Ks  [T][M] -> V_out[l][row][:]
-    for (int e = tid; e < T * M; e += 256) {
-        const int i = e / M, mcol = e - i * M;
-        if (rows[i] < 0) continue;
-        double acc = 0.0;
-        for (int j = 0; j < T; ++j) acc += ib[i * GP_TS + j] * ks[j * M + mcol];
-        V_out[((size_t)l * Bn + rows[i]) * M + mcol] = acc;
+    // V = iB Ks  [T][M] -> V_out[l][row][:] on the fp64 matrix cores (round 3: as 20 scalar FMAs per output with two LDS reads each
+    // this loop was 18 k of a workgroup's 76 k clocks -- LDS bandwidth shared by the four co-resident workgroups): wave w owns the
+    // 16-column fragments w, w + 4 of both 16-row halves; A = iB [i][j], B = Ks [j][m], k = j in steps of 4
+    {
+        const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, q = lane & 15;
+        const int nfc = (M + 15) >> 4;
+        for (int fc = wave; fc < nfc; fc += 4) {
+            f64x4_t acc2[2] = {f64x4_t{0.0, 0.0, 0.0, 0.0}, f64x4_t{0.0, 0.0, 0.0, 0.0}};
+            const int mcol = 16 * fc + q;
+            for (int k4 = 0; k4 < T; k4 += 4) {
+                const int kk = k4 + g;
+                const double b = (kk < T && mcol < M) ? ks[kk * M + mcol] : 0.0;
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi) {
+                    const int i = 16 * fi + q;
+                    const double a = (i < T && kk < T) ? ib[i * GP_TS + kk] : 0.0;
+                    acc2[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2[fi], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * fi + g + 4 * r;
+                    if (i < T && mcol < M && rows[i] >= 0) V_out[((size_t)l * Bn + rows[i]) * M + mcol] = acc2[fi][r];
+                }
+        }
     }
     GP_CLK(0, 7);      // V = iB Ks
     // block reduction of the partial sums
@@ -524,6 +545,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
     const int TS = T + 1;                                         // iB, w [T][TS]: sized for the actual T (with V_s / Y_s 49 KB at
     double* ib = ys + (size_t)T * MS;                             // T = 20, M = 120 -> three workgroups per CU instead of two)
     double* w = ib + (size_t)T * TS;
+    double* yvt = w + (size_t)T * TS;                             // (Y V^T) [T][TS], from the matrix cores
     __shared__ double xs[GP_TMAX * GP_XS];
     __shared__ int rows[GP_TMAX];
     __shared__ double vv[GP_TMAX], ee[GP_TMAX];
@@ -599,6 +621,28 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
             if (i < T && j < T) w[i * TS + j] = tmp[ii][jj];
         }
     __syncthreads();
+    // (Y V^T)[i][j] = sum_m Y_s[i][m] V_s[j][m] on the fp64 matrix cores: one 16 x 16 fragment per wave, k = m in steps of 4.  (As two
+    // scalar chains of 60 LDS-read pairs per (i, j) thread the dot products were 19 k of a workgroup's 62 k clocks: rows of V_s
+    // 121 doubles apart collide in the banks.)
+    {
+        const int wave = tid >> 6, lane = tid & 63, g4 = lane >> 4, q = lane & 15;
+        const int i = 16 * (wave & 1) + q, j = 16 * (wave >> 1) + q;
+        const double* yp = ys + (size_t)min(i, T - 1) * MS;
+        const double* vp = vs + (size_t)min(j, T - 1) * MS;
+        f64x4_t acc4 = {0.0, 0.0, 0.0, 0.0};
+        for (int m4 = 0; m4 < M; m4 += 4) {
+            const int m = m4 + g4;
+            const double a_ = (i < T && m < M) ? yp[m] : 0.0;
+            const double b_ = (j < T && m < M) ? vp[m] : 0.0;
+            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc4, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * (wave & 1) + g4 + 4 * r, col = 16 * (wave >> 1) + q;
+            if (row < T && col < T) yvt[row * TS + col] = acc4[r];
+        }
+    }
+    __syncthreads();
     GP_CLK(1, 2);      // iB w
     GpHypT<NT, NR> h0, h1;
     gp_hoist(k0, hyp, n_slots, L, l, h0);
@@ -618,14 +662,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
         if (rows[i] >= 0 && rows[j] >= 0) {
             double acc = 0.0;                                                 // (iB w iB)[i][j]
             for (int k = 0; k < T; ++k) acc += w[i * TS + k] * ib[k * TS + j];
-            double y0 = 0.0, y1 = 0.0;                                        // (Y V^T)[i][j], two chains
-            int m = 0;
-            for (; m + 1 < M; m += 2) {
-                y0 += ys[i * MS + m] * vs[j * MS + m];
-                y1 += ys[i * MS + m + 1] * vs[j * MS + m + 1];
-            }
-            if (m < M) y0 += ys[i * MS + m] * vs[j * MS + m];
-            const double yv = y0 + y1;
+            const double yv = yvt[i * TS + j];
             if (p == 0) GP_CLK(1, 5);  // (thread 0: its dots done)
             const double ibv = ib[i * TS + j];
             const double g1 = sym * 0.5 * c * (ibv - vv[i] * vv[j] - acc + yv);     // dL / dB_st
@@ -636,8 +673,68 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
     }
     GP_CLK(1, 3);      // pair loop
     const double* dpos_l = hyp + (size_t)n_slots * L + l;
-    gp_flush(k1, a1, dpos_l, L, gacc, tid & 63);
-    gp_flush(k0, a0, dpos_l, L, gacc, tid & 63);
+    constexpr int NVK = NT + NT * NR;                             // accumulators per kernel
+    if (NVK <= 8 && (size_t)T * MS >= (size_t)NVK * 256) {       // (uniform)
+        // every thread's 2 NVK accumulators -> LDS image [value][thread] over V_s / Y_s (dead now), 16 threads sum one value's 256
+        // entries, one shuffle tree per value instead of one per value AND wave (gp_flush: 16 x 12 ds_bpermute per wave, 12 k clocks)
+        __shared__ int slot_tab[16];                              // hyper-parameter row of every accumulator (uniform code, -1: unused)
+        auto fill = [&](const hlvae_gp_kernel& kk, int base) {
+            for (int t = 0; t < NT; ++t) {
+                int sl = t < kk.n_terms ? kk.scale_slot[t] : -1, lsl[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) lsl[r] = -1;
+                if (t < kk.n_terms) {
+                    int rcount = 0;
+                    for (int f = 0; f < kk.n_factors[t]; ++f)
+                        if (kk.kind[t][f] == HLVAE_GP_RBF) {
+#pragma unroll
+                            for (int r = 0; r < NR; ++r)
+                                if (r == rcount) lsl[r] = kk.ls_slot[t][f];
+                            ++rcount;
+                        }
+                }
+                if (tid == 0) {
+                    slot_tab[base + t] = sl;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) slot_tab[base + NT + t * NR + r] = lsl[r];
+                }
+            }
+        };
+        fill(k1, 0);
+        fill(k0, NVK);
+        __syncthreads();
+        double* red = vs;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            red[(size_t)t * 256 + tid] = a1.ts[t];
+            red[(size_t)(NVK + t) * 256 + tid] = a0.ts[t];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                red[(size_t)(NT + t * NR + r) * 256 + tid] = a1.tl[t][r];
+                red[(size_t)(NVK + NT + t * NR + r) * 256 + tid] = a0.tl[t][r];
+            }
+        }
+        __syncthreads();
+        for (int v0 = 0; v0 < 2 * NVK; v0 += 16) {
+            const int vi = v0 + (tid >> 4), part = tid & 15;
+            double sum = 0.0;
+            if (vi < 2 * NVK) {
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) sum += red[(size_t)vi * 256 + part + 16 * qq];
+            }
+            sum += __shfl_xor(sum, 8, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 1, 64);
+            if (part == 0 && vi < 2 * NVK && sum != 0.0) {
+                const int slot = slot_tab[vi];
+                if (slot >= 0) atomicAdd(&gacc[slot], sum * dpos_l[(size_t)slot * L]);
+            }
+        }
+    } else {
+        gp_flush(k1, a1, dpos_l, L, gacc, tid & 63);
+        gp_flush(k0, a0, dpos_l, L, gacc, tid & 63);
+    }
     GP_CLK(1, 4);      // flush
     __syncthreads();
     if (tid < n_slots && gacc[tid] != 0.0) atomicAdd(gprm + (size_t)tid * L + l, gacc[tid]);
@@ -809,7 +906,6 @@ __global__ __launch_bounds__(256) void k_gp_param_grad(hlvae_gp_kernel k, const 
 // sit whole in LDS, each wave owns one 16 x 16 fragment.  The library's batched GEMM takes
 // 11-32 us for these 120 x 120 x 120 x 32 products (3.5 TFLOP/s); seven of them per step were 18 % of the GP step.
 // ------------------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) double f64x4_t;
 #define GP_BMM_T 32                                         // tile columns
 #define GP_BMM_R 32                                         // tile rows
 __global__ __launch_bounds__(256) void k_gp_bmm(const double* __restrict__ A, const double* __restrict__ B, const double* D,
@@ -1455,7 +1551,7 @@ int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, c
     if (int rc = gp_check_kernel(k0, n_slots, Q)) return rc;
     if (int rc = gp_check_kernel(k1, n_slots, Q)) return rc;
     HL_REQUIRE(T >= 1 && T <= GP_TMAX && S >= 1 && M <= GP_MMAX, HLVAE_ESHAPE, "gp_subject_bwd: T=%d M=%d", T, M);
-    const size_t smem = ((size_t)2 * T * (M + 1) + (size_t)2 * T * (T + 1)) * sizeof(double);
+    const size_t smem = ((size_t)2 * T * (M + 1) + (size_t)3 * T * (T + 1)) * sizeof(double);
     const bool small = gp_kernel_small(k0) && gp_kernel_small(k1);
     static size_t attr_max[2] = {32 * 1024, 32 * 1024};
     if (smem > attr_max[small]) {
