@@ -629,13 +629,25 @@ __global__ __launch_bounds__(256) void k_gp_subject_bwd(
         const int i = 16 * (wave & 1) + q, j = 16 * (wave >> 1) + q;
         const double* yp = ys + (size_t)min(i, T - 1) * MS;
         const double* vp = vs + (size_t)min(j, T - 1) * MS;
-        f64x4_t acc4 = {0.0, 0.0, 0.0, 0.0};
-        for (int m4 = 0; m4 < M; m4 += 4) {
-            const int m = m4 + g4;
-            const double a_ = (i < T && m < M) ? yp[m] : 0.0;
-            const double b_ = (j < T && m < M) ? vp[m] : 0.0;
-            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc4, 0, 0, 0);
+        // four independent accumulation chains, 16 k per pass: the LDS reads of a pass are issued together and a dependent MFMA
+        // is four products away (one chain of 30 dependent MFMAs behind two LDS reads each was 14 k clocks)
+        f64x4_t ac[4];
+#pragma unroll
+        for (int c_ = 0; c_ < 4; ++c_) ac[c_] = f64x4_t{0.0, 0.0, 0.0, 0.0};
+        for (int m16 = 0; m16 < M; m16 += 16) {
+            double a_[4], b_[4];
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) {
+                const int m = m16 + 4 * c_ + g4;
+                a_[c_] = (i < T && m < M) ? yp[min(m, M - 1)] : 0.0;
+                b_[c_] = (j < T && m < M) ? vp[min(m, M - 1)] : 0.0;
+            }
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) ac[c_] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[c_], b_[c_], ac[c_], 0, 0, 0);
         }
+        f64x4_t acc4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc4[r] = (ac[0][r] + ac[1][r]) + (ac[2][r] + ac[3][r]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * (wave & 1) + g4 + 4 * r, col = 16 * (wave >> 1) + q;
@@ -1343,6 +1355,195 @@ __global__ __launch_bounds__(THREADS) void k_gp_chain(GpChainArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same algebra by ROW BLOCKS (round 3, second form): with Q = iK H iK = iK - N1 (N1 = iK - iK H iK is in hand from the state
+// stage), T1 = iK W and symmetric iK, W, H,
+//     iK (H iK W) iK = Q W iK,      iK (H iK W)^T iK = iK W Q = T1 Q,      iK H iK = Q,      iK W iK = T1 iK
+// so every 32-row block of Bm = T1 iK + iK and of G = g_alpha iK Rs iK + g_beta iK,
+//     iK Rs iK = c [(iK u)(iK m)^T + (iK m)(iK u)^T] - c T1 iK + c (Q W iK + T1 Q) + Q + (iK m)(iK m)^T,
+// needs only ITS rows of T1 = iK W and Q W: no product of one row block reads another block's result.  One workgroup per
+// (latent, 32-row block): 4 x 32 = 128 workgroups that never synchronise with each other, five 32 x N x N product passes each
+// (k_gp_chain: 64 workgroups x up to three N x N x N products), the two intermediate row blocks in LDS.
+// grid (batch, ceil(N / 32)), 512 threads: wave w owns output columns 16 w .. 16 w + 15 of both 16-row halves.
+#define GP_RB_LD 122                                          // LDS row stride of the intermediate row blocks (16-byte aligned rows)
+struct GpChainRbArgs {
+    const double *iK, *W, *N1, *iH, *m, *P1, *u, *iKm;
+    double *grad_m, *grad_H, *tmp, *G;
+    double lr, c, g_alpha, g_beta;
+    int N;
+};
+__global__ __launch_bounds__(512) void k_gp_chain_rb(GpChainRbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double rb_sm[];
+    double* t1s = rb_sm;                                      // T1 rows   [32][GP_RB_LD]
+    double* qws = t1s + 32 * GP_RB_LD;                        // (Q W) rows
+    double* ms = qws + 32 * GP_RB_LD;                         // m, P1, u, iK m, iK u   [GP_MMAX] each
+    double* ps = ms + GP_MMAX;
+    double* us = ps + GP_MMAX;
+    double* ikm = us + GP_MMAX;
+    double* iku = ikm + GP_MMAX;
+    double* rowsum = iku + GP_MMAX;                           // sum_j Bm[i][j] m[j] of the block's rows  [32]
+    const int l = blockIdx.x, R0 = 32 * blockIdx.y, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, q = lane & 15;
+    const size_t o = (size_t)l * N * N, ov = (size_t)l * N;
+    const double* iK = a.iK + o;
+    const double* W = a.W + o;
+    const double* N1 = a.N1 + o;
+    if (tid < N) { ms[tid] = a.m[ov + tid]; ps[tid] = a.P1[ov + tid]; us[tid] = a.u[ov + tid]; ikm[tid] = a.iKm[ov + tid]; }
+    if (tid < 32) rowsum[tid] = 0.0;
+    __syncthreads();
+    for (int i = tid >> 3; i < N; i += 64) {                  // iK u, all rows (eight lanes per row)
+        double s_ = 0.0;
+        for (int j = tid & 7; j < N; j += 8) s_ += iK[(size_t)i * N + j] * us[j];
+        s_ += __shfl_xor(s_, 4, 64);
+        s_ += __shfl_xor(s_, 2, 64);
+        s_ += __shfl_xor(s_, 1, 64);
+        if ((tid & 7) == 0) iku[i] = s_;
+    }
+    const int col = 16 * wave + q;
+    const bool cok = col < N;
+    const unsigned offb = (unsigned)(4 * g * N + min(col, N - 1));
+    bool rok[2];
+    unsigned offa[2];
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) { rok[fi] = R0 + 16 * fi + q < N; offa[fi] = (unsigned)(min(R0 + 16 * fi + q, N - 1) * N + 4 * g); }
+    // ---- pass 1: T1 rows = iK[R] W and (N1 W) rows, one sweep over W
+    {
+        f64x4_t at[2], an[2];
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) { at[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; an[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+        auto load = [&](int kb, f64x4_t (&xa)[2], f64x4_t (&xn)[2], double (&b)[4]) {
+            const bool kok = kb + 4 * g < N;
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi) {
+                xa[fi] = *reinterpret_cast<const f64x4_t*>(iK + kb + (kok ? offa[fi] : 0u));
+                xn[fi] = *reinterpret_cast<const f64x4_t*>(N1 + kb + (kok ? offa[fi] : 0u));
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) b[s_] = (W + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+                if (!(kok && rok[fi])) { xa[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; xn[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+            if (!(kok && cok)) { b[0] = b[1] = b[2] = b[3] = 0.0; }
+        };
+        auto mma = [&](const f64x4_t (&xa)[2], const f64x4_t (&xn)[2], const double (&b)[4]) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int fi = 0; fi < 2; ++fi) {
+                    at[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[fi][s_], b[s_], at[fi], 0, 0, 0);
+                    an[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(xn[fi][s_], b[s_], an[fi], 0, 0, 0);
+                }
+        };
+        f64x4_t xa0[2], xn0[2], xa1[2], xn1[2];
+        double b0[4], b1[4];
+        load(0, xa0, xn0, b0);
+        for (int kb = 0; kb < N; kb += 32) {
+            const bool more = kb + 16 < N;
+            if (more) load(kb + 16, xa1, xn1, b1);
+            mma(xa0, xn0, b0);
+            if (more) {
+                if (kb + 32 < N) load(kb + 32, xa0, xn0, b0);
+                mma(xa1, xn1, b1);
+            }
+        }
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * fi + g + 4 * r;
+                if (cok) { t1s[row * GP_RB_LD + col] = at[fi][r]; qws[row * GP_RB_LD + col] = at[fi][r] - an[fi][r]; }
+            }
+    }
+    __syncthreads();
+    // ---- pass 2: P = T1 iK, S1 = (Q W) iK, TN = T1 N1: A fragments from LDS, one sweep over iK and N1
+    f64x4_t ap[2], as1[2], atn[2];
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) { ap[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; as1[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; atn[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+    {
+        auto loadb = [&](int kb, double (&bk)[4], double (&bn)[4]) {
+            const bool kok = kb + 4 * g < N;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                bk[s_] = (iK + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
+                bn[s_] = (N1 + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
+            }
+            if (!(kok && cok)) { bk[0] = bk[1] = bk[2] = bk[3] = 0.0; bn[0] = bn[1] = bn[2] = bn[3] = 0.0; }
+        };
+        auto mma2 = [&](int kb, const double (&bk)[4], const double (&bn)[4]) {
+            const bool kok = kb + 4 * g < N;
+            const int kc = kok ? kb + 4 * g : 0;
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi) {
+                typedef __attribute__((ext_vector_type(2))) double f64x2_t;
+                const double* tp = t1s + (16 * fi + q) * GP_RB_LD + kc;
+                const double* qp = qws + (16 * fi + q) * GP_RB_LD + kc;
+                const f64x2_t t01 = *reinterpret_cast<const f64x2_t*>(tp), t23 = *reinterpret_cast<const f64x2_t*>(tp + 2);
+                const f64x2_t q01 = *reinterpret_cast<const f64x2_t*>(qp), q23 = *reinterpret_cast<const f64x2_t*>(qp + 2);
+                double tv[4] = {t01[0], t01[1], t23[0], t23[1]}, qv[4] = {q01[0], q01[1], q23[0], q23[1]};
+                if (!kok) { tv[0] = tv[1] = tv[2] = tv[3] = 0.0; qv[0] = qv[1] = qv[2] = qv[3] = 0.0; }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    ap[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s_], bk[s_], ap[fi], 0, 0, 0);
+                    as1[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(qv[s_], bk[s_], as1[fi], 0, 0, 0);
+                    atn[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s_], bn[s_], atn[fi], 0, 0, 0);
+                }
+            }
+        };
+        double bk0[4], bn0[4], bk1[4], bn1[4];
+        loadb(0, bk0, bn0);
+        for (int kb = 0; kb < N; kb += 32) {
+            const bool more = kb + 16 < N;
+            if (more) loadb(kb + 16, bk1, bn1);
+            mma2(kb, bk0, bn0);
+            if (more) {
+                if (kb + 32 < N) loadb(kb + 32, bk0, bn0);
+                mma2(kb + 16, bk1, bn1);
+            }
+        }
+    }
+    // ---- element-wise: grad_H, G, and this wave's share of sum_j Bm[i][j] m[j]
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lr_ = 16 * fi + g + 4 * r, i = R0 + lr_;
+            double part = 0.0;
+            if (i < N && cok) {
+                const size_t e = (size_t)i * N + col;
+                const double ik = iK[e], n1 = N1[e], P = ap[fi][r], S1 = as1[fi][r], S2 = P - atn[fi][r];
+                const double Bm = P + ik;
+                a.grad_H[o + e] = 0.5 * (Bm - a.iH[o + e]);
+                const double irs = a.c * (iku[i] * ikm[col] + ikm[i] * iku[col]) - a.c * P + a.c * (S1 + S2) + (ik - n1) + ikm[i] * ikm[col];
+                a.G[o + e] = a.g_alpha * irs + a.g_beta * ik;
+                part = Bm * ms[col];
+            }
+            part += __shfl_xor(part, 8, 64);
+            part += __shfl_xor(part, 4, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 1, 64);
+            if (q == 0 && i < N) atomicAdd(&rowsum[lr_], part);
+        }
+    __syncthreads();
+    // ---- natural-gradient vectors of the block's rows (k_gp_natgrad): eight lanes per row
+    if (tid < 256) {
+        const int lr_ = tid >> 3, i = R0 + lr_, sub = tid & 7;
+        if (i < N) {
+            double kp = 0.0, hm = 0.0;
+            for (int j = sub; j < N; j += 8) {
+                kp += iK[(size_t)i * N + j] * ps[j];
+                hm += a.iH[o + (size_t)i * N + j] * ms[j];
+            }
+            kp += __shfl_xor(kp, 4, 64); kp += __shfl_xor(kp, 2, 64); kp += __shfl_xor(kp, 1, 64);
+            hm += __shfl_xor(hm, 4, 64); hm += __shfl_xor(hm, 2, 64); hm += __shfl_xor(hm, 1, 64);
+            if (sub == 0) {
+                const double bm = rowsum[lr_], gm = bm - kp, ghm = 0.5 * (bm - hm);
+                a.grad_m[ov + i] = gm;
+                a.tmp[ov + i] = hm - a.lr * (gm - 2.0 * ghm);
+            }
+        }
+    }
+}
+
 // out[l][m] = sum_b A[l][b][m] x[l][b]: the two matrix^T-vector products of the bound (Kxz^T v, V^T mu).  As batched GEMMs with
 // one column the library reads the 15.7 MB operand at 0.5 TB/s (32 us each).  One workgroup per (latent, row chunk) streams its
 // part of the slab: thread = (column m, one of 1024 / 128 row groups), partials folded through LDS.  With ONE workgroup per
@@ -1668,6 +1869,24 @@ int hlvae_gp_chain(const double* iK, const double* W, const double* HiK, const d
     static const bool wide = [] { const char* e = getenv("HL_GP_CHAIN_THREADS"); return e != nullptr && e[0] == '1'; }();   // =1024: A/B
     if (wide) k_gp_chain<1024><<<dim3(batch, 2), 1024, 0, (hipStream_t)s>>>(a);
     else k_gp_chain<512><<<dim3(batch, 2), 512, 0, (hipStream_t)s>>>(a);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_chain_rb(const double* iK, const double* W, const double* N1, const double* iH, const double* m, const double* P1,
+                      const double* u, const double* iKm, double lr, double c, double g_alpha, double g_beta, int N, int batch,
+                      double* grad_m, double* grad_H, double* tmp, double* G, hlvae_stream s) {
+    HL_REQUIRE(iK && W && N1 && iH && m && P1 && u && iKm && grad_m && grad_H && tmp && G, HLVAE_EINVAL, "gp_chain_rb: null argument");
+    HL_REQUIRE(N >= 4 && N <= GP_MMAX && N % 4 == 0 && batch >= 1, HLVAE_ESHAPE, "gp_chain_rb: N=%d (a multiple of 4, at most %d)", N, GP_MMAX);
+    const size_t smem = ((size_t)2 * 32 * GP_RB_LD + 5 * GP_MMAX + 32) * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+        HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_chain_rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    GpChainRbArgs a{iK, W, N1, iH, m, P1, u, iKm, grad_m, grad_H, tmp, G, lr, c, g_alpha, g_beta, N};
+    HL_PROF("gp_chain", (hipStream_t)s);
+    k_gp_chain_rb<<<dim3(batch, (N + 31) / 32), 512, smem, (hipStream_t)s>>>(a);
     HL_LAUNCH_CHECK();
     return 0;
 }

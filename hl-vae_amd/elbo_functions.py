@@ -328,7 +328,7 @@ class GPPriorHIP:
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
         self._serial = _os.environ.get("HL_GP_SERIAL", "0") == "1"
         self._balance = int(_os.environ.get("HL_GP_BALANCE", "2"))        # where the chain rule through K0xz runs (kl_and_grads)
-        self._chain = _os.environ.get("HL_GP_CHAIN", "1") != "0"          # the M x M algebra behind W as one launch (k_gp_chain)
+        self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
             for t in (self._theta, self.m, self._KH):
@@ -648,11 +648,18 @@ class GPPriorHIP:
                 # (elbo_functions.py:279-283) and the symmetrised K0zz gradient (G + G^T), G = -(iK R iK) + iK / 2,
                 # R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T) -- built from global sums only, i.e. replicated:
                 # each rank contributes 1 / world of it
-                _lib.check(lib.hlvae_gp_chain(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(HiK), _lib.ptr(self.H), _lib.ptr(iH), _lib.ptr(self.m),
-                                              _lib.ptr(P1), _lib.ptr(u), _C.c_double(self.ng_lr), _C.c_double(c),
-                                              _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(mm["T1"]),
-                                              _lib.ptr(mm["Bm"]), _lib.ptr(self._grad_m), _lib.ptr(self._grad_H), _lib.ptr(self._tmp),
-                                              _lib.ptr(mm["HiKW"]), _lib.ptr(Rs), _lib.ptr(mm["T1b"]), _lib.ptr(G_Kzz_s), st), "gp_chain")
+                if self._chain == 2:
+                    # by 32-row blocks from N1 = iK - iK H iK and iK m (k_gp_chain_rb): 128 workgroups that never wait for each other
+                    _lib.check(lib.hlvae_gp_chain_rb(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(N1), _lib.ptr(iH), _lib.ptr(self.m), _lib.ptr(P1),
+                                                     _lib.ptr(u), _lib.ptr(iKm), _C.c_double(self.ng_lr), _C.c_double(c),
+                                                     _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(self._grad_m),
+                                                     _lib.ptr(self._grad_H), _lib.ptr(self._tmp), _lib.ptr(G_Kzz_s), st), "gp_chain_rb")
+                else:
+                    _lib.check(lib.hlvae_gp_chain(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(HiK), _lib.ptr(self.H), _lib.ptr(iH), _lib.ptr(self.m),
+                                                  _lib.ptr(P1), _lib.ptr(u), _C.c_double(self.ng_lr), _C.c_double(c),
+                                                  _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(mm["T1"]),
+                                                  _lib.ptr(mm["Bm"]), _lib.ptr(self._grad_m), _lib.ptr(self._grad_H), _lib.ptr(self._tmp),
+                                                  _lib.ptr(mm["HiKW"]), _lib.ptr(Rs), _lib.ptr(mm["T1b"]), _lib.ptr(G_Kzz_s), st), "gp_chain")
                 _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
                                                    _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
                            "gp_param_grad(Kzz)")

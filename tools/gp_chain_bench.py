@@ -31,8 +31,16 @@ def separate(o):
     bmm(HiK, W, o["HiKW"])
     _lib.check(lib.hlvae_gp_rsym(p(u), p(m), p(W), p(o["HiKW"]), p(H), C.c_double(c), M, L, p(o["Rs"]), st), "rsym")
     bmm(iK, o["Rs"], o["T1b"]); bmm(o["T1b"], iK, o["G"], D=iK, alpha=ga, beta=gb)
-oa, ob = outs(), outs()
-fused(oa); separate(ob); torch.cuda.synchronize()
+N1 = (iK - iK @ HiK).contiguous()
+iKm = (iK @ m.unsqueeze(2)).squeeze(2).contiguous()
+def rowblocks(o):
+    _lib.check(lib.hlvae_gp_chain_rb(p(iK), p(W), p(N1), p(iH), p(m), p(P1), p(u), p(iKm), C.c_double(lr), C.c_double(c), C.c_double(ga), C.c_double(gb),
+                                     M, L, p(o["grad_m"]), p(o["grad_H"]), p(o["tmp"]), p(o["G"]), st), "chain_rb")
+oa, ob, oc = outs(), outs(), outs()
+fused(oa); separate(ob); rowblocks(oc); torch.cuda.synchronize()
+for k in ("grad_m", "grad_H", "tmp", "G"):
+    d = (oc[k] - ob[k]).abs().max().item() / max(ob[k].abs().max().item(), 1e-300)
+    print(f"  row blocks {k:7s} max rel diff {d:.2e}")
 for k in oa:
     d = (oa[k] - ob[k]).abs().max().item() / max(ob[k].abs().max().item(), 1e-300)
     print(f"  {k:7s} max rel diff {d:.2e}")
@@ -42,4 +50,4 @@ def timeit(f, o):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); f(o); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
     ts.sort(); return ts[len(ts) // 2]
-print(f"M={M}: k_gp_chain {timeit(fused, oa):.1f} us; separate launches {timeit(separate, ob):.1f} us")
+print(f"M={M}: k_gp_chain {timeit(fused, oa):.1f} us; k_gp_chain_rb {timeit(rowblocks, oc):.1f} us; separate launches {timeit(separate, ob):.1f} us")
