@@ -133,7 +133,7 @@ _SIGS = {
     "hlvae_gp_gkxz": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_rsym": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_chain": (C.c_int, [_vp] * 8 + [C.c_double] * 4 + [C.c_int, C.c_int] + [_vp] * 9 + [_vp]),
-    "hlvae_gp_chain_rb": (C.c_int, [_vp] * 8 + [C.c_double] * 4 + [C.c_int, C.c_int] + [_vp] * 4 + [_vp]),
+    "hlvae_gp_chain_rb": (C.c_int, [_vp] * 8 + [C.c_double] * 4 + [C.c_int, C.c_int] + [_vp] * 5 + [_vp]),
     "hlvae_gp_bound": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                  C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "hlvae_gp_adam": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),

@@ -1356,191 +1356,199 @@ __global__ __launch_bounds__(THREADS) void k_gp_chain(GpChainArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// The same algebra by ROW BLOCKS (round 3, second form): with Q = iK H iK = iK - N1 (N1 = iK - iK H iK is in hand from the state
-// stage), T1 = iK W and symmetric iK, W, H,
-//     iK (H iK W) iK = Q W iK,      iK (H iK W)^T iK = iK W Q = T1 Q,      iK H iK = Q,      iK W iK = T1 iK
-// so every 32-row block of Bm = T1 iK + iK and of G = g_alpha iK Rs iK + g_beta iK,
-//     iK Rs iK = c [(iK u)(iK m)^T + (iK m)(iK u)^T] - c T1 iK + c (Q W iK + T1 Q) + Q + (iK m)(iK m)^T,
-// needs only ITS rows of T1 = iK W and Q W: no product of one row block reads another block's result.  One workgroup per
-// (latent, 32-row block): 4 x 32 = 128 workgroups that never synchronise with each other, five 32 x N x N product passes each
-// (k_gp_chain: 64 workgroups x up to three N x N x N products), the two intermediate row blocks in LDS.
+// The same algebra by ROW BLOCKS (round 3, second form).  A 32-row block of T1 = iK W, Bm = T1 iK + iK, X = (H iK) W and
+// X^T = W (H iK)^T needs no other block's results, so launch 1 gives one workgroup per (latent, row block) the natural-gradient
+// outputs and its rows of Rs = c (u m^T + m u^T - W + X + X^T) + H + m m^T; launch 2 does the same for T1b = iK Rs and
+// G = g_alpha T1b iK + g_beta iK once Rs is whole.  2 x 128 workgroups that never wait for each other, six 32 x N x N product
+// passes in all, intermediate row blocks in LDS -- 42 us alone where k_gp_chain takes 97 (64 workgroups, up to three dependent
+// N x N x N products each) and the eight separate launches 79.
+// (An expanded form -- iK Rs iK = c [..] - c T1 iK + c (Q W iK + T1 Q) + Q + .. with Q = iK H iK, five passes in ONE launch -- was
+//  built first and is algebraically equal, but it cancels AFTER the multiplication by iK instead of inside Rs: on the
+//  config-5 matrices (condition 1e8) the inducing-point gradient lost its sign in 15 % of the large entries.)
 // grid (batch, ceil(N / 32)), 512 threads: wave w owns output columns 16 w .. 16 w + 15 of both 16-row halves.
-#define GP_RB_LD 122                                          // LDS row stride of the intermediate row blocks (16-byte aligned rows)
+#define GP_RB_LD 122                                          // LDS row stride of the intermediate row block (16-byte aligned rows)
 struct GpChainRbArgs {
-    const double *iK, *W, *N1, *iH, *m, *P1, *u, *iKm;
-    double *grad_m, *grad_H, *tmp, *G;
+    const double *iK, *W, *HiK, *H, *iH, *m, *P1, *u;
+    double *grad_m, *grad_H, *tmp, *Rs, *G;
     double lr, c, g_alpha, g_beta;
     int N;
 };
-__global__ __launch_bounds__(512) void k_gp_chain_rb(GpChainRbArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double rb_sm[];
-    double* t1s = rb_sm;                                      // T1 rows   [32][GP_RB_LD]
-    double* qws = t1s + 32 * GP_RB_LD;                        // (Q W) rows
-    double* ms = qws + 32 * GP_RB_LD;                         // m, P1, u, iK m, iK u   [GP_MMAX] each
-    double* ps = ms + GP_MMAX;
-    double* us = ps + GP_MMAX;
-    double* ikm = us + GP_MMAX;
-    double* iku = ikm + GP_MMAX;
-    double* rowsum = iku + GP_MMAX;                           // sum_j Bm[i][j] m[j] of the block's rows  [32]
-    const int l = blockIdx.x, R0 = 32 * blockIdx.y, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, q = lane & 15;
-    const size_t o = (size_t)l * N * N, ov = (size_t)l * N;
-    const double* iK = a.iK + o;
-    const double* W = a.W + o;
-    const double* N1 = a.N1 + o;
-    if (tid < N) { ms[tid] = a.m[ov + tid]; ps[tid] = a.P1[ov + tid]; us[tid] = a.u[ov + tid]; ikm[tid] = a.iKm[ov + tid]; }
-    if (tid < 32) rowsum[tid] = 0.0;
-    __syncthreads();
-    for (int i = tid >> 3; i < N; i += 64) {                  // iK u, all rows (eight lanes per row)
-        double s_ = 0.0;
-        for (int j = tid & 7; j < N; j += 8) s_ += iK[(size_t)i * N + j] * us[j];
-        s_ += __shfl_xor(s_, 4, 64);
-        s_ += __shfl_xor(s_, 2, 64);
-        s_ += __shfl_xor(s_, 1, 64);
-        if ((tid & 7) == 0) iku[i] = s_;
-    }
-    const int col = 16 * wave + q;
-    const bool cok = col < N;
-    const unsigned offb = (unsigned)(4 * g * N + min(col, N - 1));
+// one sweep over a k-major B operand (B[k][col], rows of N) with up to two A operands read from global rows (A0, A1: [row][k]) and
+// optionally a second B given TRANSPOSED (Bt[col][k]) paired with A1 -- accumulators acc0 += A0 B, acc1 += A1 (Bt ? Bt^T : B)
+template <bool USE0, bool TWO_A, bool TRANS_B1>
+__device__ __forceinline__ void gp_rb_sweep_global(const double* __restrict__ A0, const double* __restrict__ A1,
+                                                   const double* __restrict__ B, const double* __restrict__ Bt, int N, int R0,
+                                                   int col, bool cok, int g, int q, f64x4_t (&acc0)[2], f64x4_t (&acc1)[2]) {
     bool rok[2];
     unsigned offa[2];
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi) { rok[fi] = R0 + 16 * fi + q < N; offa[fi] = (unsigned)(min(R0 + 16 * fi + q, N - 1) * N + 4 * g); }
-    // ---- pass 1: T1 rows = iK[R] W and (N1 W) rows, one sweep over W
-    {
-        f64x4_t at[2], an[2];
+    const unsigned offb = (unsigned)(4 * g * N + min(col, N - 1)), offbt = (unsigned)(min(col, N - 1) * N + 4 * g);
+    auto load = [&](int kb, f64x4_t (&x0)[2], f64x4_t (&x1)[2], double (&b)[4], f64x4_t& bt) {
+        const bool kok = kb + 4 * g < N;
 #pragma unroll
-        for (int fi = 0; fi < 2; ++fi) { at[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; an[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
-        auto load = [&](int kb, f64x4_t (&xa)[2], f64x4_t (&xn)[2], double (&b)[4]) {
-            const bool kok = kb + 4 * g < N;
+        for (int fi = 0; fi < 2; ++fi) {
+            if (USE0) x0[fi] = *reinterpret_cast<const f64x4_t*>(A0 + kb + (kok ? offa[fi] : 0u));
+            if (TWO_A) x1[fi] = *reinterpret_cast<const f64x4_t*>(A1 + kb + (kok ? offa[fi] : 0u));
+        }
+        if (USE0 || !TRANS_B1)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) b[s_] = (B + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
+        if (TRANS_B1) bt = *reinterpret_cast<const f64x4_t*>(Bt + kb + (kok ? offbt : 0u));
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+            if (!(kok && rok[fi])) { if (USE0) x0[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; if (TWO_A) x1[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+        if (!(kok && cok)) { if (USE0 || !TRANS_B1) { b[0] = b[1] = b[2] = b[3] = 0.0; } if (TRANS_B1) bt = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+    };
+    auto mma = [&](const f64x4_t (&x0)[2], const f64x4_t (&x1)[2], const double (&b)[4], const f64x4_t& bt) {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
             for (int fi = 0; fi < 2; ++fi) {
-                xa[fi] = *reinterpret_cast<const f64x4_t*>(iK + kb + (kok ? offa[fi] : 0u));
-                xn[fi] = *reinterpret_cast<const f64x4_t*>(N1 + kb + (kok ? offa[fi] : 0u));
+                if (USE0) acc0[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[fi][s_], b[s_], acc0[fi], 0, 0, 0);
+                if (TWO_A) acc1[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[fi][s_], TRANS_B1 ? bt[s_] : b[s_], acc1[fi], 0, 0, 0);
             }
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) b[s_] = (W + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
-#pragma unroll
-            for (int fi = 0; fi < 2; ++fi)
-                if (!(kok && rok[fi])) { xa[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; xn[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
-            if (!(kok && cok)) { b[0] = b[1] = b[2] = b[3] = 0.0; }
-        };
-        auto mma = [&](const f64x4_t (&xa)[2], const f64x4_t (&xn)[2], const double (&b)[4]) {
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-                for (int fi = 0; fi < 2; ++fi) {
-                    at[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[fi][s_], b[s_], at[fi], 0, 0, 0);
-                    an[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(xn[fi][s_], b[s_], an[fi], 0, 0, 0);
-                }
-        };
-        f64x4_t xa0[2], xn0[2], xa1[2], xn1[2];
-        double b0[4], b1[4];
-        load(0, xa0, xn0, b0);
-        for (int kb = 0; kb < N; kb += 32) {
-            const bool more = kb + 16 < N;
-            if (more) load(kb + 16, xa1, xn1, b1);
-            mma(xa0, xn0, b0);
-            if (more) {
-                if (kb + 32 < N) load(kb + 32, xa0, xn0, b0);
-                mma(xa1, xn1, b1);
-            }
+    };
+    f64x4_t xa0[2], xb0[2], xa1[2], xb1[2], bt0, bt1;
+    double b0[4], b1[4];
+    load(0, xa0, xb0, b0, bt0);
+    for (int kb = 0; kb < N; kb += 32) {
+        const bool more = kb + 16 < N;
+        if (more) load(kb + 16, xa1, xb1, b1, bt1);
+        mma(xa0, xb0, b0, bt0);
+        if (more) {
+            if (kb + 32 < N) load(kb + 32, xa0, xb0, b0, bt0);
+            mma(xa1, xb1, b1, bt1);
         }
+    }
+}
+// acc += (LDS row block [32][GP_RB_LD]) B, B k-major in global memory
+__device__ __forceinline__ void gp_rb_sweep_lds(const double* As, const double* __restrict__ B, int N, int col, bool cok, int g, int q,
+                                                f64x4_t (&acc)[2]) {
+    typedef __attribute__((ext_vector_type(2))) double f64x2_t;
+    const unsigned offb = (unsigned)(4 * g * N + min(col, N - 1));
+    auto loadb = [&](int kb, double (&b)[4]) {
+        const bool kok = kb + 4 * g < N;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) b[s_] = (B + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
+        if (!(kok && cok)) { b[0] = b[1] = b[2] = b[3] = 0.0; }
+    };
+    auto mma = [&](int kb, const double (&b)[4]) {
+        const bool kok = kb + 4 * g < N;
+        const int kc = kok ? kb + 4 * g : 0;
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            const double* tp = As + (16 * fi + q) * GP_RB_LD + kc;
+            const f64x2_t t01 = *reinterpret_cast<const f64x2_t*>(tp), t23 = *reinterpret_cast<const f64x2_t*>(tp + 2);
+            double tv[4] = {t01[0], t01[1], t23[0], t23[1]};
+            if (!kok) { tv[0] = tv[1] = tv[2] = tv[3] = 0.0; }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) acc[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s_], b[s_], acc[fi], 0, 0, 0);
+        }
+    };
+    double b0[4], b1[4];
+    loadb(0, b0);
+    for (int kb = 0; kb < N; kb += 32) {
+        const bool more = kb + 16 < N;
+        if (more) loadb(kb + 16, b1);
+        mma(kb, b0);
+        if (more) {
+            if (kb + 32 < N) loadb(kb + 32, b0);
+            mma(kb + 16, b1);
+        }
+    }
+}
+template <int PHASE>
+__global__ __launch_bounds__(512) void k_gp_chain_rb(GpChainRbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double rb_sm[];
+    double* t1s = rb_sm;                                      // T1 (phase 1) / T1b (phase 2) rows   [32][GP_RB_LD]
+    double* ms = t1s + 32 * GP_RB_LD;                         // m, P1, u   [GP_MMAX] each
+    double* ps = ms + GP_MMAX;
+    double* us = ps + GP_MMAX;
+    double* rowsum = us + GP_MMAX;                            // sum_j Bm[i][j] m[j] of the block's rows  [32]
+    const int l = blockIdx.x, R0 = 32 * blockIdx.y, N = a.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, q = lane & 15, col = 16 * wave + q;
+    const bool cok = col < N;
+    const size_t o = (size_t)l * N * N, ov = (size_t)l * N;
+    const double* iK = a.iK + o;
+    f64x4_t z2[2] = {f64x4_t{0.0, 0.0, 0.0, 0.0}, f64x4_t{0.0, 0.0, 0.0, 0.0}};
+    if (PHASE == 1) {
+        const double* W = a.W + o;
+        const double* HiK = a.HiK + o;
+        if (tid < N) { ms[tid] = a.m[ov + tid]; ps[tid] = a.P1[ov + tid]; us[tid] = a.u[ov + tid]; }
+        if (tid < 32) rowsum[tid] = 0.0;
+        // sweep over W: T1 rows = iK[R] W, X rows = HiK[R] W
+        f64x4_t at[2] = {z2[0], z2[1]}, ax[2] = {z2[0], z2[1]};
+        gp_rb_sweep_global<true, true, false>(iK, HiK, W, nullptr, N, R0, col, cok, g, q, at, ax);
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (cok) t1s[(16 * fi + g + 4 * r) * GP_RB_LD + col] = at[fi][r];
+        __syncthreads();
+        // P = T1 iK (A from LDS);  X^T rows = W[R] (H iK)^T (B transposed)
+        f64x4_t ap[2] = {z2[0], z2[1]}, axt[2] = {z2[0], z2[1]}, dum[2] = {z2[0], z2[1]};
+        gp_rb_sweep_lds(t1s, iK, N, col, cok, g, q, ap);
+        gp_rb_sweep_global<false, true, true>(W, W, iK, HiK, N, R0, col, cok, g, q, dum, axt);
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * fi + g + 4 * r;
-                if (cok) { t1s[row * GP_RB_LD + col] = at[fi][r]; qws[row * GP_RB_LD + col] = at[fi][r] - an[fi][r]; }
+                const int lr_ = 16 * fi + g + 4 * r, i = R0 + lr_;
+                double part = 0.0;
+                if (i < N && cok) {
+                    const size_t e = (size_t)i * N + col;
+                    const double Bm = ap[fi][r] + iK[e];
+                    a.grad_H[o + e] = 0.5 * (Bm - a.iH[o + e]);
+                    a.Rs[o + e] = a.c * (us[i] * ms[col] + ms[i] * us[col] - W[e] + ax[fi][r] + axt[fi][r]) + a.H[o + e] + ms[i] * ms[col];
+                    part = Bm * ms[col];
+                }
+                part += __shfl_xor(part, 8, 64);
+                part += __shfl_xor(part, 4, 64);
+                part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 1, 64);
+                if (q == 0 && i < N) atomicAdd(&rowsum[lr_], part);
             }
-    }
-    __syncthreads();
-    // ---- pass 2: P = T1 iK, S1 = (Q W) iK, TN = T1 N1: A fragments from LDS, one sweep over iK and N1
-    f64x4_t ap[2], as1[2], atn[2];
-#pragma unroll
-    for (int fi = 0; fi < 2; ++fi) { ap[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; as1[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; atn[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
-    {
-        auto loadb = [&](int kb, double (&bk)[4], double (&bn)[4]) {
-            const bool kok = kb + 4 * g < N;
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                bk[s_] = (iK + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
-                bn[s_] = (N1 + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
-            }
-            if (!(kok && cok)) { bk[0] = bk[1] = bk[2] = bk[3] = 0.0; bn[0] = bn[1] = bn[2] = bn[3] = 0.0; }
-        };
-        auto mma2 = [&](int kb, const double (&bk)[4], const double (&bn)[4]) {
-            const bool kok = kb + 4 * g < N;
-            const int kc = kok ? kb + 4 * g : 0;
-#pragma unroll
-            for (int fi = 0; fi < 2; ++fi) {
-                typedef __attribute__((ext_vector_type(2))) double f64x2_t;
-                const double* tp = t1s + (16 * fi + q) * GP_RB_LD + kc;
-                const double* qp = qws + (16 * fi + q) * GP_RB_LD + kc;
-                const f64x2_t t01 = *reinterpret_cast<const f64x2_t*>(tp), t23 = *reinterpret_cast<const f64x2_t*>(tp + 2);
-                const f64x2_t q01 = *reinterpret_cast<const f64x2_t*>(qp), q23 = *reinterpret_cast<const f64x2_t*>(qp + 2);
-                double tv[4] = {t01[0], t01[1], t23[0], t23[1]}, qv[4] = {q01[0], q01[1], q23[0], q23[1]};
-                if (!kok) { tv[0] = tv[1] = tv[2] = tv[3] = 0.0; qv[0] = qv[1] = qv[2] = qv[3] = 0.0; }
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) {
-                    ap[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s_], bk[s_], ap[fi], 0, 0, 0);
-                    as1[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(qv[s_], bk[s_], as1[fi], 0, 0, 0);
-                    atn[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s_], bn[s_], atn[fi], 0, 0, 0);
+        __syncthreads();
+        if (tid < 256) {                                      // natural-gradient vectors of the block's rows (k_gp_natgrad)
+            const int lr_ = tid >> 3, i = R0 + lr_, sub = tid & 7;
+            if (i < N) {
+                double kp = 0.0, hm = 0.0;
+                for (int j = sub; j < N; j += 8) {
+                    kp += iK[(size_t)i * N + j] * ps[j];
+                    hm += a.iH[o + (size_t)i * N + j] * ms[j];
+                }
+                kp += __shfl_xor(kp, 4, 64); kp += __shfl_xor(kp, 2, 64); kp += __shfl_xor(kp, 1, 64);
+                hm += __shfl_xor(hm, 4, 64); hm += __shfl_xor(hm, 2, 64); hm += __shfl_xor(hm, 1, 64);
+                if (sub == 0) {
+                    const double bm = rowsum[lr_], gm = bm - kp, ghm = 0.5 * (bm - hm);
+                    a.grad_m[ov + i] = gm;
+                    a.tmp[ov + i] = hm - a.lr * (gm - 2.0 * ghm);
                 }
             }
-        };
-        double bk0[4], bn0[4], bk1[4], bn1[4];
-        loadb(0, bk0, bn0);
-        for (int kb = 0; kb < N; kb += 32) {
-            const bool more = kb + 16 < N;
-            if (more) loadb(kb + 16, bk1, bn1);
-            mma2(kb, bk0, bn0);
-            if (more) {
-                if (kb + 32 < N) loadb(kb + 32, bk0, bn0);
-                mma2(kb + 16, bk1, bn1);
-            }
         }
-    }
-    // ---- element-wise: grad_H, G, and this wave's share of sum_j Bm[i][j] m[j]
+    } else {
+        const double* Rs = a.Rs + o;
+        f64x4_t at[2] = {z2[0], z2[1]}, dum[2] = {z2[0], z2[1]};
+        gp_rb_sweep_global<true, false, false>(iK, nullptr, Rs, nullptr, N, R0, col, cok, g, q, at, dum);      // T1b rows = iK[R] Rs
 #pragma unroll
-    for (int fi = 0; fi < 2; ++fi)
+        for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int lr_ = 16 * fi + g + 4 * r, i = R0 + lr_;
-            double part = 0.0;
-            if (i < N && cok) {
-                const size_t e = (size_t)i * N + col;
-                const double ik = iK[e], n1 = N1[e], P = ap[fi][r], S1 = as1[fi][r], S2 = P - atn[fi][r];
-                const double Bm = P + ik;
-                a.grad_H[o + e] = 0.5 * (Bm - a.iH[o + e]);
-                const double irs = a.c * (iku[i] * ikm[col] + ikm[i] * iku[col]) - a.c * P + a.c * (S1 + S2) + (ik - n1) + ikm[i] * ikm[col];
-                a.G[o + e] = a.g_alpha * irs + a.g_beta * ik;
-                part = Bm * ms[col];
+            for (int r = 0; r < 4; ++r)
+                if (cok) t1s[(16 * fi + g + 4 * r) * GP_RB_LD + col] = at[fi][r];
+        __syncthreads();
+        f64x4_t ag[2] = {z2[0], z2[1]};
+        gp_rb_sweep_lds(t1s, iK, N, col, cok, g, q, ag);
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = R0 + 16 * fi + g + 4 * r;
+                if (i < N && cok) {
+                    const size_t e = (size_t)i * N + col;
+                    a.G[o + e] = a.g_alpha * ag[fi][r] + a.g_beta * iK[e];
+                }
             }
-            part += __shfl_xor(part, 8, 64);
-            part += __shfl_xor(part, 4, 64);
-            part += __shfl_xor(part, 2, 64);
-            part += __shfl_xor(part, 1, 64);
-            if (q == 0 && i < N) atomicAdd(&rowsum[lr_], part);
-        }
-    __syncthreads();
-    // ---- natural-gradient vectors of the block's rows (k_gp_natgrad): eight lanes per row
-    if (tid < 256) {
-        const int lr_ = tid >> 3, i = R0 + lr_, sub = tid & 7;
-        if (i < N) {
-            double kp = 0.0, hm = 0.0;
-            for (int j = sub; j < N; j += 8) {
-                kp += iK[(size_t)i * N + j] * ps[j];
-                hm += a.iH[o + (size_t)i * N + j] * ms[j];
-            }
-            kp += __shfl_xor(kp, 4, 64); kp += __shfl_xor(kp, 2, 64); kp += __shfl_xor(kp, 1, 64);
-            hm += __shfl_xor(hm, 4, 64); hm += __shfl_xor(hm, 2, 64); hm += __shfl_xor(hm, 1, 64);
-            if (sub == 0) {
-                const double bm = rowsum[lr_], gm = bm - kp, ghm = 0.5 * (bm - hm);
-                a.grad_m[ov + i] = gm;
-                a.tmp[ov + i] = hm - a.lr * (gm - 2.0 * ghm);
-            }
-        }
     }
 }
 
@@ -1873,20 +1881,17 @@ int hlvae_gp_chain(const double* iK, const double* W, const double* HiK, const d
     return 0;
 }
 
-int hlvae_gp_chain_rb(const double* iK, const double* W, const double* N1, const double* iH, const double* m, const double* P1,
-                      const double* u, const double* iKm, double lr, double c, double g_alpha, double g_beta, int N, int batch,
-                      double* grad_m, double* grad_H, double* tmp, double* G, hlvae_stream s) {
-    HL_REQUIRE(iK && W && N1 && iH && m && P1 && u && iKm && grad_m && grad_H && tmp && G, HLVAE_EINVAL, "gp_chain_rb: null argument");
+int hlvae_gp_chain_rb(const double* iK, const double* W, const double* HiK, const double* H, const double* iH, const double* m,
+                      const double* P1, const double* u, double lr, double c, double g_alpha, double g_beta, int N, int batch,
+                      double* grad_m, double* grad_H, double* tmp, double* Rs, double* G, hlvae_stream s) {
+    HL_REQUIRE(iK && W && HiK && H && iH && m && P1 && u && grad_m && grad_H && tmp && Rs && G, HLVAE_EINVAL, "gp_chain_rb: null argument");
     HL_REQUIRE(N >= 4 && N <= GP_MMAX && N % 4 == 0 && batch >= 1, HLVAE_ESHAPE, "gp_chain_rb: N=%d (a multiple of 4, at most %d)", N, GP_MMAX);
-    const size_t smem = ((size_t)2 * 32 * GP_RB_LD + 5 * GP_MMAX + 32) * sizeof(double);
-    static bool attr = false;
-    if (!attr) {
-        HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_chain_rb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
-    GpChainRbArgs a{iK, W, N1, iH, m, P1, u, iKm, grad_m, grad_H, tmp, G, lr, c, g_alpha, g_beta, N};
+    const size_t smem = ((size_t)32 * GP_RB_LD + 3 * GP_MMAX + 32) * sizeof(double);
+    GpChainRbArgs a{iK, W, HiK, H, iH, m, P1, u, grad_m, grad_H, tmp, Rs, G, lr, c, g_alpha, g_beta, N};
+    const dim3 grid(batch, (N + 31) / 32);
     HL_PROF("gp_chain", (hipStream_t)s);
-    k_gp_chain_rb<<<dim3(batch, (N + 31) / 32), 512, smem, (hipStream_t)s>>>(a);
+    k_gp_chain_rb<1><<<grid, 512, smem, (hipStream_t)s>>>(a);
+    k_gp_chain_rb<2><<<grid, 512, smem, (hipStream_t)s>>>(a);
     HL_LAUNCH_CHECK();
     return 0;
 }

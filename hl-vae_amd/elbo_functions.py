@@ -649,11 +649,12 @@ class GPPriorHIP:
                 # R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T) -- built from global sums only, i.e. replicated:
                 # each rank contributes 1 / world of it
                 if self._chain == 2:
-                    # by 32-row blocks from N1 = iK - iK H iK and iK m (k_gp_chain_rb): 128 workgroups that never wait for each other
-                    _lib.check(lib.hlvae_gp_chain_rb(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(N1), _lib.ptr(iH), _lib.ptr(self.m), _lib.ptr(P1),
-                                                     _lib.ptr(u), _lib.ptr(iKm), _C.c_double(self.ng_lr), _C.c_double(c),
+                    # by 32-row blocks, two launches (k_gp_chain_rb): 2 x 128 workgroups that never wait for each other
+                    _lib.check(lib.hlvae_gp_chain_rb(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(HiK), _lib.ptr(self.H), _lib.ptr(iH), _lib.ptr(self.m),
+                                                     _lib.ptr(P1), _lib.ptr(u), _C.c_double(self.ng_lr), _C.c_double(c),
                                                      _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(self._grad_m),
-                                                     _lib.ptr(self._grad_H), _lib.ptr(self._tmp), _lib.ptr(G_Kzz_s), st), "gp_chain_rb")
+                                                     _lib.ptr(self._grad_H), _lib.ptr(self._tmp), _lib.ptr(Rs), _lib.ptr(G_Kzz_s), st),
+                               "gp_chain_rb")
                 else:
                     _lib.check(lib.hlvae_gp_chain(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(HiK), _lib.ptr(self.H), _lib.ptr(iH), _lib.ptr(self.m),
                                                   _lib.ptr(P1), _lib.ptr(u), _C.c_double(self.ng_lr), _C.c_double(c),

@@ -440,12 +440,12 @@ int hlvae_gp_chain(const double* iK, const double* W, const double* HiK, const d
                    const double* P1, const double* u, double lr, double c, double g_alpha, double g_beta, int N, int batch,
                    double* T1, double* Bm, double* grad_m, double* grad_H, double* tmp, double* HiKW, double* Rs, double* T1b,
                    double* G, hlvae_stream s);
-/* The same outputs (grad_m, grad_H, tmp, G) by 32-row blocks, from N1 = iK - iK H iK and iKm = iK m of the state stage: with
- * Q = iK - N1 and T1 = iK W,  iK Rs iK = c [(iK u) iKm^T + iKm (iK u)^T] - c T1 iK + c (Q W iK + T1 Q) + Q + iKm iKm^T, every row
- * block of which needs only its own rows of T1 and Q W.  grid (batch, ceil(N / 32)): no workgroup waits for another. */
-int hlvae_gp_chain_rb(const double* iK, const double* W, const double* N1, const double* iH, const double* m, const double* P1,
-                      const double* u, const double* iKm, double lr, double c, double g_alpha, double g_beta, int N, int batch,
-                      double* grad_m, double* grad_H, double* tmp, double* G, hlvae_stream s);
+/* The same outputs (grad_m, grad_H, tmp, G; Rs as a caller buffer) by 32-row blocks in two launches of grid (batch, ceil(N / 32)):
+ * a row block of T1, Bm, H iK W and W (H iK)^T needs no other block; the second launch multiplies the completed Rs from both
+ * sides.  No workgroup waits for another. */
+int hlvae_gp_chain_rb(const double* iK, const double* W, const double* HiK, const double* H, const double* iH, const double* m,
+                      const double* P1, const double* u, double lr, double c, double g_alpha, double g_beta, int N, int batch,
+                      double* grad_m, double* grad_H, double* tmp, double* Rs, double* G, hlvae_stream s);
 /* torch.optim.Adam step (HLVAE_main.py:277-278) on a flat fp64 arena (hyper-parameters + inducing points, n <= ~1e5);
  * step: device int64[2] = {completed steps, 0}, advanced by the kernel; the consumed gradients are zeroed. */
 int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,

@@ -31,14 +31,12 @@ def separate(o):
     bmm(HiK, W, o["HiKW"])
     _lib.check(lib.hlvae_gp_rsym(p(u), p(m), p(W), p(o["HiKW"]), p(H), C.c_double(c), M, L, p(o["Rs"]), st), "rsym")
     bmm(iK, o["Rs"], o["T1b"]); bmm(o["T1b"], iK, o["G"], D=iK, alpha=ga, beta=gb)
-N1 = (iK - iK @ HiK).contiguous()
-iKm = (iK @ m.unsqueeze(2)).squeeze(2).contiguous()
 def rowblocks(o):
-    _lib.check(lib.hlvae_gp_chain_rb(p(iK), p(W), p(N1), p(iH), p(m), p(P1), p(u), p(iKm), C.c_double(lr), C.c_double(c), C.c_double(ga), C.c_double(gb),
-                                     M, L, p(o["grad_m"]), p(o["grad_H"]), p(o["tmp"]), p(o["G"]), st), "chain_rb")
+    _lib.check(lib.hlvae_gp_chain_rb(p(iK), p(W), p(HiK), p(H), p(iH), p(m), p(P1), p(u), C.c_double(lr), C.c_double(c), C.c_double(ga), C.c_double(gb),
+                                     M, L, p(o["grad_m"]), p(o["grad_H"]), p(o["tmp"]), p(o["Rs"]), p(o["G"]), st), "chain_rb")
 oa, ob, oc = outs(), outs(), outs()
 fused(oa); separate(ob); rowblocks(oc); torch.cuda.synchronize()
-for k in ("grad_m", "grad_H", "tmp", "G"):
+for k in ("grad_m", "grad_H", "tmp", "Rs", "G"):
     d = (oc[k] - ob[k]).abs().max().item() / max(ob[k].abs().max().item(), 1e-300)
     print(f"  row blocks {k:7s} max rel diff {d:.2e}")
 for k in oa:
