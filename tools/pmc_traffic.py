@@ -19,7 +19,8 @@ KERNELS = {
     "normalize_pack": ("k_pack_compact", None),
     "dW1_dWd_dWmu": ("k_gemm_f32_group", None),
     "conv_enc_bwd": ("k_conv_enc_bwd", None),
-    "gp_param_grad": ("k_gp_param_grad", None),
+    "gp_param_grad": ("k_gp_param_grad", "max"),
+    "gp_chain": ("k_gp_chain_rb<1>", None),
     "gp_spd_inv": ("k_gp_spd_inv", None),
     "gp_gemm": ("k_gp_gemm", "max"),
     "gp_subject_fwd": ("k_gp_subject_fwd", None),
