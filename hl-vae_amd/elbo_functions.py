@@ -326,7 +326,7 @@ class GPPriorHIP:
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         self._prep, self._prep_stream, self._tail_pending = None, None, False
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
-        self._prep_pre = False
+        self._ahead_pre, self._prep_pre = None, False
         self._ahead_subject = _os.environ.get("HL_GP_AHEAD_SUBJECT", "1") != "0"
         self._serial = _os.environ.get("HL_GP_SERIAL", "0") == "1"
         self._balance = int(_os.environ.get("HL_GP_BALANCE", "2"))        # where the chain rule through K0xz runs (kl_and_grads)
@@ -473,28 +473,11 @@ class GPPriorHIP:
                 x, Kxz = x.contiguous(), None
             idx = groups if groups is not None else self._group(x)
             st_ = self._prepare_state(x, idx.shape[0], idx.shape[1], x.shape[0], dev, Kxz=Kxz)
-        self._prep_pre = False
-        if use_ahead and self._fuse_sums and self._ahead_subject:
-            # the state-only half of the per-subject kernel (covariances, B_st inverse, V = iB Ks: 2/3 of its time) needs K0xz and the
-            # hyper-parameters but neither iK nor the encoder's outputs: with K0xz computed ahead it starts HERE, on a stream of its
-            # own beside the iK-products above and the VAE's forward pass; kl_and_grads runs the other half (mode 2)
-            S, T = idx.shape
-            buf = st_[0]
-            sA, _ = self._streams(dev)
-            sA.wait_stream(main)
-            sA.wait_stream(self._ahead_stream)
-            with torch.cuda.stream(sA):
-                lib, st = _lib.load(), self._stream()
-                _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(self.k0), _C.byref(self.k1), _lib.ptr(self._hyp), self.n_slots, self.L, self.Q,
-                                                    _lib.ptr(x), _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(Kxz), x.shape[0], self.M,
-                                                    None, None, _C.c_double(0.0), _lib.ptr(buf["iB"]), _lib.ptr(buf["K0s"]),
-                                                    _lib.ptr(buf["V"]), _lib.ptr(buf["v"]), _lib.ptr(buf["part"]), _lib.ptr(buf["g_mu"]),
-                                                    _lib.ptr(buf["g_lv"]), None, None, None, None, 1, st), "gp_subject_fwd(pre)")
-            self._prep_pre = True
+        self._prep_pre = bool(use_ahead and self._ahead_pre is not None and self._ahead_pre == (idx.data_ptr(), tuple(idx.shape)))
         self._prep = (x, idx) + st_
         return x
 
-    def compute_ahead(self, labels, rows):
+    def compute_ahead(self, labels, rows, groups=None):
         """Covariate gather + K0xz of a FOLLOWING batch on a stream of their own, forked from the caller's here.  Called by
         ``optimizer_step(next_batch=...)`` right behind the hyper-parameter transform: K0xz of the next batch needs the updated
         hyper-parameters and inducing points but not the batched inversion, so its 31 MB kernel matrix (55 us inside the step at
@@ -512,9 +495,22 @@ class GPPriorHIP:
             ab = (torch.empty(B, labels.shape[1], dtype=torch.float64, device=dev),
                   torch.empty(self.L, B, self.M, dtype=torch.float64, device=dev))
             self._ahead_bufs[B] = ab
+        self._ahead_pre = None
         with torch.cuda.stream(sK):
             torch.index_select(labels, 0, rows.long(), out=ab[0])
             self.kernel_matrix(self.k0, ab[0], self.zt_list, out=ab[1])
+            if groups is not None and self._fuse_sums and self._ahead_subject:
+                # the state-only half of the per-subject kernel too (covariances, B_st inverse, V = iB Ks: 2/3 of its time), into
+                # the step buffers of the next batch's geometry -- free here: the chains that read them have been joined
+                S, T = groups.shape
+                buf = self._step_buffers(B, S, T, dev)
+                lib, st = _lib.load(), self._stream()
+                _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(self.k0), _C.byref(self.k1), _lib.ptr(self._hyp), self.n_slots, self.L, self.Q,
+                                                    _lib.ptr(ab[0]), _lib.ptr(self.noise), _lib.ptr(groups), S, T, _lib.ptr(ab[1]), B, self.M,
+                                                    None, None, _C.c_double(0.0), _lib.ptr(buf["iB"]), _lib.ptr(buf["K0s"]),
+                                                    _lib.ptr(buf["V"]), _lib.ptr(buf["v"]), _lib.ptr(buf["part"]), _lib.ptr(buf["g_mu"]),
+                                                    _lib.ptr(buf["g_lv"]), None, None, None, None, 1, st), "gp_subject_fwd(pre)")
+                self._ahead_pre = (groups.data_ptr(), tuple(groups.shape))
         self._ahead = B
 
     def join_ahead(self):
@@ -523,12 +519,12 @@ class GPPriorHIP:
         if self._ahead_stream is not None and self._ahead is not None:
             torch.cuda.current_stream(self.zt_list.device).wait_stream(self._ahead_stream)
 
-    def prime_ahead(self, labels, rows):
+    def prime_ahead(self, labels, rows, groups=None):
         """``compute_ahead`` outside a training step (before the first step of a pipelined sequence / the first replay of a
         captured chain): transforms the hyper-parameters first"""
         self.join()
         self._transform()
-        self.compute_ahead(labels, rows)
+        self.compute_ahead(labels, rows, groups)
 
     def _prepare_state(self, x, S, T, B, dev, Kxz=None):
         """the state-only launches (current stream); returns (buf, hyp, Kxz, iKm, HiK, N1).  Kxz given: computed ahead, behind the
@@ -570,9 +566,7 @@ class GPPriorHIP:
         pre_done = False
         if prep is not None and (train_x is None or train_x is prep[0]):
             x, idx, buf, hyp, Kxz, iKm, HiK, N1 = prep
-            pre_done = self._prep_pre and self._fuse_sums       # the state-only half of the per-subject kernel is running on sA (prepare)
-            if pre_done:
-                torch.cuda.current_stream(dev).wait_stream(self._streams(dev)[0])
+            pre_done = self._prep_pre and self._fuse_sums       # the state-only half of the per-subject kernel ran a step ahead
             torch.cuda.current_stream(dev).wait_stream(self._prep_stream)
             x.record_stream(torch.cuda.current_stream(dev))                  # (allocated on the side stream, read on this one)
             if x.shape[0] != B:
@@ -838,7 +832,7 @@ class GPPriorHIP:
         self._iH = None
         self._transform()
         if next_batch is not None:
-            self.compute_ahead(*next_batch)
+            self.compute_ahead(*next_batch)          # (labels, rows[, groups])
         self.kernel_matrix(self.k0, self.zt_list, self.zt_list, jitter=self.eps, out=self._KH2[L:])
         self._spd_inv(self._KH2, self._HiK, self._ld2, n_neg=L, logdet_neg=self._ldH)      # log det H_new = - log det iH_new
         self._bmv(self.H, self._tmp, self.m)                                 # m_new = H_new tmp
