@@ -320,7 +320,7 @@ class ELBOTrainer:
             _lib.check(lib.hlvae_step_metrics(m._plan_handle, ws, B, _lib.ptr(self.err), s), "step_metrics")
         multi = self.dp is not None and self.dp.world > 1
         if feed_next is not None and not multi:   # deferred: the backward pass queues it on its side stream (hlvae_feed_prefetch)
-            nds, nrows = feed_next[0], feed_next[1]
+            nds, nrows = feed_next
             m._require_capacity(nrows.shape[0])
             _lib.check(lib.hlvae_feed_prefetch(m._plan_handle, C.byref(m._ws_alt), _lib.ptr(nds.values), _lib.ptr(nds.mask),
                                                _lib.ptr(nrows), nrows.shape[0], s), "feed_prefetch")
@@ -329,7 +329,7 @@ class ELBOTrainer:
             # several ranks: the next batch's statistics cross the ranks between its two kernels.  Forked from here on a stream
             # of ours, so that this small all-reduce is the FIRST collective of the step on RCCL's queue and the next step starts
             # at its first GEMM instead of behind a blocking exchange
-            nds, nrows = feed_next[0], feed_next[1]
+            nds, nrows = feed_next
             m._require_capacity(nrows.shape[0])
             main = torch.cuda.current_stream(m.device)
             self._pf_stream.wait_stream(main)
