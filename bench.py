@@ -304,7 +304,6 @@ def main():
             R = [b["rows_dev"] for b in ring]
             Gr = [b["groups_dev"] for b in ring]
             nx = [R[(i + 1) % len(ring)] for i in range(len(ring))]
-            ngx = [Gr[(i + 1) % len(ring)] for i in range(len(ring))]
             # Phase 1 -- the eager warm-up steps (these execute the step's real collectives; an exception here is a genuine
             # failure of the run and is raised).  Phase 2 -- the ranks agree that all of them got here and can capture AT ALL
             # (a trivial capture with the trainer's capture mode).  Phase 3 -- the captures proper: a captured collective is
@@ -340,9 +339,8 @@ def main():
                         for l in chain_lens:
                             idx = [(o + j) % len(ring) for j in range(l)]
                             trainer.capture_rows(("chain", o, l), dsd, [R[k] for k in idx], [PB[k] for k in idx],
-                                                 next_rows=[nx[k] for k in idx], groups=[Gr[k] for k in idx], next_groups=[ngx[k] for k in idx])
-                        trainer.capture_rows(o, dsd, R[o], PB[o], next_rows=nx[o] if feed_pf else None, groups=Gr[o],
-                                             next_groups=ngx[o] if feed_pf else None)
+                                                 next_rows=[nx[k] for k in idx], groups=[Gr[k] for k in idx])
+                        trainer.capture_rows(o, dsd, R[o], PB[o], next_rows=nx[o] if feed_pf else None, groups=Gr[o])
                     if a.graph_chain and not feed_pf:      # (no pipelined input stage: one chain from position 0, as before)
                         reps = max(1, a.chain // len(ring))
                         trainer.capture_rows("ring", dsd, R * reps, PB * reps, next_rows=None, groups=Gr * reps)
@@ -357,7 +355,7 @@ def main():
                 feed_pf = False
                 print(f"[bench] rank {rank}: HIP-graph capture unavailable ({graph_note}); launching eagerly", file=sys.stderr, flush=True)
             elif feed_pf:
-                trainer.prime_rows(dsd, R[0], Gr[0])
+                trainer.prime_rows(dsd, R[0])
     else:
         for b in ring:
             b["data"] = torch.tensor(src.data[b["rows"]], dtype=torch.float64, device=dev)

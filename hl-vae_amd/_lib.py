@@ -113,7 +113,7 @@ _SIGS = {
     "hlvae_gp_chol_inv": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "hlvae_gp_subject_fwd": (C.c_int, [C.POINTER(HlvaeGpKernel), C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp,
                                        _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_double, _vp, _vp, _vp,
-                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hlvae_gp_subject_bwd": (C.c_int, [C.POINTER(HlvaeGpKernel), C.POINTER(HlvaeGpKernel), _vp, C.c_int, C.c_int, C.c_int, _vp,
                                        _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp,
                                        _vp]),

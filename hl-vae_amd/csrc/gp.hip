@@ -350,12 +350,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     const double* __restrict__ Kxz, int Bn, int M, const double* __restrict__ resid, const float* __restrict__ lv, double c,
     double* __restrict__ iB_out, double* __restrict__ K0_out, double* __restrict__ V_out, double* __restrict__ v_out,
     double* __restrict__ part, float* __restrict__ g_mu, float* __restrict__ g_lv, const double* __restrict__ iKm,
-    const float* __restrict__ mu, double* __restrict__ u_acc, double* __restrict__ p1_acc, int mode) {
-    // mode 0: everything.  1 ("pre", round 3): only what depends on the prior's state and the batch's covariates -- covariances, the
-    // inverse of B_st, V = iB Ks, log det, sum(iB * K0) -- so that it can run a step AHEAD beside the state update's inversion
-    // (GPPriorHIP.compute_ahead).  2 ("post"): the rest, from the iB mode 1 left in iB_out: residual, v, the encoder gradients,
-    // the per-subject sums.  (uniform branches)
-    const bool do_pre = mode != 2, do_post = mode != 1;
+    const float* __restrict__ mu, double* __restrict__ u_acc, double* __restrict__ p1_acc) {
     // iKm != nullptr (training step, round 3): the residual a = K0xz (iK m) - mu of the subject's rows is computed HERE from the
     // staged rows of K0xz (`resid` is then unused: one launch and one 31 MB pass less), and the two matrix^T-vector sums over
     // the batch that followed as launches of their own -- u = K0xz^T v and P1 = V^T mu = Ks^T (iB mu), one streaming pass over
@@ -375,11 +370,10 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     GP_CLK(0, 0);
     if (tid < GP_TMAX) rows[tid] = tid < T ? idx[(size_t)s * T + tid] : -1;
     __syncthreads();
-    if (do_pre)
-        for (int e = tid; e < T * Q; e += 256) {
-            const int t = e / Q, r = rows[t];
-            xs[t * GP_XS + e % Q] = r >= 0 ? x[(size_t)r * Q + e % Q] : 0.0;
-        }
+    for (int e = tid; e < T * Q; e += 256) {
+        const int t = e / Q, r = rows[t];
+        xs[t * GP_XS + e % Q] = r >= 0 ? x[(size_t)r * Q + e % Q] : 0.0;
+    }
     for (int e0 = tid; e0 < T * M; e0 += 4 * 256) {       // stage Ks (coalesced along M), zero rows for padding;
         double tk[4];                                     // four loads in flight per lane
 #pragma unroll
@@ -393,7 +387,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
             if (e < T * M) ks[e] = rows[e / M] >= 0 ? tk[u] : 0.0;
         }
     }
-    if (do_post && iKm == nullptr && tid < T) rs[tid] = rows[tid] >= 0 ? resid[(size_t)l * Bn + rows[tid]] : 0.0;
+    if (iKm == nullptr && tid < T) rs[tid] = rows[tid] >= 0 ? resid[(size_t)l * Bn + rows[tid]] : 0.0;
     if (tid < GP_TMAX) {
         vsh[tid] = wsh[tid] = 0.0;
         mus[tid] = (mu != nullptr && tid < T && rows[tid] >= 0) ? (double)mu[(size_t)rows[tid] * L + l] : 0.0;
@@ -403,7 +397,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     gp_hoist(k0, hyp, n_slots, L, l, h0);
     gp_hoist(k1, hyp, n_slots, L, l, h1);
     __syncthreads();
-    if (do_post && iKm != nullptr) {                              // a[t] = sum_m Ks[t][m] (iK m)[m] - mu[t]: 8 lanes per row
+    if (iKm != nullptr) {                                         // a[t] = sum_m Ks[t][m] (iK m)[m] - mu[t]: 8 lanes per row
         const int t = tid >> 3, sub = tid & 7;                    // (256 threads = 32 rows x 8)
         double sa = 0.0;
         if (t < T)
@@ -414,65 +408,60 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
         if (sub == 0 && t < T) rs[t] = rows[t] >= 0 ? sa - mus[t] : 0.0;
     }
     GP_CLK(0, 2);      // staged + residual
-    double d1 = 0.0;
-    if (do_pre) {
-        const double nz = noise[l];
-        // covariance entries: the kernels are symmetric, so the T (T + 1) / 2 = 210 pairs i <= j are evaluated once, one per
-        // thread, into LDS (in the 2 x 2 register blocking of the Gauss-Jordan below 16 threads would evaluate 4 pairs each)
-        for (int p = tid; p < T * (T + 1) / 2; p += 256) {
-            int i = 0, rem = p;
-            while (rem >= T - i) { rem -= T - i; ++i; }
-            const int j = i + rem;
-            double kb = i == j ? 1.0 : 0.0, kz = 0.0;                 // padded rows: identity block
-            if (rows[i] >= 0 && rows[j] >= 0) {
-                kb = gp_value(k1, h1, xs + i * GP_XS, xs + j * GP_XS) + (i == j ? nz : 0.0);       // elbo_functions.py:249-250
-                kz = gp_value(k0, h0, xs + i * GP_XS, xs + j * GP_XS);                              // :248
-            }
-            ib[i * GP_TS + j] = kb; ib[j * GP_TS + i] = kb;
-            kzs[i * GP_TS + j] = kz; kzs[j * GP_TS + i] = kz;
+    const double nz = noise[l];
+    // covariance entries: the kernels are symmetric, so the T (T + 1) / 2 = 210 pairs i <= j are evaluated once, one per
+    // thread, into LDS (in the 2 x 2 register blocking of the Gauss-Jordan below 16 threads would evaluate 4 pairs each)
+    for (int p = tid; p < T * (T + 1) / 2; p += 256) {
+        int i = 0, rem = p;
+        while (rem >= T - i) { rem -= T - i; ++i; }
+        const int j = i + rem;
+        double kb = i == j ? 1.0 : 0.0, kz = 0.0;                 // padded rows: identity block
+        if (rows[i] >= 0 && rows[j] >= 0) {
+            kb = gp_value(k1, h1, xs + i * GP_XS, xs + j * GP_XS) + (i == j ? nz : 0.0);       // elbo_functions.py:249-250
+            kz = gp_value(k0, h0, xs + i * GP_XS, xs + j * GP_XS);                              // :248
         }
-        __syncthreads();
-        GP_CLK(0, 3);      // covariance pairs
-        double a[2][2], k0v[2][2];
-    #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-    #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int i = ti + 16 * ii, j = tj + 16 * jj;
-                const bool in = i < T && j < T;
-                a[ii][jj] = in ? ib[i * GP_TS + j] : (i == j ? 1.0 : 0.0);
-                k0v[ii][jj] = in ? kzs[i * GP_TS + j] : 0.0;
-            }
-        __syncthreads();                                              // ib is reused for the inverse below
-        gj_pivots<2, 0>(a, gjrow, gjcol, pv, T, ti, tj);
-        gj_pivots<2, 1>(a, gjrow, gjcol, pv, T, ti, tj);
-        GP_CLK(0, 4);      // Gauss-Jordan
-        // mask the inverse to the valid block, write iB and K0_st
-    #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-    #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int i = ti + 16 * ii, j = tj + 16 * jj;
-                if (i < T && j < T) {
-                    const bool ok = rows[i] >= 0 && rows[j] >= 0;
-                    const double v = ok ? a[ii][jj] : 0.0;
-                    ib[i * GP_TS + j] = v;
-                    const size_t o = (((size_t)s * L + l) * T + i) * T + j;
-                    iB_out[o] = v;
-                    K0_out[o] = k0v[ii][jj];
-                    d1 += v * k0v[ii][jj];                            // sum(iB * K0_st)  (:259)
-                }
-            }
-        __syncthreads();
-    } else {
-        for (int e = tid; e < T * T; e += 256) ib[(e / T) * GP_TS + e % T] = iB_out[((size_t)s * L + l) * T * T + e];      // (masked when written)
-        __syncthreads();
+        ib[i * GP_TS + j] = kb; ib[j * GP_TS + i] = kb;
+        kzs[i * GP_TS + j] = kz; kzs[j * GP_TS + i] = kz;
     }
+    __syncthreads();
+    GP_CLK(0, 3);      // covariance pairs
+    double a[2][2], k0v[2][2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            const bool in = i < T && j < T;
+            a[ii][jj] = in ? ib[i * GP_TS + j] : (i == j ? 1.0 : 0.0);
+            k0v[ii][jj] = in ? kzs[i * GP_TS + j] : 0.0;
+        }
+    __syncthreads();                                              // ib is reused for the inverse below
+    gj_pivots<2, 0>(a, gjrow, gjcol, pv, T, ti, tj);
+    gj_pivots<2, 1>(a, gjrow, gjcol, pv, T, ti, tj);
+    GP_CLK(0, 4);      // Gauss-Jordan
+    // mask the inverse to the valid block, write iB and K0_st
+    double d1 = 0.0;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int i = ti + 16 * ii, j = tj + 16 * jj;
+            if (i < T && j < T) {
+                const bool ok = rows[i] >= 0 && rows[j] >= 0;
+                const double v = ok ? a[ii][jj] : 0.0;
+                ib[i * GP_TS + j] = v;
+                const size_t o = (((size_t)s * L + l) * T + i) * T + j;
+                iB_out[o] = v;
+                K0_out[o] = k0v[ii][jj];
+                d1 += v * k0v[ii][jj];                            // sum(iB * K0_st)  (:259)
+            }
+        }
+    __syncthreads();
     GP_CLK(0, 5);      // iB, K0 written
     // v = iB a, A = a.v, Bt = sum diag(iB) e^lv, g_mu, g_lv
     double pa = 0.0, pb = 0.0, pc = 0.0;
     if (tid < T) {
-        if (do_post && rows[tid] >= 0) {
+        if (rows[tid] >= 0) {
             const int i = tid, r = rows[i];
             double acc = 0.0, accw = 0.0;
             for (int j = 0; j < T; ++j) { acc += ib[i * GP_TS + j] * rs[j]; accw += ib[i * GP_TS + j] * mus[j]; }
@@ -485,13 +474,13 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
             g_mu[(size_t)r * L + l] = (float)(-c * acc);         // d/dmu  of  c/2 a^T iB a  with a = pred - mu
             g_lv[(size_t)r * L + l] = (float)(c * 0.5 * (ib[i * GP_TS + i] * e - 1.0));
         }
-        if (do_pre) pc = log(pv[tid]);                            // log det B_st = sum of log pivots (:258)
+        pc = log(pv[tid]);                                        // log det B_st = sum of log pivots (:258)
     }
     GP_CLK(0, 6);      // v, g_mu, g_lv
     // V = iB Ks  [T][M] -> V_out[l][row][:] on the fp64 matrix cores (round 3: as 20 scalar FMAs per output with two LDS reads each
     // this loop was 18 k of a workgroup's 76 k clocks -- LDS bandwidth shared by the four co-resident workgroups): wave w owns the
     // 16-column fragments w, w + 4 of both 16-row halves; A = iB [i][j], B = Ks [j][m], k = j in steps of 4
-    if (do_pre) {
+    {
         const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, q = lane & 15;
         const int nfc = (M + 15) >> 4;
         for (int fc = wave; fc < nfc; fc += 4) {
@@ -521,7 +510,7 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     pa = wave_sum_d(pa); pb = wave_sum_d(pb); d1 = wave_sum_d(d1); pc = wave_sum_d(pc);
     if ((tid & 63) == 0) { red[0][tid >> 6] = pa; red[1][tid >> 6] = pb; red[2][tid >> 6] = d1; }
     __syncthreads();
-    if (do_post && u_acc != nullptr && tid < M) {                            // this subject's share of K0xz^T v and of V^T mu = Ks^T (iB mu)
+    if (u_acc != nullptr && tid < M) {                            // this subject's share of K0xz^T v and of V^T mu = Ks^T (iB mu)
         double su = 0.0, sp = 0.0;
         for (int i = 0; i < T; ++i) {
             const double kv = ks[i * M + tid];
@@ -534,14 +523,10 @@ __global__ __launch_bounds__(256) void k_gp_subject_fwd(
     GP_CLK(0, 8);      // u / P1 atomics
     if (tid == 0) {
         double* p = part + ((size_t)s * L + l) * 4;
-        if (do_post) {
-            p[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-            p[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        }
-        if (do_pre) {
-            p[2] = pc;                                            // wave 0 holds all T <= 32 pivots
-            p[3] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-        }
+        p[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        p[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        p[2] = pc;                                                // wave 0 holds all T <= 32 pivots
+        p[3] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
     }
 }
 
@@ -1750,19 +1735,18 @@ int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, c
                          const double* x, const double* noise, const int32_t* idx, int S, int T, const double* Kxz, int B,
                          int M, const double* resid, const float* lv, double c, double* iB, double* K0s, double* V,
                          double* v, double* part, float* g_mu, float* g_lv, const double* iKm, const float* mu, double* u_acc,
-                         double* p1_acc, int mode, hlvae_stream s) {
+                         double* p1_acc, hlvae_stream s) {
     if (int rc = gp_check_kernel(k0, n_slots, Q)) return rc;
     if (int rc = gp_check_kernel(k1, n_slots, Q)) return rc;
     HL_REQUIRE(T >= 1 && T <= GP_TMAX && S >= 1 && Q <= 8 && M <= GP_MMAX, HLVAE_ESHAPE,
                "gp_subject_fwd: T=%d (max %d), M=%d (max %d)", T, GP_TMAX, M, GP_MMAX);
-    HL_REQUIRE(mode >= 0 && mode <= 2, HLVAE_EINVAL, "gp_subject_fwd: mode %d", mode);
-    HL_REQUIRE(mode == 1 || ((iKm == nullptr || mu != nullptr) && (resid != nullptr || iKm != nullptr) &&
-                             ((u_acc == nullptr) == (p1_acc == nullptr)) && (u_acc == nullptr || mu != nullptr) && lv != nullptr),
-               HLVAE_EINVAL, "gp_subject_fwd: resid or (iKm, mu); u_acc / p1_acc both or none, with mu");
+    HL_REQUIRE((iKm == nullptr || mu != nullptr) && (resid != nullptr || iKm != nullptr) && ((u_acc == nullptr) == (p1_acc == nullptr)) &&
+                   (u_acc == nullptr || mu != nullptr), HLVAE_EINVAL,
+               "gp_subject_fwd: resid or (iKm, mu); u_acc / p1_acc both or none, with mu");
     HL_PROF("gp_subject_fwd", (hipStream_t)s);
 #define GP_SF(NTv, NRv)                                                                                                         \
     k_gp_subject_fwd<NTv, NRv><<<dim3(S, L), 256, (size_t)T * M * sizeof(double), (hipStream_t)s>>>(                               \
-        *k0, *k1, hyp, n_slots, L, Q, x, noise, idx, T, Kxz, B, M, resid, lv, c, iB, K0s, V, v, part, g_mu, g_lv, iKm, mu, u_acc, p1_acc, mode)
+        *k0, *k1, hyp, n_slots, L, Q, x, noise, idx, T, Kxz, B, M, resid, lv, c, iB, K0s, V, v, part, g_mu, g_lv, iKm, mu, u_acc, p1_acc)
     if (gp_kernel_small(k0) && gp_kernel_small(k1)) GP_SF(4, 1); else GP_SF(HLVAE_GP_MAX_TERMS, GP_MAX_RBF);
 #undef GP_SF
     HL_LAUNCH_CHECK();

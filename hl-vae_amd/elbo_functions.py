@@ -326,8 +326,6 @@ class GPPriorHIP:
         self._bufs, self._mm, self._side, self._pending = {}, None, None, False
         self._prep, self._prep_stream, self._tail_pending = None, None, False
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
-        self._ahead_pre, self._prep_pre = None, False
-        self._ahead_subject = _os.environ.get("HL_GP_AHEAD_SUBJECT", "1") != "0"
         self._serial = _os.environ.get("HL_GP_SERIAL", "0") == "1"
         self._balance = int(_os.environ.get("HL_GP_BALANCE", "2"))        # where the chain rule through K0xz runs (kl_and_grads)
         self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
@@ -473,11 +471,10 @@ class GPPriorHIP:
                 x, Kxz = x.contiguous(), None
             idx = groups if groups is not None else self._group(x)
             st_ = self._prepare_state(x, idx.shape[0], idx.shape[1], x.shape[0], dev, Kxz=Kxz)
-        self._prep_pre = bool(use_ahead and self._ahead_pre is not None and self._ahead_pre == (idx.data_ptr(), tuple(idx.shape)))
         self._prep = (x, idx) + st_
         return x
 
-    def compute_ahead(self, labels, rows, groups=None):
+    def compute_ahead(self, labels, rows):
         """Covariate gather + K0xz of a FOLLOWING batch on a stream of their own, forked from the caller's here.  Called by
         ``optimizer_step(next_batch=...)`` right behind the hyper-parameter transform: K0xz of the next batch needs the updated
         hyper-parameters and inducing points but not the batched inversion, so its 31 MB kernel matrix (55 us inside the step at
@@ -495,22 +492,9 @@ class GPPriorHIP:
             ab = (torch.empty(B, labels.shape[1], dtype=torch.float64, device=dev),
                   torch.empty(self.L, B, self.M, dtype=torch.float64, device=dev))
             self._ahead_bufs[B] = ab
-        self._ahead_pre = None
         with torch.cuda.stream(sK):
             torch.index_select(labels, 0, rows.long(), out=ab[0])
             self.kernel_matrix(self.k0, ab[0], self.zt_list, out=ab[1])
-            if groups is not None and self._fuse_sums and self._ahead_subject:
-                # the state-only half of the per-subject kernel too (covariances, B_st inverse, V = iB Ks: 2/3 of its time), into
-                # the step buffers of the next batch's geometry -- free here: the chains that read them have been joined
-                S, T = groups.shape
-                buf = self._step_buffers(B, S, T, dev)
-                lib, st = _lib.load(), self._stream()
-                _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(self.k0), _C.byref(self.k1), _lib.ptr(self._hyp), self.n_slots, self.L, self.Q,
-                                                    _lib.ptr(ab[0]), _lib.ptr(self.noise), _lib.ptr(groups), S, T, _lib.ptr(ab[1]), B, self.M,
-                                                    None, None, _C.c_double(0.0), _lib.ptr(buf["iB"]), _lib.ptr(buf["K0s"]),
-                                                    _lib.ptr(buf["V"]), _lib.ptr(buf["v"]), _lib.ptr(buf["part"]), _lib.ptr(buf["g_mu"]),
-                                                    _lib.ptr(buf["g_lv"]), None, None, None, None, 1, st), "gp_subject_fwd(pre)")
-                self._ahead_pre = (groups.data_ptr(), tuple(groups.shape))
         self._ahead = B
 
     def join_ahead(self):
@@ -519,12 +503,12 @@ class GPPriorHIP:
         if self._ahead_stream is not None and self._ahead is not None:
             torch.cuda.current_stream(self.zt_list.device).wait_stream(self._ahead_stream)
 
-    def prime_ahead(self, labels, rows, groups=None):
+    def prime_ahead(self, labels, rows):
         """``compute_ahead`` outside a training step (before the first step of a pipelined sequence / the first replay of a
         captured chain): transforms the hyper-parameters first"""
         self.join()
         self._transform()
-        self.compute_ahead(labels, rows, groups)
+        self.compute_ahead(labels, rows)
 
     def _prepare_state(self, x, S, T, B, dev, Kxz=None):
         """the state-only launches (current stream); returns (buf, hyp, Kxz, iKm, HiK, N1).  Kxz given: computed ahead, behind the
@@ -563,10 +547,8 @@ class GPPriorHIP:
         dev = mu.device
         c = float(P_total) / float(P_batch)
         prep, self._prep = self._prep, None
-        pre_done = False
         if prep is not None and (train_x is None or train_x is prep[0]):
             x, idx, buf, hyp, Kxz, iKm, HiK, N1 = prep
-            pre_done = self._prep_pre and self._fuse_sums       # the state-only half of the per-subject kernel ran a step ahead
             torch.cuda.current_stream(dev).wait_stream(self._prep_stream)
             x.record_stream(torch.cuda.current_stream(dev))                  # (allocated on the side stream, read on this one)
             if x.shape[0] != B:
@@ -610,7 +592,7 @@ class GPPriorHIP:
                                             _lib.ptr(log_v), _C.c_double(c), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
                                             _lib.ptr(part), _lib.ptr(g_mu), _lib.ptr(g_lv), _lib.ptr(iKm) if fused else None,
                                             _lib.ptr(mu) if fused else None, _lib.ptr(u) if fused else None,
-                                            _lib.ptr(P1) if fused else None, 2 if pre_done else 0, st), "gp_subject_fwd")
+                                            _lib.ptr(P1) if fused else None, st), "gp_subject_fwd")
         # g_mu / g_lv -- all the VAE's backward pass needs -- are final here.  What follows (the bound's value, the natural-gradient
         # terms, the chain rule into hyper-parameters and inducing points) is two independent chains of latency-bound kernels:
         # they run side by side on two streams of ours, and with join = False also beside whatever the caller queues next on
@@ -764,7 +746,7 @@ class GPPriorHIP:
         _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(px),
                                             _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(K0xz), Np, M, _lib.ptr(mu64T),
                                             _lib.ptr(zeros32), _C.c_double(1.0), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
-                                            _lib.ptr(part), _lib.ptr(g1), _lib.ptr(g2), None, None, None, None, 0, st), "gp_subject_fwd(predict)")
+                                            _lib.ptr(part), _lib.ptr(g1), _lib.ptr(g2), None, None, None, None, st), "gp_subject_fwd(predict)")
         K0zx = K0xz.transpose(1, 2)
         inv, _ = self.chol_inv(torch.cat([K0zz + K0zx @ V, K0zz]))                       # H = K0zz + sum_s Ks^T iB Ks (:156-157)
         iH, iK = inv[:L], inv[L:]
@@ -832,7 +814,7 @@ class GPPriorHIP:
         self._iH = None
         self._transform()
         if next_batch is not None:
-            self.compute_ahead(*next_batch)          # (labels, rows[, groups])
+            self.compute_ahead(*next_batch)
         self.kernel_matrix(self.k0, self.zt_list, self.zt_list, jitter=self.eps, out=self._KH2[L:])
         self._spd_inv(self._KH2, self._HiK, self._ld2, n_neg=L, logdet_neg=self._ldH)      # log det H_new = - log det iH_new
         self._bmv(self.H, self._tmp, self.m)                                 # m_new = H_new tmp

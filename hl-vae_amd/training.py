@@ -232,15 +232,14 @@ class ELBOTrainer:
             m._run_normalize(data, mask, B, hook)
         self._step_core(B, scale, eps, train_x, P_batch, prefetch, hook)
 
-    def prime_rows(self, ds, rows: torch.Tensor, groups=None):
-        """input stage of a batch of the compact dataset now, for a following ``step_rows(..., prepacked=True)``
-        (GP prior: also what it computes a step ahead for that batch; ``groups`` = its subject structure, if known)"""
+    def prime_rows(self, ds, rows: torch.Tensor):
+        """input stage of a batch of the compact dataset now, for a following ``step_rows(..., prepacked=True)``"""
         m = self.model
         B = rows.shape[0]
         m._ensure_device_state(B)
         self._feed_stage(ds, rows, B)
         if self._gp_ahead():
-            self.gp.prime_ahead(ds.labels, rows, groups)
+            self.gp.prime_ahead(ds.labels, rows)
 
     def _gp_ahead(self):
         """GP prior: the next batch's K0xz computed beside the state update's inversion (GPPriorHIP.compute_ahead; HL_GP_AHEAD=0
@@ -249,7 +248,7 @@ class ELBOTrainer:
             and os.environ.get("HL_GP_PREPARE", "1") != "0"
 
     def step_rows(self, ds, rows: torch.Tensor, P_batch: int, eps: Optional[torch.Tensor] = None, groups=None,
-                  prefetch_rows: Optional[torch.Tensor] = None, prepacked: bool = False, prefetch_groups=None):
+                  prefetch_rows: Optional[torch.Tensor] = None, prepacked: bool = False):
         """One step on the rows ``rows`` (int32 device tensor) of a device-resident ``datafeed.DeviceDataset``: the input
         stage gathers from the compact form inside its kernels (csrc/feed.hip); nothing else crosses PCIe.  Capturable:
         refill ``rows`` in place and replay.
@@ -280,7 +279,7 @@ class ELBOTrainer:
             else:
                 train_x = ds.labels.index_select(0, rows.long())
         self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None,
-                        feed_next=None if prefetch_rows is None else (ds, prefetch_rows, prefetch_groups), groups=groups)
+                        feed_next=None if prefetch_rows is None else (ds, prefetch_rows), groups=groups)
 
     def _feed_stage(self, ds, rows, B):
         """statistics -> [all-reduce over ranks] -> normalise + pack of the rows ``rows`` on the current stream, into the
@@ -422,7 +421,7 @@ class ELBOTrainer:
         m._grad_region_clean = True
         if self.kl == "gp":
             # (not together with the deferred state update, an experiment that stays off: HL_GP_DEFER)
-            nb = {"next_batch": (feed_next[0].labels, feed_next[1], feed_next[2] if len(feed_next) > 2 else None)} if (feed_next is not None and self._gp_ahead() and not self._gp_defer) else {}
+            nb = {"next_batch": (feed_next[0].labels, feed_next[1])} if (feed_next is not None and self._gp_ahead() and not self._gp_defer) else {}
             if self._gp_defer and hasattr(self.gp, "join_tail"):
                 self.gp.optimizer_step(defer=True, **nb)      # (inside a captured chain: the state update runs beside the next step's forward pass)
             else:
@@ -468,7 +467,7 @@ class ELBOTrainer:
         self._graphs[key] = g
         return g
 
-    def capture_rows(self, key, ds, rows, P_batch, next_rows=None, groups=None, next_groups=None):
+    def capture_rows(self, key, ds, rows, P_batch, next_rows=None, groups=None):
         """Capture ``step_rows`` reading the STATIC index tensor ``rows``: refill it in place (``rows.copy_(...)``) and
         replay -- one graph serves every batch of that size and subject count.
 
@@ -486,7 +485,6 @@ class ELBOTrainer:
         chain = list(zip(rows, P_batch)) if many else [(rows, P_batch)]
         nxt = [None] * len(chain) if next_rows is None else (list(next_rows) if many else [next_rows])
         grp = [None] * len(chain) if groups is None else (list(groups) if many else [groups])
-        ngrp = [None] * len(chain) if next_groups is None else (list(next_groups) if many else [next_groups])     # subject structure of next_rows
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -494,7 +492,7 @@ class ELBOTrainer:
             for _ in range(2):                       # warm-up (an even number of steps: the buffer sets end where they began)
                 self.step_rows(ds, chain[0][0], chain[0][1], groups=grp[0])
             if next_rows is not None:
-                self.prime_rows(ds, chain[0][0], grp[0])
+                self.prime_rows(ds, chain[0][0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # y_layer's shadows alternate between two buffer pairs inside a chain with an even number of steps (the graph ends where
@@ -507,8 +505,8 @@ class ELBOTrainer:
                           and os.environ.get("HL_GP_DEFER", "0") != "0")      # (measured: 0.834 vs 0.796 ms -- off by default)
         try:
             with torch.cuda.graph(g, **self._capture_kw()):
-                for (r, pb), nr, gr, ngr in zip(chain, nxt, grp, ngrp):
-                    self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None, groups=gr, prefetch_groups=ngr)
+                for (r, pb), nr, gr in zip(chain, nxt, grp):
+                    self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None, groups=gr)
                 if self.dp is not None:
                     self.opt.finish_pending()          # nothing may stay in flight across the end of a graph
                 if self._gp_defer:

@@ -362,15 +362,12 @@ int hlvae_gp_chol_inv(const double* A, int n, int N, double* inv, double* logdet
  * contributions; g_mu, g_lv [B][L] fp32 = d(KL bound)/d(mu, log_var) with c = P / P_batch.
  * iKm [L][M] = iK0zz m (or NULL): the residual is then computed inside from the staged rows of K0xz and mu [B][L] (resid unused).
  * u_acc, p1_acc [L][M] (both or NULL; need mu): += this batch's K0xz^T v and V^T mu (elbo_functions.py:262-266), per-subject
- * fp64 atomics -- the caller zeroes them.
- * mode 0: all of it.  mode 1: only what depends on the prior's state and the covariates (iB, K0s, V, part[2], part[3]; resid, lv,
- * iKm, mu, the accumulators and the other outputs are not touched) -- a caller that knows the next batch runs it a step ahead.
- * mode 2: the rest, reading iB as mode 1 left it (v, g_mu, g_lv, part[0], part[1], the accumulators). */
+ * fp64 atomics -- the caller zeroes them. */
 int hlvae_gp_subject_fwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* hyp, int n_slots, int L, int Q,
                          const double* x, const double* noise, const int32_t* idx, int S, int T, const double* Kxz, int B,
                          int M, const double* resid, const float* lv, double c, double* iB, double* K0s, double* V,
                          double* v, double* part, float* g_mu, float* g_lv, const double* iKm, const float* mu, double* u_acc,
-                         double* p1_acc, int mode, hlvae_stream s);
+                         double* p1_acc, hlvae_stream s);
 /* gradients of the bound w.r.t. B_st and K0_st chained into the hyper-parameters (accumulates into gprm [n_slots][L]).
  * Y [L][B][M] = V (iK0zz - iK0zz H iK0zz). */
 int hlvae_gp_subject_bwd(const hlvae_gp_kernel* k0, const hlvae_gp_kernel* k1, const double* hyp, int n_slots, int L, int Q,

@@ -672,10 +672,8 @@ def test_gp_captured_chain_matches_eager_steps():
         gp = GPPriorHIP.from_reference_config(model, src, 40, dev)
         tr = ELBOTrainer(model, P_total=40, kl="gp", gp=gp, max_batch=256, metrics=True)
         if graph:
-            # (two warm-up steps on R[0] first.)  next_groups: the prior computes K0xz AND the state-only half of its per-subject kernel
-            # for the following batch beside the state update -- the eager run below takes the one-kernel form
-            tr.capture_rows("c", ds, R, PB, next_rows=[R[1], R[0]], groups=G, next_groups=[G[1], G[0]])
-            tr.prime_rows(ds, R[0], G[0])
+            tr.capture_rows("c", ds, R, PB, next_rows=[R[1], R[0]], groups=G)       # (two warm-up steps on R[0] first)
+            tr.prime_rows(ds, R[0])
             for _ in range(2):
                 tr.replay("c")
         else:
