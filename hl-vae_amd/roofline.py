@@ -39,6 +39,11 @@ def gp_algorithmic_work(gp, B, S, T):
     w["gp_adam"] = ((n * L + L * M * Q) * 7 * f, 0)
     # fp64 matrix-core products of the M x M algebra: priced against the dense fp64 MFMA peak (MI355X: 78.6 TFLOP/s)
     w["gp_bmm"] = (4 * L * M * M * f, 2 * L * M * M * M, MFMA_FP64_PEAK_TFLOPS)
+    # the rectangular products Y = V (iK - Q) and W = K0xz^T V (k_gp_gemm, two launches per step of the same size)
+    w["gp_gemm"] = ((2 * L * B * M + L * M * M) * f, 2 * L * B * M * M, MFMA_FP64_PEAK_TFLOPS)
+    # the M x M algebra behind W by row blocks (k_gp_chain_rb, both launches under one label): six 32 x M x M product passes per
+    # row block; iK, W, H iK, H, iH in, grad_H, Rs (written, read back), G out
+    w["gp_chain"] = (10 * L * M * M * f, 12 * L * M * M * M, MFMA_FP64_PEAK_TFLOPS)
     w["gp_rsym"] = (4 * L * M * M * f, 0)
     w["gp_gemv_t"] = (L * B * M * f, 0)
     w["gp_gkxz"] = (2 * L * B * M * f, 0)
