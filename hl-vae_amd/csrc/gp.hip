@@ -19,6 +19,8 @@
 #include <stdlib.h>
 #include "common.h"
 
+#pragma clang diagnostic ignored "-Wpass-failed"       // (unroll requests on run-time trip counts, as in mid.hip)
+
 typedef __attribute__((ext_vector_type(4))) double f64x4_t;     // one v_mfma_f64_16x16x4_f64 accumulator fragment
 #define GP_TMAX 32
 #define GP_MMAX 128

@@ -459,7 +459,7 @@ __device__ __forceinline__ int acc_dest(const hlvae_var& var, int n) {
 // DMA: the U x Wy^T tile runs on the LDS-DMA core (gemm_dma.h, round 3: no staging registers, no ds_write pass, swizzled
 // conflict-free fragment reads, two 20 KB buffers instead of two 23 KB ones); false: the register-staged core of rounds 1-2
 template <int YD, int BM, int KMAX, int CORE = 2>
-__global__ __launch_bounds__(HL_THREADS, KMAX <= 5 ? 3 : (KMAX <= 8 ? 2 : 1)) void k_y_heads(
+__global__ __launch_bounds__(HL_THREADS, (YD > 5 || KMAX > 8) ? 1 : (KMAX <= 5 ? 3 : 2)) void k_y_heads(      // (y_dim 8: 245 VGPRs)
     const bf16_t* __restrict__ U, int ldu, const bf16_t* __restrict__ Wy, int K, const hlvae_var* __restrict__ vars,
     const float* __restrict__ P, float* __restrict__ hgpart, long o_by, const float* __restrict__ norm, int n_stat,
     const float* __restrict__ xt, const uint8_t* __restrict__ m8, int D, const float* __restrict__ g_elem, float g_scale,

@@ -655,6 +655,52 @@ def test_gp_bmm_and_rsym_against_torch(N, batch):
     assert rel_err(o2, (R.transpose(1, 2) @ xv.t().unsqueeze(2)).squeeze(2)) < 1e-13
 
 
+@pytest.mark.parametrize("N,batch", [(120, 32), (128, 3), (24, 5), (100, 2), (4, 1)])
+def test_gp_chain_kernels_against_torch(N, batch):
+    """The M x M algebra of a GP step behind W as one call (round 3): hlvae_gp_chain (one workgroup per (latent, chain)) and
+    hlvae_gp_chain_rb (two launches of independent 32-row blocks) against the torch.float64 statement of elbo_functions.py:279-283
+    and of the K0zz gradient, on symmetric positive definite operands -- different summation order only."""
+    import ctypes as C
+    from hlvae_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(1000 + N)
+
+    def spd():
+        a = torch.randn(batch, N, N, generator=g, dtype=torch.float64)
+        return (a @ a.transpose(1, 2) / N + torch.eye(N, dtype=torch.float64)).to(dev)
+
+    iK, W, H, iH = spd(), spd(), spd(), spd()
+    HiK = (H @ iK).contiguous()
+    m, P1, u = (torch.randn(batch, N, 1, generator=g, dtype=torch.float64).to(dev) for _ in range(3))
+    lr, c, ga, gb = 0.01, 1.7, -0.5, 0.5
+    # the statement
+    Bm = iK @ W @ iK + iK
+    grad_m = Bm @ m - iK @ P1
+    grad_H = 0.5 * (Bm - iH)
+    tmp = iH @ m - lr * (grad_m - 2.0 * grad_H @ m)
+    X = HiK @ W
+    mT = m.transpose(1, 2)
+    Rs = c * (u @ mT + m @ u.transpose(1, 2) - W + X + X.transpose(1, 2)) + H + m @ mT
+    G = ga * (iK @ Rs @ iK) + gb * iK
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = _lib.ptr
+    e = lambda *sh: torch.full(sh, float("nan"), dtype=torch.float64, device=dev)
+    for which in ("chain", "chain_rb"):
+        o = dict(T1=e(batch, N, N), Bm=e(batch, N, N), grad_m=e(batch, N, 1), grad_H=e(batch, N, N), tmp=e(batch, N, 1), HiKW=e(batch, N, N),
+                 Rs=e(batch, N, N), T1b=e(batch, N, N), G=e(batch, N, N))
+        if which == "chain":
+            _lib.check(lib.hlvae_gp_chain(p(iK), p(W), p(HiK), p(H), p(iH), p(m), p(P1), p(u), C.c_double(lr), C.c_double(c), C.c_double(ga),
+                                          C.c_double(gb), N, batch, p(o["T1"]), p(o["Bm"]), p(o["grad_m"]), p(o["grad_H"]), p(o["tmp"]),
+                                          p(o["HiKW"]), p(o["Rs"]), p(o["T1b"]), p(o["G"]), st), which)
+        else:
+            _lib.check(lib.hlvae_gp_chain_rb(p(iK), p(W), p(HiK), p(H), p(iH), p(m), p(P1), p(u), C.c_double(lr), C.c_double(c), C.c_double(ga),
+                                             C.c_double(gb), N, batch, p(o["grad_m"]), p(o["grad_H"]), p(o["tmp"]), p(o["Rs"]), p(o["G"]), st), which)
+        torch.cuda.synchronize()
+        for k, ref in (("grad_m", grad_m), ("grad_H", grad_H), ("tmp", tmp), ("Rs", Rs), ("G", G)):
+            assert rel_err(o[k], ref) < 1e-12, (which, k, rel_err(o[k], ref))
+
+
 def test_gp_prior_config5_size_against_autograd_statement():
     """BASELINE configs[4] (GP variant) at its full size: 32 latent GPs, 120 inducing points, 6 covariates, a 1024-row batch
     of 51 whole subjects x 20 rows + 4 rows of a 52nd -- bound, gradients w.r.t. mu / log-variance, natural-gradient
