@@ -97,7 +97,6 @@ _SIGS = {
     "hlvae_scale_dy": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, _vp]),
     "hlvae_backward": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_float, C.c_int, C.c_int, _vp]),
     "hlvae_backward_wy": (C.c_int, [_vp, C.POINTER(HlvaeWs), C.c_int, _vp]),
-    "hlvae_backward_du": (C.c_int, [_vp, C.POINTER(HlvaeWs), C.c_int, _vp]),
     "hlvae_zero_grad": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp]),
     "hlvae_adam_step": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, _vp]),

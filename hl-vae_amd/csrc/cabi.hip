@@ -248,7 +248,6 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     p->kmax = 2;
     p->pend_flags = 0;
     p->defer_join = 0;
-    p->du_early = 0;
     for (int i = 0; i < d.D; ++i)
         if ((vars[i].kind == HLVAE_CAT || vars[i].kind == HLVAE_ORDINAL) && vars[i].ncls > p->kmax) p->kmax = vars[i].ncls;
     for (auto& st : p->side) st = nullptr;
@@ -545,7 +544,6 @@ int hlvae_set_defer_join(const hlvae_plan* p, int on) {
 int hlvae_reset_pending(const hlvae_plan* p) {
     HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
     p->pend_flags = 0;          // deferred side work recorded against a capture that failed: dropped
-    p->du_early = 0;
     return 0;
 }
 
@@ -613,9 +611,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         if ((rc = hl_launch_head_grad_reduce(p, ws, Bp, st))) return rc;
     const bf16_t* dyl = d.conv ? ws->dyc : ws->dy;          // gradient of y_layer's output, both layouts
     const bf16_t* dylT = d.conv ? ws->dycT : ws->dyT;
-    const bool du_early = p->du_early != 0;        // hlvae_backward_du recorded ev[0] / ev[2] and queued dU_splitk already
-    p->du_early = 0;
-    if (!du_early) HL_CHECK(hipEventRecord(p->ev[0], st));        // dY is final
+    HL_CHECK(hipEventRecord(p->ev[0], st));        // dY is final
     const bool fused_opt = opt != nullptr && !skip_wy && hl_fused_optimiser(d, Bp);
     AdamGemmGroup g_rest{}, g_wy{};
     unsigned tickets = 0;
@@ -641,7 +637,6 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     // d U slabs = dY Wy (split-K), then the fused middle: dU -> dz -> d(mu, lv) -> dT, bias gradients
     const bool direct_bwd = hl_mid_direct_bwd(d);      // narrow y_layer: the fused middle computes dY Wy itself (and is then the last
     if (direct_bwd) {                                  // reader of y_layer's shadows)
-    } else if (d.n_xd == 0 && du_early) {
     } else if (d.n_xd == 0) {
         if ((rc = hl_launch_gemm_splitk(dyl, d.NYlp, ws->wyTs, d.NYlp, ws->slab, d.hdp, Bp, d.hdp, d.NYlp, ws->splitk_dec, "dU_splitk", st))) return rc;
         HL_CHECK(hipEventRecord(p->ev[2], st));        // the last reader of y_layer's weight shadows is done
@@ -820,18 +815,6 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     // it calls hlvae_join at the end of its step
     if ((skip_wy && opt == nullptr) || p->defer_join) return 0;
     return hlvae_join(p, s);
-}
-
-int hlvae_backward_du(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stream s) {
-    CHECK_B();
-    HL_REQUIRE(ws->splitk_dec >= 1, HLVAE_EINVAL, "splitk_dec");
-    if (d.conv || d.n_xd != 0 || hl_mid_direct_bwd(d) || p->du_early) return 0;      // not applicable: the backward call does it
-    HL_CHECK(hipEventRecord(p->ev[0], st));        // dY is final
-    if (int rc = hl_launch_gemm_splitk(ws->dy, d.NYlp, ws->wyTs, d.NYlp, ws->slab, d.hdp, Bp, d.hdp, d.NYlp, ws->splitk_dec, "dU_splitk", st))
-        return rc;
-    HL_CHECK(hipEventRecord(p->ev[2], st));        // the last reader of y_layer's weight shadows is done
-    p->du_early = 1;
-    return 0;
 }
 
 int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv, float kl_std_weight,

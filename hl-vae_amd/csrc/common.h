@@ -137,7 +137,6 @@ struct hlvae_plan {
     // launches are queued on a side stream by the next hlvae_backward* / hlvae_join (cabi.hip: hl_flush_deferred)
     mutable int pend_flags;        // HL_PEND_*
     mutable int defer_join;        // hlvae_set_defer_join: hlvae_backward* return without joining the deferred side chain
-    mutable int du_early;          // hlvae_backward_du queued dY Wy for this step already
     mutable hlvae_ws pend_ws, pend_fin_ws;
     mutable int pend_B, pend_fin_B;
     mutable float* pend_err;

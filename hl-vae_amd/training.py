@@ -343,11 +343,6 @@ class ELBOTrainer:
             # the GP prior's own chains (bound, natural gradient, hyper-parameter gradients) keep running on its streams beside
             # the VAE's backward pass; gp.optimizer_step() below joins them
             kw = {"join": False} if hasattr(self.gp, "join") else {}
-            if self.dp is None and hasattr(self.gp, "join") and os.environ.get("HL_GP_EARLY_DU", "1") != "0":
-                # dY Wy needs the head kernel's output only: queued AHEAD of the prior's per-subject kernel (which produces the
-                # g_mu / g_lv the backward pass needs at its second kernel), so that the VAE's backward pass and optimiser launches
-                # do not start 75 us later beside the prior's two chains
-                _lib.check(lib.hlvae_backward_du(m._plan_handle, ws, B, s), "backward_du")
             g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch, groups=groups, **kw)
         fused_opt = self.dp is None
         late_join = False

@@ -283,11 +283,6 @@ int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx
  * call hlvae_join at the end of the step. */
 int hlvae_backward(const hlvae_plan* p, const hlvae_ws* ws, const float* g_mu, const float* g_lv,
                    float kl_std_weight, int skip_wy, int B, hlvae_stream s);
-/* dU slabs = dY Wy (the first launch of the backward pass: it needs the head kernel's dY only) queued NOW; the following
- * hlvae_backward / hlvae_backward_adam of this plan skips it.  For hosts that have independent work to queue between the
- * forward pass and the backward call (the GP prior's per-subject kernel produces g_mu / g_lv, which the backward pass needs
- * only at its second kernel).  No-op for the convolutional model, deeper decoder trunks and narrow y_layers. */
-int hlvae_backward_du(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stream s);
 /* only d Wy = dY^T U, on the given stream.  Data-parallel hosts call this first, start the all-reduce of that arena
  * slice, then hlvae_backward(..., skip_wy = 1): the collective overlaps the rest of the backward pass. */
 int hlvae_backward_wy(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stream s);

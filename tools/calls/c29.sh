@@ -5,10 +5,3 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --workload d4 --rows 50000 --batch 1024 --kl gp --no-also --tag r3_cfg4 > $R/gpurun_out/r3_cfg4_bench.json 2> $R/gpurun_out/r3_cfg4_bench.log; python3 $R/tools/calls/show.py $R/gpurun_out/r3_cfg4_bench.json cfg4 | head -1 | cut -c1-200
 python3 $R/bench.py --conv --kl gp --no-also --tag r3_convgp > $R/gpurun_out/r3_convgp_bench.json 2> $R/gpurun_out/r3_convgp_bench.log; python3 $R/tools/calls/show.py $R/gpurun_out/r3_convgp_bench.json convgp | head -1 | cut -c1-200
-cd $R
-for cfg in "a 0" "b 1" "a 0" "b 1"; do
-  set -- $cfg
-  HL_GP_EARLY_DU=$2 python bench.py --no-cpu-baseline --no-also --workload d4 --rows 50000 --batch 1024 --kl gp --steps 200 --warmup 20 > gpurun_out/r3_c29_$1.json 2> gpurun_out/r3_c29_$1.log || tail -5 gpurun_out/r3_c29_$1.log
-  python tools/calls/show.py gpurun_out/r3_c29_$1.json "gp early_du=$2" | head -2 | cut -c1-260
-done
-python -m pytest tests/test_gpu_configs.py -x -q -m gpu -k "gp or config5" 2>&1 | tail -2
