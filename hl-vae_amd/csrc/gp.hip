@@ -1368,7 +1368,8 @@ __global__ __launch_bounds__(THREADS) void k_gp_chain(GpChainArgs a) {
 //  built first and is algebraically equal, but it cancels AFTER the multiplication by iK instead of inside Rs: on the
 //  config-5 matrices (condition 1e8) the inducing-point gradient lost its sign in 15 % of the large entries.)
 // grid (batch, ceil(N / 32)), 512 threads: wave w owns output columns 16 w .. 16 w + 15 of both 16-row halves.
-#define GP_RB_LD 122                                          // LDS row stride of the intermediate row block (16-byte aligned rows)
+#define GP_RB_LD 130                                          // LDS row stride of the intermediate row block (>= GP_MMAX, 16-byte aligned rows)
+static_assert(GP_RB_LD >= GP_MMAX && GP_RB_LD % 2 == 0, "row blocks of up to GP_MMAX columns, 16-byte aligned rows");
 struct GpChainRbArgs {
     const double *iK, *W, *HiK, *H, *iH, *m, *P1, *u;
     double *grad_m, *grad_H, *tmp, *Rs, *G;
