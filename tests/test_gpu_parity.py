@@ -655,6 +655,30 @@ def test_gp_bmm_and_rsym_against_torch(N, batch):
     assert rel_err(o2, (R.transpose(1, 2) @ xv.t().unsqueeze(2)).squeeze(2)) < 1e-13
 
 
+@pytest.mark.parametrize("M,N,K,batch,transA", [(1024, 120, 120, 4, 0), (120, 120, 1024, 4, 1), (203, 100, 36, 2, 0), (100, 128, 300, 3, 1),
+                                                 (64, 130, 64, 2, 0), (33, 7, 21, 2, 1)])
+def test_gp_gemm_against_torch(M, N, K, batch, transA):
+    """hlvae_gp_gemm, C = alpha op(A) B + beta D on the fp64 matrix cores: the fragment-from-L2 kernel (N <= 128, K % 4 == 0: every
+    product of the GP step, with and without split-K) and the LDS-staged one (everything else) against torch.float64."""
+    import ctypes as C
+    from hlvae_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + 7 * N + 13 * K)
+    A = torch.randn(batch, *((K, M) if transA else (M, K)), generator=g, dtype=torch.float64).to(dev)
+    B = torch.randn(batch, K, N, generator=g, dtype=torch.float64).to(dev)
+    D = torch.randn(batch, M, N, generator=g, dtype=torch.float64).to(dev)
+    out = torch.full((batch, M, N), float("nan"), dtype=torch.float64, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    opA = A.transpose(1, 2) if transA else A
+    for alpha, beta, d in ((1.0, 0.0, None), (-0.5, 2.0, D)):
+        _lib.check(lib.hlvae_gp_gemm(_lib.ptr(A), A.shape[2], A.stride(0), transA, _lib.ptr(B), N, B.stride(0), _lib.ptr(d), N if d is not None else 0,
+                                     d.stride(0) if d is not None else 0, _lib.ptr(out), N, out.stride(0), M, N, K, batch, C.c_double(alpha),
+                                     C.c_double(beta), st), "gp_gemm")
+        ref = alpha * (opA @ B) + (beta * d if d is not None else 0.0)
+        assert rel_err(out, ref) < 1e-13, (alpha, beta, rel_err(out, ref))
+
+
 @pytest.mark.parametrize("N,batch", [(120, 32), (128, 3), (24, 5), (100, 2), (4, 1)])
 def test_gp_chain_kernels_against_torch(N, batch):
     """The M x M algebra of a GP step behind W as one call (round 3): hlvae_gp_chain (one workgroup per (latent, chain)) and
