@@ -1118,85 +1118,8 @@ __global__ __launch_bounds__(256) void k_gp_gemm(const double* __restrict__ A, i
         }
 }
 
-// k_gp_gemm's job for N <= 128 columns (every product of the GP step) in the fragment-from-L2 form of k_gp_chain_rb (round 3): a
-// workgroup of eight waves owns 32 rows x up to 128 columns, wave w the columns 16 w .. 16 w + 15; both operands come straight
-// from global memory as MFMA fragments (a block of 16 k per step, the next block requested before the current one's products)
-// -- no LDS, no barrier.  k_gp_gemm stages 32-k chunks through LDS with two barriers per chunk and 8-byte loads: 44 + 34 us alone
-// for Y = V (iK - Q) and W = K0xz^T V at configs[4] against an fp64-MFMA bound of 12 us each.
-// TA: A is given k-major (element (row, k) at A[k lda + row]).  K % 4 == 0; !TA: lda even (16-byte aligned fragment loads).
-template <bool TA>
-__global__ __launch_bounds__(512) void k_gp_fgemm(const double* __restrict__ A, int lda, long sA, const double* __restrict__ B, int ldb,
-                                                  long sB, const double* D, int ldd, long sD, double* C, int ldc, long sC, int M,
-                                                  int N, int K, int kper, double alpha, double beta, int atomic) {
-    const int l = blockIdx.z, R0 = 32 * blockIdx.x, ks = blockIdx.y;
-    const int kb0 = ks * kper, ke = min(K, kb0 + kper);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, q = lane & 15, col = 16 * wave + q;
-    const bool cok = col < N;
-    const double* Al = A + (size_t)l * sA;
-    const double* Bl = B + (size_t)l * sB;
-    bool rok[2];
-    unsigned offa[2];
-#pragma unroll
-    for (int fi = 0; fi < 2; ++fi) {
-        const int row = R0 + 16 * fi + q;
-        rok[fi] = row < M;
-        offa[fi] = TA ? (unsigned)(4 * g * lda + min(row, M - 1)) : (unsigned)(min(row, M - 1) * lda + 4 * g);
-    }
-    const unsigned offb = (unsigned)(4 * g * ldb + min(col, N - 1));
-    f64x4_t acc[2] = {f64x4_t{0.0, 0.0, 0.0, 0.0}, f64x4_t{0.0, 0.0, 0.0, 0.0}};
-    auto load = [&](int kb, f64x4_t (&a)[2], double (&b)[4]) {
-        const bool kok = kb + 4 * g < ke;
-#pragma unroll
-        for (int fi = 0; fi < 2; ++fi) {
-            if (TA) {
-                const double* ap = Al + (size_t)kb * lda;
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) a[fi][s_] = ap[(kok ? offa[fi] : 0u) + (unsigned)(s_ * lda)];
-            } else {
-                a[fi] = *reinterpret_cast<const f64x4_t*>(Al + kb + (kok ? offa[fi] : 0u));
-            }
-            if (!(kok && rok[fi])) a[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0};
-        }
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) b[s_] = (Bl + (size_t)kb * ldb)[(kok ? offb : 0u) + (unsigned)(s_ * ldb)];
-        if (!(kok && cok)) { b[0] = b[1] = b[2] = b[3] = 0.0; }
-    };
-    auto mma = [&](const f64x4_t (&a)[2], const double (&b)[4]) {
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-            for (int fi = 0; fi < 2; ++fi) acc[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[fi][s_], b[s_], acc[fi], 0, 0, 0);
-    };
-    if (kb0 < ke) {
-        f64x4_t a0[2], a1[2];
-        double b0[4], b1[4];
-        load(kb0, a0, b0);
-        for (int kb = kb0; kb < ke; kb += 32) {
-            const bool more = kb + 16 < ke;
-            if (more) load(kb + 16, a1, b1);
-            mma(a0, b0);
-            if (more) {
-                if (kb + 32 < ke) load(kb + 32, a0, b0);
-                mma(a1, b1);
-            }
-        }
-    }
-    const double* Dl = D != nullptr ? D + (size_t)l * sD : nullptr;
-    double* Cl = C + (size_t)l * sC;
-#pragma unroll
-    for (int fi = 0; fi < 2; ++fi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = R0 + 16 * fi + g + 4 * r;
-            if (row < M && cok) {
-                double v = alpha * acc[fi][r];
-                if (Dl != nullptr && ks == 0) v += beta * Dl[(size_t)row * ldd + col];
-                if (atomic) atomicAdd(Cl + (size_t)row * ldc + col, v);
-                else Cl[(size_t)row * ldc + col] = v;
-            }
-        }
-}
-
+// (Round 3 also built k_gp_gemm's job in the fragment-from-L2 form of k_gp_chain_rb -- 32 rows x 128 columns per workgroup, no LDS, no
+//  barrier: 40 us per product alone, the same as this kernel; both sit at a third of the fp64 MFMA peak.  Not kept.)
 // out[l] = alpha A[l] x[l] + beta y[l]      (A: [batch][N][N] row-major, x, y, out: [batch][N]; y may be null or alias out)
 // eight lanes per row, one workgroup per matrix: the matrix-vector products of the natural gradient (iK m, Bm m, iK P1, H tmp)
 __global__ __launch_bounds__(1024) void k_gp_bmv(const double* __restrict__ A, const double* __restrict__ x, const double* y,
@@ -2007,24 +1930,6 @@ int hlvae_gp_gemm(const double* A, int lda, int64_t strideA, int transA, const d
     HL_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && batch >= 1, HLVAE_EINVAL, "gp_gemm: M=%d N=%d K=%d batch=%d", M, N, K, batch);
     HL_REQUIRE(lda >= (transA ? M : K) && ldb >= N && ldc >= N && (D == nullptr || ldd >= N), HLVAE_ESHAPE, "gp_gemm: leading dimensions");
     hipStream_t st = (hipStream_t)s;
-    static const bool frag = [] { const char* e = getenv("HL_GP_FGEMM"); return !(e != nullptr && e[0] == '0'); }();   // =0: the LDS-staged kernel (A/B)
-    if (frag && N <= GP_MMAX && K % 4 == 0 && (transA || (lda % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && strideA % 2 == 0))) {
-        const int rb = (M + 31) / 32;
-        int ksplit = 1;
-        while ((long)rb * batch * ksplit < 1024 && K / (2 * ksplit) >= 64) ksplit *= 2;
-        const int kper = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
-        if (ksplit > 1) {
-            HL_REQUIRE(D == nullptr || D != C, HLVAE_EINVAL, "gp_gemm: D aliasing C is not available with split-K");
-            HL_REQUIRE(ldc == N && strideC == (int64_t)M * N, HLVAE_ESHAPE, "gp_gemm: split-K needs a dense C");
-            HL_CHECK(hipMemsetAsync(C, 0, sizeof(double) * (size_t)batch * M * N, st));
-        }
-        HL_PROF("gp_gemm", st);
-        const dim3 grid(rb, ksplit, batch);
-        if (transA) k_gp_fgemm<true><<<grid, 512, 0, st>>>(A, lda, strideA, B, ldb, strideB, D, ldd, strideD, C, ldc, strideC, M, N, K, kper, alpha, beta, ksplit > 1);
-        else k_gp_fgemm<false><<<grid, 512, 0, st>>>(A, lda, strideA, B, ldb, strideB, D, ldd, strideD, C, ldc, strideC, M, N, K, kper, alpha, beta, ksplit > 1);
-        HL_LAUNCH_CHECK();
-        return 0;
-    }
     const int TM = M >= 256 ? 64 : 32;
     const int tiles_n = (N + 31) / 32, tiles_m = (M + TM - 1) / TM;
     // few output tiles and a long K (W = Kxz^T V: 16 tiles per latent, K = batch rows): slices of K add into a cleared C

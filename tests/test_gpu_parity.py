@@ -658,8 +658,8 @@ def test_gp_bmm_and_rsym_against_torch(N, batch):
 @pytest.mark.parametrize("M,N,K,batch,transA", [(1024, 120, 120, 4, 0), (120, 120, 1024, 4, 1), (203, 100, 36, 2, 0), (100, 128, 300, 3, 1),
                                                  (64, 130, 64, 2, 0), (33, 7, 21, 2, 1)])
 def test_gp_gemm_against_torch(M, N, K, batch, transA):
-    """hlvae_gp_gemm, C = alpha op(A) B + beta D on the fp64 matrix cores: the fragment-from-L2 kernel (N <= 128, K % 4 == 0: every
-    product of the GP step, with and without split-K) and the LDS-staged one (everything else) against torch.float64."""
+    """hlvae_gp_gemm, C = alpha op(A) B + beta D on the fp64 matrix cores (both tile heights, with and without split-K, odd sizes)
+    against torch.float64."""
     import ctypes as C
     from hlvae_amd import _lib
     lib = _lib.load()
