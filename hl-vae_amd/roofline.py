@@ -142,6 +142,20 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None, P_
         else:
             trainer.step(batch["data"], batch["mask"], P_batch, train_x=batch.get("labels"))
 
+    # the GP prior's chains are Python-side streams: for this pass they collapse onto the caller's stream, like the library's own
+    # side streams under hlvae_prof_enable -- every kernel is then timed ALONE (with the chains side by side the "alone" column
+    # of a GP configuration was the contended duration)
+    gp = getattr(trainer, "gp", None)
+    serial_gp = gp is not None and hasattr(gp, "_serial") and not gp._serial
+
+    def gp_streams(serial):
+        torch.cuda.synchronize()
+        gp._serial = serial
+        gp._side = gp._prep_stream = gp._ahead_stream = None
+        gp._prep = None
+
+    if serial_gp:
+        gp_streams(True)
     for _ in range(3):
         one()
     torch.cuda.synchronize()
@@ -149,6 +163,8 @@ def measure_dominant_kernel(trainer, batch, steps, eager_steps=None, ds=None, P_
     for _ in range(n):
         one()
     lib.hlvae_prof_enable(0)
+    if serial_gp:
+        gp_streams(False)
     buf = C.create_string_buffer(1 << 16)
     _lib.check(lib.hlvae_prof_report(buf, len(buf)), "hlvae_prof_report")
     work = algorithmic_work(m, B, trainer.dp.world if trainer.dp is not None else 1)
