@@ -1463,11 +1463,79 @@ __device__ __forceinline__ void gp_rb_sweep_lds(const double* As, const double* 
         }
     }
 }
+// both A operands from LDS row blocks: acc0 += As0 B (B k-major in global memory), acc1 += As1 (Bt given ? Bt^T : B)
+// (the A fragments of a row block are the same for all eight waves: read from global memory by each of them they were eight
+//  times the L2 traffic of the B fragments and the latency every k-block waited for)
+template <bool USE0, bool USE1, bool TRANS_B1>
+__device__ __forceinline__ void gp_rb_sweep_lds2(const double* As0, const double* As1, const double* __restrict__ B,
+                                                 const double* __restrict__ Bt, int N, int col, bool cok, int g, int q,
+                                                 f64x4_t (&acc0)[2], f64x4_t (&acc1)[2]) {
+    typedef __attribute__((ext_vector_type(2))) double f64x2_t;
+    const unsigned offb = (unsigned)(4 * g * N + min(col, N - 1)), offbt = (unsigned)(min(col, N - 1) * N + 4 * g);
+    auto loadb = [&](int kb, double (&b)[4], f64x4_t& bt) {
+        const bool kok = kb + 4 * g < N;
+        if (USE0 || !TRANS_B1)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) b[s_] = (B + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
+        if (TRANS_B1) bt = *reinterpret_cast<const f64x4_t*>(Bt + kb + (kok ? offbt : 0u));
+        if (!(kok && cok)) { if (USE0 || !TRANS_B1) { b[0] = b[1] = b[2] = b[3] = 0.0; } if (TRANS_B1) bt = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
+    };
+    auto mma = [&](int kb, const double (&b)[4], const f64x4_t& bt) {
+        const bool kok = kb + 4 * g < N;
+        const int kc = kok ? kb + 4 * g : 0;
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+            double t0[4], t1[4];
+            if (USE0) {
+                const double* tp = As0 + (16 * fi + q) * GP_RB_LD + kc;
+                const f64x2_t x01 = *reinterpret_cast<const f64x2_t*>(tp), x23 = *reinterpret_cast<const f64x2_t*>(tp + 2);
+                t0[0] = x01[0]; t0[1] = x01[1]; t0[2] = x23[0]; t0[3] = x23[1];
+                if (!kok) { t0[0] = t0[1] = t0[2] = t0[3] = 0.0; }
+            }
+            if (USE1) {
+                const double* tp = As1 + (16 * fi + q) * GP_RB_LD + kc;
+                const f64x2_t x01 = *reinterpret_cast<const f64x2_t*>(tp), x23 = *reinterpret_cast<const f64x2_t*>(tp + 2);
+                t1[0] = x01[0]; t1[1] = x01[1]; t1[2] = x23[0]; t1[3] = x23[1];
+                if (!kok) { t1[0] = t1[1] = t1[2] = t1[3] = 0.0; }
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                if (USE0) acc0[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0[s_], b[s_], acc0[fi], 0, 0, 0);
+                if (USE1) acc1[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(t1[s_], TRANS_B1 ? bt[s_] : b[s_], acc1[fi], 0, 0, 0);
+            }
+        }
+    };
+    double b0[4], b1[4];
+    f64x4_t bt0, bt1;
+    loadb(0, b0, bt0);
+    for (int kb = 0; kb < N; kb += 32) {
+        const bool more = kb + 16 < N;
+        if (more) loadb(kb + 16, b1, bt1);
+        mma(kb, b0, bt0);
+        if (more) {
+            if (kb + 32 < N) loadb(kb + 32, b0, bt0);
+            mma(kb + 16, b1, bt1);
+        }
+    }
+}
+// rows [R0, R0 + 32) of a row-major N x N matrix -> LDS [32][GP_RB_LD] (16-byte pieces, zero rows past the matrix)
+__device__ __forceinline__ void gp_rb_stage(const double* __restrict__ A, int N, int R0, double* As, int tid) {
+    typedef __attribute__((ext_vector_type(2))) double f64x2_t;
+    const int n2 = N >> 1;                                    // (N even)
+    for (int e = tid; e < 32 * n2; e += 512) {
+        const int r = e / n2, c2 = e - r * n2;
+        const f64x2_t v = R0 + r < N ? *reinterpret_cast<const f64x2_t*>(A + (size_t)(R0 + r) * N + 2 * c2) : f64x2_t{0.0, 0.0};
+        *reinterpret_cast<f64x2_t*>(As + r * GP_RB_LD + 2 * c2) = v;
+    }
+}
 template <int PHASE>
 __global__ __launch_bounds__(512) void k_gp_chain_rb(GpChainRbArgs a) {
     extern __shared__ __attribute__((aligned(16))) double rb_sm[];
     double* t1s = rb_sm;                                      // T1 (phase 1) / T1b (phase 2) rows   [32][GP_RB_LD]
-    double* ms = t1s + 32 * GP_RB_LD;                         // m, P1, u   [GP_MMAX] each
+    double* ar0 = t1s + 32 * GP_RB_LD;                        // staged A row blocks: iK[R] | (phase 1) (H iK)[R] | W[R]
+    double* ar1 = ar0 + 32 * GP_RB_LD;
+    double* ar2 = ar1 + 32 * GP_RB_LD;
+    double* ms = ar2 + 32 * GP_RB_LD;                         // m, P1, u   [GP_MMAX] each
     double* ps = ms + GP_MMAX;
     double* us = ps + GP_MMAX;
     double* rowsum = us + GP_MMAX;                            // sum_j Bm[i][j] m[j] of the block's rows  [32]
@@ -1482,9 +1550,13 @@ __global__ __launch_bounds__(512) void k_gp_chain_rb(GpChainRbArgs a) {
         const double* HiK = a.HiK + o;
         if (tid < N) { ms[tid] = a.m[ov + tid]; ps[tid] = a.P1[ov + tid]; us[tid] = a.u[ov + tid]; }
         if (tid < 32) rowsum[tid] = 0.0;
+        gp_rb_stage(iK, N, R0, ar0, tid);
+        gp_rb_stage(HiK, N, R0, ar1, tid);
+        gp_rb_stage(W, N, R0, ar2, tid);
+        __syncthreads();
         // sweep over W: T1 rows = iK[R] W, X rows = HiK[R] W
         f64x4_t at[2] = {z2[0], z2[1]}, ax[2] = {z2[0], z2[1]};
-        gp_rb_sweep_global<true, true, false>(iK, HiK, W, nullptr, N, R0, col, cok, g, q, at, ax);
+        gp_rb_sweep_lds2<true, true, false>(ar0, ar1, W, nullptr, N, col, cok, g, q, at, ax);
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
@@ -1492,9 +1564,8 @@ __global__ __launch_bounds__(512) void k_gp_chain_rb(GpChainRbArgs a) {
                 if (cok) t1s[(16 * fi + g + 4 * r) * GP_RB_LD + col] = at[fi][r];
         __syncthreads();
         // P = T1 iK (A from LDS);  X^T rows = W[R] (H iK)^T (B transposed)
-        f64x4_t ap[2] = {z2[0], z2[1]}, axt[2] = {z2[0], z2[1]}, dum[2] = {z2[0], z2[1]};
-        gp_rb_sweep_lds(t1s, iK, N, col, cok, g, q, ap);
-        gp_rb_sweep_global<false, true, true>(W, W, iK, HiK, N, R0, col, cok, g, q, dum, axt);
+        f64x4_t ap[2] = {z2[0], z2[1]}, axt[2] = {z2[0], z2[1]};
+        gp_rb_sweep_lds2<true, true, true>(t1s, ar2, iK, HiK, N, col, cok, g, q, ap, axt);
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
@@ -1534,8 +1605,10 @@ __global__ __launch_bounds__(512) void k_gp_chain_rb(GpChainRbArgs a) {
         }
     } else {
         const double* Rs = a.Rs + o;
+        gp_rb_stage(iK, N, R0, ar0, tid);
+        __syncthreads();
         f64x4_t at[2] = {z2[0], z2[1]}, dum[2] = {z2[0], z2[1]};
-        gp_rb_sweep_global<true, false, false>(iK, nullptr, Rs, nullptr, N, R0, col, cok, g, q, at, dum);      // T1b rows = iK[R] Rs
+        gp_rb_sweep_lds2<true, false, false>(ar0, nullptr, Rs, nullptr, N, col, cok, g, q, at, dum);      // T1b rows = iK[R] Rs
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
@@ -1543,7 +1616,7 @@ __global__ __launch_bounds__(512) void k_gp_chain_rb(GpChainRbArgs a) {
                 if (cok) t1s[(16 * fi + g + 4 * r) * GP_RB_LD + col] = at[fi][r];
         __syncthreads();
         f64x4_t ag[2] = {z2[0], z2[1]};
-        gp_rb_sweep_lds(t1s, iK, N, col, cok, g, q, ag);
+        gp_rb_sweep_lds2<true, false, false>(t1s, nullptr, iK, nullptr, N, col, cok, g, q, ag, dum);
 #pragma unroll
         for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
@@ -1891,7 +1964,13 @@ int hlvae_gp_chain_rb(const double* iK, const double* W, const double* HiK, cons
                       double* grad_m, double* grad_H, double* tmp, double* Rs, double* G, hlvae_stream s) {
     HL_REQUIRE(iK && W && HiK && H && iH && m && P1 && u && grad_m && grad_H && tmp && Rs && G, HLVAE_EINVAL, "gp_chain_rb: null argument");
     HL_REQUIRE(N >= 4 && N <= GP_MMAX && N % 4 == 0 && batch >= 1, HLVAE_ESHAPE, "gp_chain_rb: N=%d (a multiple of 4, at most %d)", N, GP_MMAX);
-    const size_t smem = ((size_t)32 * GP_RB_LD + 3 * GP_MMAX + 32) * sizeof(double);
+    const size_t smem = ((size_t)4 * 32 * GP_RB_LD + 3 * GP_MMAX + 32) * sizeof(double);
+    static bool attr = false;
+    if (!attr) {
+        HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_chain_rb<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        HL_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gp_chain_rb<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
     GpChainRbArgs a{iK, W, HiK, H, iH, m, P1, u, grad_m, grad_H, tmp, Rs, G, lr, c, g_alpha, g_beta, N};
     const dim3 grid(batch, (N + 31) / 32);
     HL_PROF("gp_chain", (hipStream_t)s);

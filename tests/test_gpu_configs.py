@@ -787,3 +787,23 @@ def test_workspace_grows_at_the_top_of_the_step_not_inside_it():
     model._ensure_device_state(96)
     with pytest.raises(RuntimeError, match="does not fit the workspace"):
         model._require_capacity(200)
+
+
+@pytest.mark.gpu
+def test_head_kernel_cores_are_bit_identical():
+    """The head kernel's GEMM phase exists in two LDS-DMA forms (csrc/gemm_dma.h): [A; B] through LDS (HL_HEADS_CORE=1) and, the default
+    for K a multiple of 256, A fragments loaded straight to registers by inline assembly with hand-counted s_waitcnt.  A stage
+    register copied by the compiler before its wait would hand stale data on -- so the two forms must leave bit-identical dY (both
+    layouts), log-likelihoods and x_hat (tools/heads_ab.py, one process per form: the choice is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for core in ("1", "2"):
+        env = dict(os.environ, HL_HEADS_CORE=core)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "heads_ab.py"), "512"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l.split(": ", 1)[1] for l in r.stdout.splitlines() if l.startswith("core=")]
+        assert len(lines) == 3, r.stdout[-2000:]
+        outs.append(lines)
+    assert outs[0] == outs[1], (outs[0][-1], outs[1][-1])
