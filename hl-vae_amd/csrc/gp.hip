@@ -1378,91 +1378,6 @@ struct GpChainRbArgs {
     double lr, c, g_alpha, g_beta;
     int N;
 };
-// one sweep over a k-major B operand (B[k][col], rows of N) with up to two A operands read from global rows (A0, A1: [row][k]) and
-// optionally a second B given TRANSPOSED (Bt[col][k]) paired with A1 -- accumulators acc0 += A0 B, acc1 += A1 (Bt ? Bt^T : B)
-template <bool USE0, bool TWO_A, bool TRANS_B1>
-__device__ __forceinline__ void gp_rb_sweep_global(const double* __restrict__ A0, const double* __restrict__ A1,
-                                                   const double* __restrict__ B, const double* __restrict__ Bt, int N, int R0,
-                                                   int col, bool cok, int g, int q, f64x4_t (&acc0)[2], f64x4_t (&acc1)[2]) {
-    bool rok[2];
-    unsigned offa[2];
-#pragma unroll
-    for (int fi = 0; fi < 2; ++fi) { rok[fi] = R0 + 16 * fi + q < N; offa[fi] = (unsigned)(min(R0 + 16 * fi + q, N - 1) * N + 4 * g); }
-    const unsigned offb = (unsigned)(4 * g * N + min(col, N - 1)), offbt = (unsigned)(min(col, N - 1) * N + 4 * g);
-    auto load = [&](int kb, f64x4_t (&x0)[2], f64x4_t (&x1)[2], double (&b)[4], f64x4_t& bt) {
-        const bool kok = kb + 4 * g < N;
-#pragma unroll
-        for (int fi = 0; fi < 2; ++fi) {
-            if (USE0) x0[fi] = *reinterpret_cast<const f64x4_t*>(A0 + kb + (kok ? offa[fi] : 0u));
-            if (TWO_A) x1[fi] = *reinterpret_cast<const f64x4_t*>(A1 + kb + (kok ? offa[fi] : 0u));
-        }
-        if (USE0 || !TRANS_B1)
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) b[s_] = (B + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
-        if (TRANS_B1) bt = *reinterpret_cast<const f64x4_t*>(Bt + kb + (kok ? offbt : 0u));
-#pragma unroll
-        for (int fi = 0; fi < 2; ++fi)
-            if (!(kok && rok[fi])) { if (USE0) x0[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; if (TWO_A) x1[fi] = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
-        if (!(kok && cok)) { if (USE0 || !TRANS_B1) { b[0] = b[1] = b[2] = b[3] = 0.0; } if (TRANS_B1) bt = f64x4_t{0.0, 0.0, 0.0, 0.0}; }
-    };
-    auto mma = [&](const f64x4_t (&x0)[2], const f64x4_t (&x1)[2], const double (&b)[4], const f64x4_t& bt) {
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-            for (int fi = 0; fi < 2; ++fi) {
-                if (USE0) acc0[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[fi][s_], b[s_], acc0[fi], 0, 0, 0);
-                if (TWO_A) acc1[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[fi][s_], TRANS_B1 ? bt[s_] : b[s_], acc1[fi], 0, 0, 0);
-            }
-    };
-    f64x4_t xa0[2], xb0[2], xa1[2], xb1[2], bt0, bt1;
-    double b0[4], b1[4];
-    load(0, xa0, xb0, b0, bt0);
-    for (int kb = 0; kb < N; kb += 32) {
-        const bool more = kb + 16 < N;
-        if (more) load(kb + 16, xa1, xb1, b1, bt1);
-        mma(xa0, xb0, b0, bt0);
-        if (more) {
-            if (kb + 32 < N) load(kb + 32, xa0, xb0, b0, bt0);
-            mma(xa1, xb1, b1, bt1);
-        }
-    }
-}
-// acc += (LDS row block [32][GP_RB_LD]) B, B k-major in global memory
-__device__ __forceinline__ void gp_rb_sweep_lds(const double* As, const double* __restrict__ B, int N, int col, bool cok, int g, int q,
-                                                f64x4_t (&acc)[2]) {
-    typedef __attribute__((ext_vector_type(2))) double f64x2_t;
-    const unsigned offb = (unsigned)(4 * g * N + min(col, N - 1));
-    auto loadb = [&](int kb, double (&b)[4]) {
-        const bool kok = kb + 4 * g < N;
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) b[s_] = (B + (size_t)kb * N)[(kok ? offb : 0u) + (unsigned)(s_ * N)];
-        if (!(kok && cok)) { b[0] = b[1] = b[2] = b[3] = 0.0; }
-    };
-    auto mma = [&](int kb, const double (&b)[4]) {
-        const bool kok = kb + 4 * g < N;
-        const int kc = kok ? kb + 4 * g : 0;
-#pragma unroll
-        for (int fi = 0; fi < 2; ++fi) {
-            const double* tp = As + (16 * fi + q) * GP_RB_LD + kc;
-            const f64x2_t t01 = *reinterpret_cast<const f64x2_t*>(tp), t23 = *reinterpret_cast<const f64x2_t*>(tp + 2);
-            double tv[4] = {t01[0], t01[1], t23[0], t23[1]};
-            if (!kok) { tv[0] = tv[1] = tv[2] = tv[3] = 0.0; }
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) acc[fi] = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[s_], b[s_], acc[fi], 0, 0, 0);
-        }
-    };
-    double b0[4], b1[4];
-    loadb(0, b0);
-    for (int kb = 0; kb < N; kb += 32) {
-        const bool more = kb + 16 < N;
-        if (more) loadb(kb + 16, b1);
-        mma(kb, b0);
-        if (more) {
-            if (kb + 32 < N) loadb(kb + 32, b0);
-            mma(kb + 16, b1);
-        }
-    }
-}
 // both A operands from LDS row blocks: acc0 += As0 B (B k-major in global memory), acc1 += As1 (Bt given ? Bt^T : B)
 // (the A fragments of a row block are the same for all eight waves: read from global memory by each of them they were eight
 //  times the L2 traffic of the B fragments and the latency every k-block waited for)
