@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(THREADS) void k_gp_chain(GpChainArgs a) {
 // X^T = W (H iK)^T needs no other block's results, so launch 1 gives one workgroup per (latent, row block) the natural-gradient
 // outputs and its rows of Rs = c (u m^T + m u^T - W + X + X^T) + H + m m^T; launch 2 does the same for T1b = iK Rs and
 // G = g_alpha T1b iK + g_beta iK once Rs is whole.  2 x 128 workgroups that never wait for each other, six 32 x N x N product
-// passes in all, intermediate row blocks in LDS -- 42 us alone where k_gp_chain takes 97 (64 workgroups, up to three dependent
+// passes in all, A and intermediate row blocks in LDS -- 52 us alone where k_gp_chain takes 97 (64 workgroups, up to three dependent
 // N x N x N products each) and the eight separate launches 79.
 // (An expanded form -- iK Rs iK = c [..] - c T1 iK + c (Q W iK + T1 Q) + Q + .. with Q = iK H iK, five passes in ONE launch -- was
 //  built first and is algebraically equal, but it cancels AFTER the multiplication by iK instead of inside Rs: on the
