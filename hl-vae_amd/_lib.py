@@ -137,6 +137,8 @@ _SIGS = {
     "hlvae_gp_bound": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                  C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "hlvae_gp_adam": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
+    "hlvae_gp_state_head": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _vp,
+                                      _vp, _vp, C.c_double, C.c_int, C.c_int, _vp]),
     "hlvae_reset_pending": (C.c_int, [_vp]),
     "hlvae_stamp_slots": (C.c_int, []),
     "hlvae_stamp_words": (C.c_int, []),

@@ -201,10 +201,12 @@ template <int NT, int NR>
 __global__ __launch_bounds__(256) void k_gp_kernel_matrix(hlvae_gp_kernel k, const double* __restrict__ hyp, int n_slots, int L,
                                                           int Q, const double* __restrict__ x1, int n1, int per_latent1,
                                                           const double* __restrict__ x2, int n2, int per_latent2,
-                                                          double jitter, double* __restrict__ out) {
+                                                          double jitter, double* __restrict__ out, int rows_wg) {
+    // rows_wg <= GP_KM_ROWS rows per workgroup: 32 for the batch's K0xz, 8 for K0zz (120 rows: 4 x L workgroups walked 16 rows
+    // per thread one after the other -- 26 us on the state update's chain for 0.46 M entries; 15 x L workgroups of 4 rows)
     __shared__ double xs[GP_KM_ROWS * GP_XS], zs[GP_MMAX * GP_XS];
-    const int l = blockIdx.y, row0 = blockIdx.x * GP_KM_ROWS, tid = threadIdx.x;
-    const int nrow = min(GP_KM_ROWS, n1 - row0);
+    const int l = blockIdx.y, row0 = blockIdx.x * rows_wg, tid = threadIdx.x;
+    const int nrow = min(rows_wg, n1 - row0);
     const double* x1l = x1 + (size_t)(per_latent1 ? l : 0) * n1 * Q;
     const double* x2l = x2 + (size_t)(per_latent2 ? l : 0) * n2 * Q;
     for (int e = tid; e < nrow * Q; e += 256) xs[(e / Q) * GP_XS + e % Q] = x1l[(size_t)row0 * Q + e];
@@ -1666,6 +1668,52 @@ __global__ __launch_bounds__(256) void k_gp_adam(double* __restrict__ p, double*
     }
 }
 
+// The head of the prior's state update as ONE launch (round 3): Adam on [raw hyper-parameters | inducing points] with the
+// transform of the hyper-parameters it has just produced, and iH <- iH + lr (grad_H + grad_H^T) in the remaining workgroups --
+// k_gp_adam -> k_gp_ih_update -> k_gp_transform were three dependent launches of 5-8 us each at the start of the step's serial tail.
+__global__ __launch_bounds__(256) void k_gp_state_head(double* __restrict__ p, double* __restrict__ g, double* __restrict__ m1,
+                                                       double* __restrict__ m2, int n, int64_t* __restrict__ step, double lr,
+                                                       double b1, double b2, double eps, int n_hyp, double* __restrict__ hyp,
+                                                       const double* __restrict__ grad_H, double* __restrict__ iH, double ng_lr,
+                                                       int N, int n_ih, int blocks_adam) {
+    if ((int)blockIdx.x < blocks_adam) {
+        const double t = (double)(step[0] + 1);
+        const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+        const double step_size = lr / bc1, rs = 1.0 / sqrt(bc2);
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n) {
+            const double gi = g[i];
+            const double a = b1 * m1[i] + (1.0 - b1) * gi, v = b2 * m2[i] + (1.0 - b2) * gi * gi;
+            m1[i] = a;
+            m2[i] = v;
+            const double pn = p[i] - step_size * a / (sqrt(v) * rs + eps);
+            p[i] = pn;
+            g[i] = 0.0;
+            if (i < n_hyp) {                                      // k_gp_transform
+                const double x = pn + 16.0;
+                const double sp = x > 20.0 ? x : log1p(exp(x));
+                const double pos = exp(sp - 16.0);
+                hyp[i] = pos;
+                hyp[(size_t)n_hyp + i] = 1.0 / (1.0 + exp(-x));
+                hyp[(size_t)2 * n_hyp + i] = 1.0 / (pos * pos);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long*>(step + 1), 1ull);
+            if (done == (unsigned long long)blocks_adam - 1) {
+                step[1] = 0;
+                step[0] += 1;
+            }
+        }
+    } else {                                                      // k_gp_ih_update
+        const int e = ((int)blockIdx.x - blocks_adam) * 256 + threadIdx.x;
+        if (e >= n_ih) return;
+        const int NN = N * N, l = e / NN, ij = e - l * NN, i = ij / N, j = ij - i * N;
+        iH[e] += ng_lr * (grad_H[e] + grad_H[(size_t)l * NN + (size_t)j * N + i]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------
@@ -1706,12 +1754,14 @@ int hlvae_gp_kernel_matrix(const hlvae_gp_kernel* k, const double* hyp, int n_sl
     HL_REQUIRE(hyp && x1 && x2 && out && L > 0 && n1 > 0 && n2 > 0, HLVAE_EINVAL, "gp_kernel_matrix: bad arguments");
     HL_REQUIRE(n2 <= GP_MMAX && Q <= 8, HLVAE_ESHAPE, "gp_kernel_matrix: n2=%d (max %d columns), Q=%d (max 8)", n2, GP_MMAX, Q);
     HL_PROF("gp_kernel_matrix", (hipStream_t)s);
-    const dim3 grid((n1 + GP_KM_ROWS - 1) / GP_KM_ROWS, L);
+    const int rows_wg = (long)((n1 + GP_KM_ROWS - 1) / GP_KM_ROWS) * L >= 512 ? GP_KM_ROWS : 8;
+    const dim3 grid((n1 + rows_wg - 1) / rows_wg, L);
     if (gp_kernel_small(k))
-        k_gp_kernel_matrix<4, 1><<<grid, 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2, per_latent2, jitter, out);
+        k_gp_kernel_matrix<4, 1><<<grid, 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2, per_latent2, jitter, out,
+                                                                  rows_wg);
     else
         k_gp_kernel_matrix<HLVAE_GP_MAX_TERMS, GP_MAX_RBF><<<grid, 256, 0, (hipStream_t)s>>>(*k, hyp, n_slots, L, Q, x1, n1, per_latent1, x2, n2,
-                                                                                           per_latent2, jitter, out);
+                                                                                           per_latent2, jitter, out, rows_wg);
     HL_LAUNCH_CHECK();
     return 0;
 }
@@ -2004,6 +2054,19 @@ int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* 
     HL_REQUIRE(p && g && m1 && m2 && step && n > 0, HLVAE_EINVAL, "gp_adam: bad arguments");
     HL_PROF("gp_adam", (hipStream_t)s);
     k_gp_adam<<<(n + 255) / 256, 256, 0, (hipStream_t)s>>>(p, g, m1, m2, n, step, lr, b1, b2, eps);
+    HL_LAUNCH_CHECK();
+    return 0;
+}
+
+int hlvae_gp_state_head(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,
+                        double eps, int n_slots, int L, double* hyp, const double* grad_H, double* iH, double ng_lr, int N, int batch,
+                        hlvae_stream s) {
+    HL_REQUIRE(p && g && m1 && m2 && step && hyp && grad_H && iH && n > 0 && n_slots > 0 && L > 0 && n_slots * L <= n && N >= 1 && batch >= 1,
+               HLVAE_EINVAL, "gp_state_head: bad arguments");
+    const int blocks_adam = (n + 255) / 256, n_ih = batch * N * N;
+    HL_PROF("gp_adam", (hipStream_t)s);
+    k_gp_state_head<<<blocks_adam + (n_ih + 255) / 256, 256, 0, (hipStream_t)s>>>(p, g, m1, m2, n, step, lr, b1, b2, eps, n_slots * L, hyp, grad_H,
+                                                                                   iH, ng_lr, N, n_ih, blocks_adam);
     HL_LAUNCH_CHECK();
     return 0;
 }

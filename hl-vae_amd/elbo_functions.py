@@ -806,13 +806,12 @@ class GPPriorHIP:
     def _state_update(self, next_batch=None):
         lib, st, L, M = _lib.load(), self._stream(), self.L, self.M
         self._ahead = None
-        _lib.check(lib.hlvae_gp_adam(_lib.ptr(self._theta), _lib.ptr(self._gtheta), _lib.ptr(self._adam_m),
-                                     _lib.ptr(self._adam_v), self._theta.numel(), _lib.ptr(self._adam_step),
-                                     _C.c_double(self.lr), _C.c_double(0.9), _C.c_double(0.999), _C.c_double(1e-8), st), "gp_adam")
-        _lib.check(lib.hlvae_gp_natgrad_apply(_lib.ptr(self._grad_H), _lib.ptr(self._iHb), _C.c_double(self.ng_lr), M, L, st),
-                   "gp_natgrad_apply")                                       # iH_new, in place in _KH2[:L]
+        # Adam, the transform of the hyper-parameters it produced and iH_new (in place in _KH2[:L]): one launch
+        _lib.check(lib.hlvae_gp_state_head(_lib.ptr(self._theta), _lib.ptr(self._gtheta), _lib.ptr(self._adam_m), _lib.ptr(self._adam_v),
+                                           self._theta.numel(), _lib.ptr(self._adam_step), _C.c_double(self.lr), _C.c_double(0.9),
+                                           _C.c_double(0.999), _C.c_double(1e-8), self.n_slots, L, _lib.ptr(self._hyp),
+                                           _lib.ptr(self._grad_H), _lib.ptr(self._iHb), _C.c_double(self.ng_lr), M, L, st), "gp_state_head")
         self._iH = None
-        self._transform()
         if next_batch is not None:
             self.compute_ahead(*next_batch)
         self.kernel_matrix(self.k0, self.zt_list, self.zt_list, jitter=self.eps, out=self._KH2[L:])

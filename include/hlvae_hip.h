@@ -450,6 +450,12 @@ int hlvae_gp_chain_rb(const double* iK, const double* W, const double* HiK, cons
  * step: device int64[2] = {completed steps, 0}, advanced by the kernel; the consumed gradients are zeroed. */
 int hlvae_gp_adam(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,
                   double eps, hlvae_stream s);
+/* hlvae_gp_adam on the arena [raw hyper-parameters n_slots x L | inducing points], hlvae_gp_transform of the updated
+ * hyper-parameters into hyp, and hlvae_gp_natgrad_apply (iH += ng_lr (grad_H + grad_H^T), [batch][N][N]) as ONE launch: the head of
+ * the prior's state update (reference HLVAE_main.py:277-278, training.py:130-133). */
+int hlvae_gp_state_head(double* p, double* g, double* m1, double* m2, int n, int64_t* step, double lr, double b1, double b2,
+                        double eps, int n_slots, int L, double* hyp, const double* grad_H, double* iH, double ng_lr, int N, int batch,
+                        hlvae_stream s);
 
 /* Per-kernel HIP-event timing (bench.py's roofline leg): while enabled every kernel launch of this library is
  * bracketed by hipEventRecord on its stream, and the work the library normally forks onto its side streams is queued on
