@@ -114,9 +114,6 @@ class HLVAE(nn.Module):
         if conv and (n_variables != 36 * 36 or y_dim != 5):
             raise ValueError("conv=True views the variables as one 36 x 36 image with y_dim = 5 output channels "
                              "(reference HLVAE.py:305, 257-258)")
-        if logvar_network and conv:
-            raise NotImplementedError("logvar_network=True with the convolutional decoder is not built (the shipped configuration "
-                                      "uses logvar_network=False, config/hlvae_config_file.txt)")
         if not (isinstance(h_dim_e, (list, tuple)) and isinstance(h_dim_d, (list, tuple))
                 and 1 <= len(h_dim_e) <= 1 + _lib.MAX_EXTRA and 1 <= len(h_dim_d) <= 1 + _lib.MAX_EXTRA
                 and all(int(w) > 0 for w in list(h_dim_e) + list(h_dim_d))):

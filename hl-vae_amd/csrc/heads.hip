@@ -621,7 +621,7 @@ __global__ __launch_bounds__(HL_THREADS, (YD > 5 || KMAX > 8) ? 1 : (KMAX <= 5 ?
                 const bool is_pos = var.kind == HLVAE_POS;
                 if (logvar)      // (uniform: a kernel argument)
                     proc_realpos<YD, BM, CLD, NHEAD, true>(is_pos, Cs, v, rg, m0, B, D, dv, var, P, norm, n_stat, byv, xt, m8, g_elem,
-                                                           g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, false);
+                                                           g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, conv && !is_pos);
                 else
                     proc_realpos<YD, BM, CLD, NHEAD, false>(is_pos, Cs, v, rg, m0, B, D, dv, var, P, norm, n_stat, byv, xt, m8, g_elem,
                                                             g_scale, logpx, logpx_miss, pfull, X, xhat, hacc, lpo, conv && !is_pos);

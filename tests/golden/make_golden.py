@@ -220,6 +220,36 @@ def case_d4_conv():
     print("d4_conv_small loss", out["loss"])
 
 
+def case_d4_conv_logvar():
+    """conv=True together with logvar_network=True (round 3): the sigmoid of the convolutional decoder goes on the MEAN half of a real
+    variable's head output only (HLVAE.py:428-430: obs_output[:, :cov_dim]), the log-variance half is the head's second output
+    (HLVAE.py:42-51, loglik.py:45-47)."""
+    src = synthetic.make_d4(n_subjects=2, T=4, seed=5)
+    dims = [src.cov_dim_ext, [32], 8, [32], 5]
+    info = layout.build_types_info(src.types_info["types_dict"], miss_mask=src.mask, logvar_network=True)
+    state = orc.init_state(dims, info, src.n_variables, seed=19, std=0.05, conv=True, logvar_network=True)
+    out, grads = run_reference_model(src, np.arange(8), dims, state, seed=29, nll_scale=2.5, conv=True, logvar_network=True)
+    out["data_argsum"] = np.array([out["data"].sum(), (out["data"] * np.arange(out["data"].shape[1])).sum()])
+    del out["data"]
+    out["state_checksum"] = state_checksum(state)
+    small = ("mean_layer.0.weight", "mean_layer.0.bias", "log_var_layer.0.bias", "d_layers.0.bias", "obs_layer.0.bias",
+             "obs_layer.1.bias_mean", "obs_layer.1.weight_mean", "obs_layer.1.bias_logvar", "obs_layer.1.weight_logvar",
+             "VAE_encoder_common_layers.0.bias", "conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "deconv_layer.0.weight",
+             "deconv_layer.0.bias", "deconv_layer.2.weight", "deconv_layer.2.bias", "representation_layer.0.weight",
+             "representation_layer.0.bias", "y_layer.0.bias")
+    for k in small:
+        out["grad__" + k] = np64(grads[k])
+    out["grad_slice__y_layer.0.weight"] = np64(grads["y_layer.0.weight"][:40])
+    out["grad_slice__VAE_encoder_common_layers.0.weight"] = np64(grads["VAE_encoder_common_layers.0.weight"][:, :64])
+    out["grad_slice__obs_layer.0.weight"] = np64(grads["obs_layer.0.weight"][:50])
+    for k in list(out):
+        if k.startswith("p_params") or k.startswith("test_p_params") or k in ("p_params_full",):
+            out[k] = out[k][:, :200] if out[k].ndim == 2 else out[k][:, :40]
+    out["param_indexes"] = np.asarray(info["param_indexes"])
+    np.savez_compressed(os.path.join(HERE, "d4_conv_logvar_small.npz"), **out)
+    print("d4_conv_logvar_small loss", out["loss"])
+
+
 def case_types_info():
     """reference read_data on CSV files written from the mix spec (layout pin)."""
     src = synthetic.make_tabular(n_rows=24, T=6, seed=7, spec=MIX_SPEC)
@@ -418,3 +448,4 @@ if __name__ == "__main__":
     case_gp()
     case_gp_predict()
     case_mix_logvar_deep()
+    case_d4_conv_logvar()
