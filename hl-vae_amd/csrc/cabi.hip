@@ -207,7 +207,7 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
         if (v.kind == HLVAE_REAL || v.kind == HLVAE_POS) {
             const bool lvn = v.w2_off >= 0;      // logvar_network: a second head (log-variance) instead of the free parameter
             HL_REQUIRE(v.sidx >= 0 && v.sidx < d.n_stat && (lvn ? (v.b2_off >= 0 && v.w2_off < d.atomic_region && v.b2_off < d.atomic_region &&
-                                                                   v.poff2 >= 0 && v.poff2 < d.Theta && !d.conv)
+                                                                   v.poff2 >= 0 && v.poff2 < d.Theta)
                                                                 : v.e_off >= 0), HLVAE_EINVAL, "variable %d: sidx / variance parameter offsets", i);
             stat_var[v.sidx] = i;
             ++nstat_seen;
