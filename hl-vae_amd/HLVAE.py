@@ -119,8 +119,6 @@ class HLVAE(nn.Module):
                 and all(int(w) > 0 for w in list(h_dim_e) + list(h_dim_d))):
             raise NotImplementedError(f"dims[1] / dims[3] must list 1..{1 + _lib.MAX_EXTRA} positive hidden widths per side (reference "
                                       "config: [500]; the reference's h_dim = [] / 0 'no hidden layer' variants are not built)")
-        if conv and (len(h_dim_e) != 1 or len(h_dim_d) != 1):
-            raise NotImplementedError("the convolutional model is built with one hidden layer per side (config/hlvae_config_file.txt)")
         h_dim_e = [int(w) for w in h_dim_e]
         h_dim_d = [int(i) for i in reversed(h_dim_d)]                               # HLVAE.py:113
         self.z_dim, self.num_dim, self.y_dim = z_dim, n_variables, y_dim

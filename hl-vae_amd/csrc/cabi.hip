@@ -42,6 +42,7 @@ int hl_launch_gemm_adam(AdamGemmGroup, float*, float*, float*, int64_t*, float, 
 int hl_wgrad_ksplit(long, int);
 int hl_launch_transpose_bf16(const bf16_t*, int, bf16_t*, int, int, int, const char*, hipStream_t);
 int hl_adam_grid(const hlvae_plan*, const hlvae_ws*, unsigned, int);
+unsigned hl_all_matrices(const hlvae_plan*);
 int hl_adam_part(const hlvae_plan*, const hlvae_ws*, float*, float*, int64_t*, float, float, float, float, float, unsigned, int,
                  unsigned, const char*, hipStream_t, long flat_n = -1, int tick_slot = 0);
 int hl_adam_flat(const hlvae_plan*, const hlvae_ws*, const float*, float*, float*, uint16_t*, const int64_t*, long, long, float, float,
@@ -159,7 +160,6 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     HL_REQUIRE(d.arena_size % 4 == 0, HLVAE_EINVAL, "plan_create: arena_size must be a multiple of 4 floats");
     HL_REQUIRE(dims->n_xe >= 0 && dims->n_xe <= HLVAE_MAX_EXTRA && dims->n_xd >= 0 && dims->n_xd <= HLVAE_MAX_EXTRA, HLVAE_EINVAL,
                "plan_create: at most %d extra hidden layers per side (got %d / %d)", HLVAE_MAX_EXTRA, dims->n_xe, dims->n_xd);
-    HL_REQUIRE(!d.conv || (d.n_xe == 0 && d.n_xd == 0), HLVAE_EINVAL, "plan_create: the convolutional model has one hidden layer per side");
     for (int i = 0; i < d.n_xe + d.n_xd; ++i) {     // chains: X -> xe[0] -> .. -> K1 (-> h_e);  h_d0 -> xd[0] -> .. -> h_d
         const bool enc = i < d.n_xe;
         const int k = enc ? i : i - d.n_xe;
@@ -762,7 +762,10 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     // nothing to keep apart, and the side chain (dWy -> Adam -> gradient fold) was what the final launch waited for
     const bool small_wy = opt != nullptr && !d.conv && !skip_wy && (long)d.NYl * d.h_d <= 512l * 1024;
     if (d.conv) {   // the convolutional features receive a gradient: d feat = dT W1, then conv2 / conv1 / representation layer
-        if ((rc = hl_launch_gemm_f32(ws->dt, d.hep, ws->w1Ts, d.hep, ws->dfeat, d.Xep, Bp, d.Xe, d.hep, 0, 0, nullptr, "dfeat", st))) return rc;   // (conv: K1 = Xe)
+        if (d.n_xe > 0) {   // deeper encoder: the features feed the FIRST extra layer, whose pre-activation gradient the loop above left
+            if ((rc = hl_launch_gemm_f32(ws->xe[0].d, d.xe[0].n_out_p, ws->xe[0].wT, d.xe[0].n_out_p, ws->dfeat, d.Xep, Bp, d.Xe, d.xe[0].n_out_p,
+                                         0, 0, nullptr, "dfeat", st))) return rc;
+        } else if ((rc = hl_launch_gemm_f32(ws->dt, d.hep, ws->w1Ts, d.hep, ws->dfeat, d.Xep, Bp, d.Xe, d.hep, 0, 0, nullptr, "dfeat", st))) return rc;   // (K1 = Xe)
         if (conv_opt) HL_CHECK(hipEventRecord(p->ev[1], st));      // dense gradients final, W1's transposed shadow read
         if ((rc = hl_launch_conv_enc_bwd(p, ws, B, st))) return rc;
     }
@@ -783,8 +786,8 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
                                    0u, "adam_wy_early", s0))) return rc;
             if (conv_opt) {     // convolutional model: the other dense matrices too, under the 56 us of the encoder's backward
                 HL_CHECK(hipStreamWaitEvent(s0, p->ev[1], 0));
-                if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0x1e,
-                                       0, 0u, "adam_dense_early", s0))) return rc;
+                if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
+                                       hl_all_matrices(p) & ~0x01u, 0, 0u, "adam_dense_early", s0))) return rc;      // (extra layers too)
             }
         }
         // head-parameter / y_layer-bias gradients: the head kernel left per-row-block partial sums; they are folded into the arena

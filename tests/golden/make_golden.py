@@ -250,6 +250,34 @@ def case_d4_conv_logvar():
     print("d4_conv_logvar_small loss", out["loss"])
 
 
+def case_d4_conv_deep():
+    """conv=True with two hidden layers per side (round 3; HLVAE.py:125-137 / 156-165 under conv, 232-242; h_dim_d reversed, :113): the
+    convolutional features feed the first extra encoder layer, the last decoder layer feeds y_layer's [2592]-wide Linear."""
+    src = synthetic.make_d4(n_subjects=2, T=4, seed=5)
+    hid_e, hid_d = [40, 32], [24, 48]
+    dims = [src.cov_dim_ext, hid_e, 8, hid_d, 5]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=23, std=0.05, conv=True)
+    out, grads = run_reference_model(src, np.arange(8), dims, state, seed=31, nll_scale=2.5, conv=True)
+    out["data_argsum"] = np.array([out["data"].sum(), (out["data"] * np.arange(out["data"].shape[1])).sum()])
+    del out["data"]
+    out["state_checksum"] = state_checksum(state)
+    small = ("mean_layer.0.weight", "mean_layer.0.bias", "log_var_layer.0.bias", "d_layers.0.bias", "d_layers.0.weight", "d_layers.2.bias",
+             "d_layers.2.weight", "_log_vy_real", "obs_layer.0.bias", "obs_layer.1.bias_mean", "obs_layer.1.weight_mean",
+             "VAE_encoder_common_layers.0.bias", "VAE_encoder_common_layers.2.bias", "VAE_encoder_common_layers.2.weight", "conv1.weight",
+             "conv1.bias", "conv2.weight", "conv2.bias", "deconv_layer.0.weight", "deconv_layer.0.bias", "deconv_layer.2.weight",
+             "deconv_layer.2.bias", "representation_layer.0.weight", "representation_layer.0.bias", "y_layer.0.bias")
+    for k in small:
+        out["grad__" + k] = np64(grads[k])
+    out["grad_slice__y_layer.0.weight"] = np64(grads["y_layer.0.weight"][:40])
+    out["grad_slice__VAE_encoder_common_layers.0.weight"] = np64(grads["VAE_encoder_common_layers.0.weight"][:, :64])
+    for k in list(out):
+        if k.startswith("p_params") or k.startswith("test_p_params") or k in ("p_params_full",):
+            out[k] = out[k][:, :200] if out[k].ndim == 2 else out[k][:, :40]
+    out["hid_e"], out["hid_d"] = np.array(hid_e), np.array(hid_d)
+    np.savez_compressed(os.path.join(HERE, "d4_conv_deep_small.npz"), **out)
+    print("d4_conv_deep_small loss", out["loss"])
+
+
 def case_types_info():
     """reference read_data on CSV files written from the mix spec (layout pin)."""
     src = synthetic.make_tabular(n_rows=24, T=6, seed=7, spec=MIX_SPEC)
@@ -449,3 +477,4 @@ if __name__ == "__main__":
     case_gp_predict()
     case_mix_logvar_deep()
     case_d4_conv_logvar()
+    case_d4_conv_deep()

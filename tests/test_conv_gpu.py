@@ -204,6 +204,62 @@ def test_conv_logvar_network_against_reference_fixture(golden_dir):
     assert len(errs) >= 20 and not bad, (bad, errs)
 
 
+def test_conv_deeper_trunks_against_reference_fixture(golden_dir):
+    """conv=True with two hidden layers per side (round 3; fixture d4_conv_deep_small): forward, loss and every gradient against the
+    reference, then fused training steps that reduce the NLL (the extra layers' Adam sets ride in the dense launch)."""
+    import hlvae_oracle as orc
+    from hlvae_amd.HLVAE import HLVAE
+    from hlvae_amd.training import ELBOTrainer
+    g = np.load(os.path.join(golden_dir, "d4_conv_deep_small.npz"))
+    src = synthetic.make_d4(n_subjects=2, T=4, seed=5)
+    dims = [src.cov_dim_ext, [int(v) for v in g["hid_e"]], 8, [int(v) for v in g["hid_d"]], 5]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=23, std=0.05, conv=True)
+    dev = torch.device("cuda:0")
+    model = HLVAE(dims, src.types_info, src.n_variables, conv=True, max_batch=128, materialize_samples=False)
+    model.load_state_dict(state)
+    model = model.to(dev)
+    data, mask, eps = torch.tensor(src.data[:8], device=dev), torch.tensor(g["mask"], device=dev), torch.tensor(g["eps"], device=dev)
+    out = model(data, mask, None, src.types_info, eps=eps)
+    mu, lv, lpx, lpm = out[1], out[2], out[3], out[4]
+    assert max_abs_err(mu.cpu(), g["mu"]) < 2e-2 and max_abs_err(lv.cpu(), g["log_var"]) < 2e-2
+    e_lpx = np.abs(lpx.detach().double().cpu().numpy() - g["log_p_x"])
+    assert np.all(e_lpx <= 3e-2 + 2e-2 * np.abs(g["log_p_x"]))
+    elbo, elbo_ref = float(lpx.double().sum()), float(g["log_p_x"].sum())
+    assert abs(elbo - elbo_ref) <= 1e-4 * abs(elbo_ref), (elbo, elbo_ref)
+    nll = model.loss_function(lpx)
+    kl = -0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
+    loss = float(g["nll_scale"][0]) * nll.sum() + kl
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"][0])) <= 1e-4 * abs(float(g["loss"][0]))
+    sd = dict(model.named_parameters())
+    errs = {}
+    for k in g.files:
+        if k.startswith("grad__"):
+            pname = k[len("grad__"):]
+            assert sd[pname].grad is not None, pname
+            errs[pname] = rel_err(sd[pname].grad.double().cpu().numpy(), g[k])
+    errs["y_layer.0.weight[:40]"] = rel_err(sd["y_layer.0.weight"].grad[:40].double().cpu().numpy(), g["grad_slice__y_layer.0.weight"])
+    errs["enc.0.weight[:, :64]"] = rel_err(sd["VAE_encoder_common_layers.0.weight"].grad[:, :64].double().cpu().numpy(),
+                                           g["grad_slice__VAE_encoder_common_layers.0.weight"])
+    enc_side = ("conv1.", "conv2.", "representation_layer.")       # (bf16 storage moves a few ReLU / max-pool gates of an 8-row batch: see above)
+    bad = {k: v for k, v in errs.items() if not v < (0.12 if k.startswith(enc_side) else 6e-2)}
+    assert len(errs) >= 24 and not bad, (bad, errs)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    tr = ELBOTrainer(model, P_total=2, kl="normal", max_batch=128, lr=1e-3)
+    nll = []
+    for i in range(30):
+        tr.step(data, mask, 2)
+        nll.append(float(tr.scalars()["nll_sum"]))
+    assert np.isfinite(nll).all() and nll[-1] < nll[0], nll
+    torch.cuda.synchronize()
+    after = model.state_dict()
+    moved = [k for k in before if before[k].numel() and not torch.equal(before[k], after[k])]
+    for k in ("VAE_encoder_common_layers.0.weight", "VAE_encoder_common_layers.2.weight", "d_layers.0.weight", "d_layers.2.weight",
+              "y_layer.0.weight", "conv1.weight"):
+        assert k in moved, (k, moved)
+
+
 def test_conv_training_steps_run_and_reduce_the_loss(golden_dir):
     """fused ELBOTrainer step with the convolutional model (Adam on the conv parameters through the small-region kernel,
     re-packed convolution weights every step): the NLL of a fixed batch goes down."""

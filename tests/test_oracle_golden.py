@@ -122,6 +122,41 @@ def test_d4_conv_logvar_small(golden_dir):
     assert rel_err(st["y_layer.0.weight"].grad[:40].numpy(), g["grad_slice__y_layer.0.weight"]) < 1e-9
 
 
+def test_d4_conv_deep_small(golden_dir):
+    """conv=True with two hidden layers per side (round 3): the oracle against the reference run"""
+    g = np.load(os.path.join(golden_dir, "d4_conv_deep_small.npz"))
+    src = synthetic.make_d4(n_subjects=2, T=4, seed=5)
+    d = src.data[:8]
+    assert np.allclose([d.sum(), (d * np.arange(d.shape[1])).sum()], g["data_argsum"]), "generator drifted"
+    dims = [src.cov_dim_ext, [int(v) for v in g["hid_e"]], 8, [int(v) for v in g["hid_d"]], 5]
+    state = orc.init_state(dims, src.types_info, src.n_variables, seed=23, std=0.05, conv=True)
+    chk = float(sum(v.double().abs().sum() for v in state.values()))
+    assert abs(chk - g["state_checksum"][0]) < 1e-9 * chk, "weight generator drifted"
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    for k in list(st):
+        if k.startswith("hidden."):
+            st[k] = st["d_layers." + k[len("hidden."):]]
+        if k.startswith("Decoder_Conv_layer."):
+            st[k] = st["deconv_layer." + k[len("Decoder_Conv_layer."):]]
+    model = orc.OracleHLVAE(dims, src.types_info, src.n_variables, st, conv=True)
+    out = model.forward(torch.tensor(d), torch.tensor(g["mask"]), torch.tensor(g["eps"]))
+    for k in ("mu", "log_var", "log_p_x", "log_p_x_missing"):
+        assert rel_err(out[k].detach().numpy(), g[k]) < TOL, k
+    loss = float(g["nll_scale"][0]) * model.loss_function(out["log_p_x"]).sum() + \
+        orc.standard_normal_kl(out["mu"], out["log_var"])
+    assert rel_err(loss.detach().numpy(), g["loss"][0]) < TOL
+    loss.backward()
+    n = 0
+    for k in g.files:
+        if k.startswith("grad__"):
+            assert rel_err(st[k[6:]].grad.numpy(), g[k]) < 1e-9, k
+            n += 1
+    assert n >= 24
+    assert rel_err(st["y_layer.0.weight"].grad[:40].numpy(), g["grad_slice__y_layer.0.weight"]) < 1e-9
+    assert rel_err(st["VAE_encoder_common_layers.0.weight"].grad[:, :64].numpy(),
+                   g["grad_slice__VAE_encoder_common_layers.0.weight"]) < 1e-9
+
+
 def test_d4_conv_small(golden_dir):
     """convolutional front/back end: the oracle against the reference run with conv=True"""
     g = np.load(os.path.join(golden_dir, "d4_conv_small.npz"))
