@@ -314,16 +314,18 @@ def test_gp_prior_hip_against_reference_fixture(golden_dir):
     assert rel_err(gp.m, g["m_new"]) < 1e-9 and rel_err(gp.H, g["H_new"]) < 1e-10      # measured 7e-12 / 5e-16
 
 
-@pytest.mark.parametrize("B", [512, 1024])
-def test_conv_backward_against_oracle(B):
-    """convolutional model (what config/hlvae_config_file.txt:51 selects) at 512 and 1024 rows, hidden 500, latent 32:
-    ELBO, loss and EVERY gradient tensor against the fp64 oracle on the same weights and noise (the head kernel runs in its
-    `ysrc` mode: the tile of y_grouped comes from the second transposed convolution)."""
+@pytest.mark.parametrize("B,hid_e,hid_d", [(512, [500], [500]), (1024, [500], [500]), (512, [500, 132], [260, 500])],
+                         ids=["512", "1024", "512-deep"])
+def test_conv_backward_against_oracle(B, hid_e, hid_d):
+    """convolutional model (what config/hlvae_config_file.txt:51 selects) at 512 and 1024 rows, hidden 500, latent 32 -- and
+    (round 3) with two hidden layers either side of the convolutional stages: ELBO, loss and EVERY gradient tensor against
+    the fp64 oracle on the same weights and noise (the head kernel runs in its `ysrc` mode: the tile of y_grouped comes from
+    the second transposed convolution)."""
     import hlvae_oracle as orc
     from hlvae_amd.HLVAE import HLVAE
     dev = _dev()
     src = synthetic.make_d4(n_subjects=(B + 19) // 20 + 1, T=20, seed=100)
-    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    dims = [src.cov_dim_ext, hid_e, 32, hid_d, 5]
     torch.manual_seed(3)
     model = HLVAE(dims, src.types_info, src.n_variables, conv=True, max_batch=B, materialize_samples=False).to(dev)
     state = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
@@ -346,7 +348,7 @@ def test_conv_backward_against_oracle(B):
     ref_loss = scale * om.loss_function(ref["log_p_x"]).sum() + orc.standard_normal_kl(ref["mu"], ref["log_var"])
     ref_loss.backward()
     elbo, elbo_ref = float(lpx.double().sum()), float(ref["log_p_x"].sum())
-    key = f"conv_b{B}"
+    key = f"conv_b{B}" + ("_deep" if len(hid_e) > 1 else "")
     _report(key, elbo_rel=abs(elbo - elbo_ref) / abs(elbo_ref), loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
     assert abs(elbo - elbo_ref) <= ELBO_RTOL * abs(elbo_ref), (elbo, elbo_ref)
     assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss))
