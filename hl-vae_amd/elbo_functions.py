@@ -28,6 +28,7 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 import numpy as np
+import contextlib
 import torch
 
 from . import GP_model
@@ -328,6 +329,7 @@ class GPPriorHIP:
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
         self._serial = _os.environ.get("HL_GP_SERIAL", "0") == "1"
         self._balance = int(_os.environ.get("HL_GP_BALANCE", "2"))        # where the chain rule through K0xz runs (kl_and_grads)
+        self._early = _os.environ.get("HL_GP_EARLY", "1") != "0"          # per-subject kernel forked behind the ENCODER (kl_and_grads(after=...))
         self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
         if dp is not None:                     # inducing points are drawn from rank-local covariates: replicate rank 0's state
@@ -537,19 +539,26 @@ class GPPriorHIP:
             self._xchg[LMM:LMM + 2 * LM].zero_()                             # P1, u: accumulated by the per-subject kernel
         return buf, hyp, Kxz, iKm, HiK, N1
 
-    def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None, join=True):
+    def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None, join=True, after=None):
         """mu, log_v: fp32 [B, L] (the workspace tensors of the VAE); returns fp32 [B, L] gradients.  Hyper-parameter
         and inducing-point gradients are left in ``prm.grad`` / ``zt_list.grad``.  Every product, reduction and element-wise
         step runs in the kernels of csrc/gp.hip; no host synchronisation when ``groups`` comes from the sampler.
-        train_x None: the batch ``prepare`` was called for."""
+        train_x None: the batch ``prepare`` was called for.
+        after: an event the caller recorded on its stream when mu / log_v were final (ELBOTrainer: behind the encoder, BEFORE it
+        queued the decoder): the per-subject kernel is then forked from that point -- it runs on the prior's preparation stream
+        beside the VAE's head kernel instead of behind it (round-3 timeline: 50 us of the step's critical path at 1024 rows) --
+        and the caller's stream waits for g_mu / g_lv here."""
         lib, st = _lib.load(), self._stream()
         L, M, Q, B = self.L, self.M, self.Q, mu.shape[0]
         dev = mu.device
         c = float(P_total) / float(P_batch)
         prep, self._prep = self._prep, None
+        early = False
         if prep is not None and (train_x is None or train_x is prep[0]):
             x, idx, buf, hyp, Kxz, iKm, HiK, N1 = prep
-            torch.cuda.current_stream(dev).wait_stream(self._prep_stream)
+            early = after is not None and self._early and self._fuse_sums and not self._serial
+            if not early:
+                torch.cuda.current_stream(dev).wait_stream(self._prep_stream)
             x.record_stream(torch.cuda.current_stream(dev))                  # (allocated on the side stream, read on this one)
             if x.shape[0] != B:
                 raise ValueError(f"kl_and_grads: prepare() saw {x.shape[0]} rows, the encoder outputs have {B}")
@@ -587,20 +596,35 @@ class GPPriorHIP:
             resid = buf["resid"]                                             # K0xz iK m - mu^T   [L,B]
             _lib.check(lib.hlvae_gp_resid(_lib.ptr(Kxz), _lib.ptr(iKm), _lib.ptr(mu), L, B, M, _lib.ptr(resid), st), "gp_resid")
         iB, K0s, V, v, part, g_mu, g_lv = (buf[k] for k in ("iB", "K0s", "V", "v", "part", "g_mu", "g_lv"))
-        _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x),
+        main = torch.cuda.current_stream(dev)
+        if early:
+            self._prep_stream.wait_event(after)
+            fwd_ctx = torch.cuda.stream(self._prep_stream)
+        else:
+            fwd_ctx = contextlib.nullcontext()
+        with fwd_ctx:
+          st = self._stream()
+          _lib.check(lib.hlvae_gp_subject_fwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x),
                                             _lib.ptr(self.noise), _lib.ptr(idx), S, T, _lib.ptr(Kxz), B, M, _lib.ptr(resid),
                                             _lib.ptr(log_v), _C.c_double(c), _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v),
                                             _lib.ptr(part), _lib.ptr(g_mu), _lib.ptr(g_lv), _lib.ptr(iKm) if fused else None,
                                             _lib.ptr(mu) if fused else None, _lib.ptr(u) if fused else None,
                                             _lib.ptr(P1) if fused else None, st), "gp_subject_fwd")
+        st = None
         # g_mu / g_lv -- all the VAE's backward pass needs -- are final here.  What follows (the bound's value, the natural-gradient
         # terms, the chain rule into hyper-parameters and inducing points) is two independent chains of latency-bound kernels:
         # they run side by side on two streams of ours, and with join = False also beside whatever the caller queues next on
         # its own stream (ELBOTrainer: the VAE's backward pass + optimiser); optimizer_step() / join() wait for them.
-        main = torch.cuda.current_stream(dev)
         sA, sC = self._streams(dev)
-        sA.wait_stream(main)
-        sC.wait_stream(main)
+        if early:       # the two chains continue from the per-subject kernel, not from whatever the caller has queued since
+            evF = torch.cuda.Event()
+            evF.record(self._prep_stream)
+            main.wait_event(evF)
+            sA.wait_event(evF)
+            sC.wait_event(evF)
+        else:
+            sA.wait_stream(main)
+            sC.wait_stream(main)
         world = 1 if self.dp is None else self.dp.world
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
         balance = self._balance if (self._chain and M % 4 == 0) else 0

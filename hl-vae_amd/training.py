@@ -300,6 +300,11 @@ class ELBOTrainer:
         # forward (+ head backward in the same pass: upstream gradient of log_p_x is -scale).
         # eps None -> reparameterisation noise from the in-kernel Philox stream (device-side offset: graph safe)
         _lib.check(lib.hlvae_encoder_fwd(m._plan_handle, ws, _lib.ptr(eps), 1, C.c_uint64(0), B, s), "encoder_fwd")
+        ev_enc = None
+        if self.kl == "gp" and getattr(self.gp, "_early", False):
+            # mu / log_var are final: the GP prior's per-subject kernel forks HERE (beside the head kernel), see kl_and_grads(after=)
+            ev_enc = torch.cuda.Event()
+            ev_enc.record(torch.cuda.current_stream(m.device))
         if prefetch is not None:
             # forked HERE: the HBM-streaming input stage of the next batch shares the machine with the compute-heavy head
             # kernel instead of the bandwidth/latency-bound first GEMM (measured: forking at the top of the step costs more
@@ -343,6 +348,8 @@ class ELBOTrainer:
             # the GP prior's own chains (bound, natural gradient, hyper-parameter gradients) keep running on its streams beside
             # the VAE's backward pass; gp.optimizer_step() below joins them
             kw = {"join": False} if hasattr(self.gp, "join") else {}
+            if ev_enc is not None:
+                kw["after"] = ev_enc
             g_mu, g_lv = self.gp.kl_and_grads(m._ws_t["mu"][:B], m._ws_t["lv"][:B], train_x, self.P_total, P_batch, groups=groups, **kw)
         fused_opt = self.dp is None
         late_join = False
