@@ -188,6 +188,7 @@ class ELBOTrainer:
         dev, L = model.device, model.z_dim
         self._graphs = {}
         self._wy_dbuf = False        # y_layer shadows double-buffered (only inside an even chain of captured steps)
+        self._gp_defer_noahead = os.environ.get("HL_GP_DEFER_AHEAD", "1") == "0"
         self._gp_defer = False       # GP state update deferred onto the prior's stream (only inside a captured chain, prepare() in use)
         if dp is not None and dp.world > 1:
             # every rank draws its own reparameterisation noise: the in-kernel Philox stream is indexed by the LOCAL row, so
@@ -275,7 +276,7 @@ class ELBOTrainer:
         if self.kl == "gp":
             if hasattr(self.gp, "prepare") and os.environ.get("HL_GP_PREPARE", "1") != "0":
                 # the prior's state-only launches (and the covariate gather) run on a stream of its own under the VAE's forward pass
-                train_x = self.gp.prepare(ds.labels, rows, groups=groups, ahead=prepacked and self._gp_ahead() and not self._gp_defer)
+                train_x = self.gp.prepare(ds.labels, rows, groups=groups, ahead=prepacked and self._gp_ahead() and not (self._gp_defer and self._gp_defer_noahead))
             else:
                 train_x = ds.labels.index_select(0, rows.long())
         self._step_core(B, float(self.P_total) / float(P_batch), eps, train_x, P_batch, None, None,
@@ -428,7 +429,7 @@ class ELBOTrainer:
         m._grad_region_clean = True
         if self.kl == "gp":
             # (not together with the deferred state update, an experiment that stays off: HL_GP_DEFER)
-            nb = {"next_batch": (feed_next[0].labels, feed_next[1])} if (feed_next is not None and self._gp_ahead() and not self._gp_defer) else {}
+            nb = {"next_batch": (feed_next[0].labels, feed_next[1])} if (feed_next is not None and self._gp_ahead() and not (self._gp_defer and self._gp_defer_noahead)) else {}
             if self._gp_defer and hasattr(self.gp, "join_tail"):
                 self.gp.optimizer_step(defer=True, **nb)      # (inside a captured chain: the state update runs beside the next step's forward pass)
             else:
