@@ -821,6 +821,20 @@ class GPPriorHIP:
         self.join()
         self._state_update(next_batch)
 
+    def fork_streams(self):
+        """first thing inside a stream capture that will use optimizer_step(defer=True): every stream of the prior's enters the
+        capture from the CAPTURING stream.  (ROCm 7.2: ending a capture in which a side stream entered by waiting on ANOTHER side
+        stream's event and was later joined back into that stream crashes in hipStreamEndCapture.)"""
+        dev = self.zt_list.device
+        main = torch.cuda.current_stream(dev)
+        if self._prep_stream is None:
+            self._prep_stream = torch.cuda.Stream(device=dev)
+        if self._ahead_stream is None:
+            self._ahead_stream = torch.cuda.Stream(device=dev)
+        for s_ in self._streams(dev) + (self._prep_stream, self._ahead_stream):
+            if s_ != main:
+                s_.wait_stream(main)
+
     def join_tail(self):
         """the caller's stream waits for a deferred state update (optimizer_step(defer=True))"""
         if self._tail_pending:
