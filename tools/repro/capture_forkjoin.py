@@ -14,6 +14,8 @@ ahead = "ahead" in variant
 viamain = "viamain" in variant       # chains A / C forked from main (behind evF) instead of from sP's event
 own = "own" in variant               # state update on a stream of its own (sU)
 prefork = "prefork" in variant
+kmain = "kmain" in variant           # look-ahead stream forked from main behind an event of the state update's head
+konc = "konc" in variant             # look-ahead work on chain C's stream (which entered the capture from main)
 
 
 def op(i):
@@ -25,7 +27,7 @@ def step():
     if own:
         sP.wait_stream(sU)
     if ahead:
-        sP.wait_stream(sK)
+        sP.wait_stream(sC if konc else sK)
     with torch.cuda.stream(sP):
         op(0)
     op(1)
@@ -63,7 +65,20 @@ def step():
         sX.wait_stream(sC)
         with torch.cuda.stream(sX):
             op(5)
-            if ahead:
+            if ahead and kmain:
+                e = torch.cuda.Event()
+                e.record(sX)
+                main.wait_event(e)
+                sK.wait_stream(main)
+                with torch.cuda.stream(sK):
+                    op(6)
+            elif ahead and konc:
+                e = torch.cuda.Event()
+                e.record(sX)
+                sC.wait_event(e)
+                with torch.cuda.stream(sC):
+                    op(6)
+            elif ahead:
                 sK.wait_stream(sX)
                 with torch.cuda.stream(sK):
                     op(6)
@@ -92,7 +107,7 @@ with torch.cuda.stream(main):
         if defer:
             main.wait_stream(sU if own else sP)
         if ahead:
-            main.wait_stream(sK)
+            main.wait_stream(sC if konc else sK)
         if prefork:
             for s_ in (sP, sA, sC, sK, sU):
                 main.wait_stream(s_)
