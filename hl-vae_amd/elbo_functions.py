@@ -476,14 +476,14 @@ class GPPriorHIP:
         self._prep = (x, idx) + st_
         return x
 
-    def compute_ahead(self, labels, rows):
+    def compute_ahead(self, labels, rows, fork_from=None):
         """Covariate gather + K0xz of a FOLLOWING batch on a stream of their own, forked from the caller's here.  Called by
         ``optimizer_step(next_batch=...)`` right behind the hyper-parameter transform: K0xz of the next batch needs the updated
         hyper-parameters and inducing points but not the batched inversion, so its 31 MB kernel matrix (55 us inside the step at
         configs[4]) runs BESIDE the 82 us inversion instead of behind it (round-3 timeline: the state update -> K0xz ->
         iK-products chain is the step's loop-carried critical path).  ``prepare(..., ahead=True)`` picks the buffers up."""
         dev = labels.device
-        main = torch.cuda.current_stream(dev)
+        main = fork_from if fork_from is not None else torch.cuda.current_stream(dev)
         if self._ahead_stream is None:
             self._ahead_stream = torch.cuda.current_stream(dev) if self._serial else torch.cuda.Stream(device=dev)
         sK = self._ahead_stream
@@ -616,15 +616,16 @@ class GPPriorHIP:
         # they run side by side on two streams of ours, and with join = False also beside whatever the caller queues next on
         # its own stream (ELBOTrainer: the VAE's backward pass + optimiser); optimizer_step() / join() wait for them.
         sA, sC = self._streams(dev)
-        if early:       # the two chains continue from the per-subject kernel, not from whatever the caller has queued since
+        if early:
+            # the caller's stream picks g_mu / g_lv up, and the two chains fork from IT (not from the event itself: a side stream
+            # that waits on another side stream's event and is later joined back into that stream -- optimizer_step(defer=True) --
+            # crashes ROCm 7.2's hipStreamEndCapture, tools/repro/capture_forkjoin.py; the caller's head kernel, which the chains
+            # now also wait for, is over long before the per-subject kernel)
             evF = torch.cuda.Event()
             evF.record(self._prep_stream)
             main.wait_event(evF)
-            sA.wait_event(evF)
-            sC.wait_event(evF)
-        else:
-            sA.wait_stream(main)
-            sC.wait_stream(main)
+        sA.wait_stream(main)
+        sC.wait_stream(main)
         world = 1 if self.dp is None else self.dp.world
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
         balance = self._balance if (self._chain and M % 4 == 0) else 0
@@ -814,26 +815,13 @@ class GPPriorHIP:
             for s_ in self._side:
                 self._prep_stream.wait_stream(s_)
             self._pending = False
+            caller = torch.cuda.current_stream(dev)
             with torch.cuda.stream(self._prep_stream):
-                self._state_update(next_batch)
+                self._state_update(next_batch, caller=caller)
             self._tail_pending = True
             return
         self.join()
         self._state_update(next_batch)
-
-    def fork_streams(self):
-        """first thing inside a stream capture that will use optimizer_step(defer=True): every stream of the prior's enters the
-        capture from the CAPTURING stream.  (ROCm 7.2: ending a capture in which a side stream entered by waiting on ANOTHER side
-        stream's event and was later joined back into that stream crashes in hipStreamEndCapture.)"""
-        dev = self.zt_list.device
-        main = torch.cuda.current_stream(dev)
-        if self._prep_stream is None:
-            self._prep_stream = torch.cuda.Stream(device=dev)
-        if self._ahead_stream is None:
-            self._ahead_stream = torch.cuda.Stream(device=dev)
-        for s_ in self._streams(dev) + (self._prep_stream, self._ahead_stream):
-            if s_ != main:
-                s_.wait_stream(main)
 
     def join_tail(self):
         """the caller's stream waits for a deferred state update (optimizer_step(defer=True))"""
@@ -841,7 +829,7 @@ class GPPriorHIP:
             torch.cuda.current_stream(self.zt_list.device).wait_stream(self._prep_stream)
             self._tail_pending = False
 
-    def _state_update(self, next_batch=None):
+    def _state_update(self, next_batch=None, caller=None):
         lib, st, L, M = _lib.load(), self._stream(), self.L, self.M
         self._ahead = None
         # Adam, the transform of the hyper-parameters it produced and iH_new (in place in _KH2[:L]): one launch
@@ -851,7 +839,14 @@ class GPPriorHIP:
                                            _lib.ptr(self._grad_H), _lib.ptr(self._iHb), _C.c_double(self.ng_lr), M, L, st), "gp_state_head")
         self._iH = None
         if next_batch is not None:
-            self.compute_ahead(*next_batch)
+            if caller is not None:
+                # deferred update (this runs on the preparation stream): the look-ahead stream forks from the CALLER's stream behind
+                # an event of the launch above -- forked from this stream and joined back into it by the next prepare() it would be
+                # the capture pattern described in kl_and_grads.  The caller's stream waits for one 8 us launch, not for the update.
+                e_head = torch.cuda.Event()
+                e_head.record(torch.cuda.current_stream(self.zt_list.device))
+                caller.wait_event(e_head)
+            self.compute_ahead(*next_batch, fork_from=caller)
         self.kernel_matrix(self.k0, self.zt_list, self.zt_list, jitter=self.eps, out=self._KH2[L:])
         self._spd_inv(self._KH2, self._HiK, self._ld2, n_neg=L, logdet_neg=self._ldH)      # log det H_new = - log det iH_new
         self._bmv(self.H, self._tmp, self.m)                                 # m_new = H_new tmp

@@ -513,8 +513,6 @@ class ELBOTrainer:
                           and os.environ.get("HL_GP_DEFER", "0") != "0")      # (measured: 0.834 vs 0.796 ms -- off by default)
         try:
             with torch.cuda.graph(g, **self._capture_kw()):
-                if self._gp_defer and hasattr(self.gp, "fork_streams"):
-                    self.gp.fork_streams()
                 for (r, pb), nr, gr in zip(chain, nxt, grp):
                     self.step_rows(ds, r, pb, prefetch_rows=nr, prepacked=nr is not None, groups=gr)
                 if self.dp is not None:
