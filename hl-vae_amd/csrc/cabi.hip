@@ -537,7 +537,7 @@ int hlvae_join(const hlvae_plan* p, hlvae_stream s) {
 
 int hlvae_set_defer_join(const hlvae_plan* p, int on) {
     HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
-    p->defer_join = on ? 1 : 0;
+    p->defer_join = on == 2 ? 2 : (on ? 1 : 0);   // 2: the deferred side work is queued on the CALLER's stream at the end of the backward call
     return 0;
 }
 
@@ -716,7 +716,12 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         HL_CHECK(hipEventRecord(p->ev[3], s0));
         // (large batches, metrics behind side 0's chain and the input stage alone on side 1: its 16-workgroup statistics kernel
         //  starves beside the streaming launches -- 110 us instead of 12 -- and the step does not move, 0.490 vs 0.483 ms)
-        if (p->pend_flags & HL_PEND_DEFERRED) {
+        if ((p->pend_flags & HL_PEND_DEFERRED) && p->defer_join == 2) {
+            // the caller does not wait for anything else at the end of this step (GP prior with a deferred state update: its chains
+            // are the step's critical path and share the hardware queues with side 1 -- the next batch's input stage sat 250 us
+            // behind them, and the next step's encoder behind it): metrics and input stage in line, beside y_layer's launch
+            if ((rc = hl_flush_deferred(p, st, true, HL_PEND_DEFERRED, false, true))) return rc;
+        } else if (p->pend_flags & HL_PEND_DEFERRED) {
             HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));   // forked at the head kernel like side 0: with the fork behind
             // dU_splitk the graph executor put both side chains on ONE hardware queue, y_layer's launch last (0.166 vs 0.144 ms/step)
             if ((rc = hl_flush_deferred(p, s1, true, HL_PEND_DEFERRED, false, small_batch))) return rc;
@@ -800,7 +805,7 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
             // final optimiser launch, 132 -> 122 us traced)
             if ((rc = hl_flush_deferred(p, s0, true, HL_PEND_FINALIZE | HL_PEND_METRICS, true))) return rc;
     }
-    if (p->pend_flags & HL_PEND_DEFERRED) {
+    if ((p->pend_flags & HL_PEND_DEFERRED) && p->defer_join != 2) {
         HL_CHECK(hipStreamWaitEvent(s1, p->ev[direct_bwd ? 0 : 2], 0));     // (narrow y_layer: ev[2] is behind the fused middle)
         if ((rc = hl_flush_deferred(p, s1, true))) return rc;
     }
@@ -816,6 +821,8 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     // skip_wy (data-parallel host): the deferred side chain (metrics, next batch's input stage) stays un-joined -- the host's
     // reduce-scatters and optimiser launches that follow do not need it (they were starting 17 us late behind the input stage);
     // it calls hlvae_join at the end of its step
+    if ((p->pend_flags & HL_PEND_DEFERRED) && p->defer_join == 2)       // in line, behind the last optimiser launch (see the fused path)
+        if ((rc = hl_flush_deferred(p, st, true, HL_PEND_DEFERRED, false, true))) return rc;
     if ((skip_wy && opt == nullptr) || p->defer_join) return 0;
     return hlvae_join(p, s);
 }

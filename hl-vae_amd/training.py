@@ -366,7 +366,7 @@ class ELBOTrainer:
             # hardware queue with the prior's chain C and ended 45 us after both GP chains; the state update waited for it)
             late_join = self.kl == "gp" and hasattr(self.gp, "join") and os.environ.get("HL_GP_LATE_JOIN", "1") != "0"
             if late_join:
-                _lib.check(lib.hlvae_set_defer_join(m._plan_handle, 1), "set_defer_join")
+                _lib.check(lib.hlvae_set_defer_join(m._plan_handle, 2 if self._gp_defer else 1), "set_defer_join")
             try:
                 _lib.check(lib.hlvae_backward_adam(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), B, _lib.ptr(o.m1),
                                                    _lib.ptr(o.m2), _lib.ptr(o.step_count), C.c_float(o.lr), C.c_float(o.betas[0]),

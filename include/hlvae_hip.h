@@ -268,7 +268,9 @@ int hlvae_step_metrics(const hlvae_plan* p, const hlvae_ws* ws, int B, float* er
 int hlvae_join(const hlvae_plan* p, hlvae_stream s);
 /* on != 0: hlvae_backward / hlvae_backward_adam return WITHOUT joining the deferred side chain (metrics, next batch's input stage);
  * the host queues what does not depend on it (the GP prior's state update) and calls hlvae_join itself.  Un-joined work is
- * joined by the plan's next forward call at the latest. */
+ * joined by the plan's next forward call at the latest.
+ * on == 2: as 1, and the deferred work is queued on the CALLER's stream behind the backward pass's last launch of its own instead
+ * of on the library's side stream (a host whose own side streams own the hardware queues: the GP prior with a deferred update). */
 int hlvae_set_defer_join(const hlvae_plan* p, int on);
 
 /* rescale ws->dy by a per-element upstream gradient after the fact (autograd path) */
