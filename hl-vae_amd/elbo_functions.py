@@ -329,6 +329,7 @@ class GPPriorHIP:
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
         self._serial = _os.environ.get("HL_GP_SERIAL", "0") == "1"
         self._balance = int(_os.environ.get("HL_GP_BALANCE", "2"))        # where the chain rule through K0xz runs (kl_and_grads)
+        self._fork_direct = _os.environ.get("HL_GP_FORK_DIRECT", "0") != "0"
         self._early = _os.environ.get("HL_GP_EARLY", "1") != "0"          # per-subject kernel forked behind the ENCODER (kl_and_grads(after=...))
         self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
@@ -624,8 +625,12 @@ class GPPriorHIP:
             evF = torch.cuda.Event()
             evF.record(self._prep_stream)
             main.wait_event(evF)
-        sA.wait_stream(main)
-        sC.wait_stream(main)
+        if early and self._fork_direct:      # (A/B switch HL_GP_FORK_DIRECT=1; never with the deferred update)
+            sA.wait_event(evF)
+            sC.wait_event(evF)
+        else:
+            sA.wait_stream(main)
+            sC.wait_stream(main)
         world = 1 if self.dp is None else self.dp.world
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
         balance = self._balance if (self._chain and M % 4 == 0) else 0
