@@ -329,7 +329,11 @@ class GPPriorHIP:
         self._ahead_stream, self._ahead_bufs, self._ahead = None, {}, None
         self._serial = _os.environ.get("HL_GP_SERIAL", "0") == "1"
         self._balance = int(_os.environ.get("HL_GP_BALANCE", "2"))        # where the chain rule through K0xz runs (kl_and_grads)
-        self._fork_direct = _os.environ.get("HL_GP_FORK_DIRECT", "0") != "0"
+        # the two chains behind the per-subject kernel fork from ITS event (0.591 ms at configs[4]) or from the caller's stream behind
+        # that event (0.607: their first launches then start behind a cross-queue signal of the caller's queue; without the early
+        # fork 0.610).  Inside a capture with the deferred state update only the second form survives hipStreamEndCapture.
+        self._fork_direct = _os.environ.get("HL_GP_FORK_DIRECT", "1") != "0"
+        self._defer_capture = False
         self._early = _os.environ.get("HL_GP_EARLY", "1") != "0"          # per-subject kernel forked behind the ENCODER (kl_and_grads(after=...))
         self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
@@ -625,7 +629,7 @@ class GPPriorHIP:
             evF = torch.cuda.Event()
             evF.record(self._prep_stream)
             main.wait_event(evF)
-        if early and self._fork_direct:      # (A/B switch HL_GP_FORK_DIRECT=1; never with the deferred update)
+        if early and self._fork_direct and not self._defer_capture:
             sA.wait_event(evF)
             sC.wait_event(evF)
         else:

@@ -511,6 +511,8 @@ class ELBOTrainer:
         self._wy_dbuf = len(chain) % 2 == 0
         self._gp_defer = (self.kl == "gp" and self.dp is None and hasattr(self.gp, "join_tail") and os.environ.get("HL_GP_PREPARE", "1") != "0"
                           and os.environ.get("HL_GP_DEFER", "0") != "0")      # (measured: 0.834 vs 0.796 ms -- off by default)
+        if self.kl == "gp" and hasattr(self.gp, "_defer_capture"):
+            self.gp._defer_capture = self._gp_defer
         try:
             with torch.cuda.graph(g, **self._capture_kw()):
                 for (r, pb), nr, gr in zip(chain, nxt, grp):
@@ -524,6 +526,8 @@ class ELBOTrainer:
         finally:
             self._wy_dbuf = False
             self._gp_defer = False
+            if self.kl == "gp" and hasattr(self.gp, "_defer_capture"):
+                self.gp._defer_capture = False
         self._graphs[key] = g
         return g
 
