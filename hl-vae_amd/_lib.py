@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HLVAE_LIB_PATH", os.path.join(_HERE, "libhlvae_hip.so"))      # (override: diagnostic builds)
-ABI_VERSION = 33
+ABI_VERSION = 34
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -123,6 +123,8 @@ _SIGS = {
     "hlvae_gp_spd_inv2": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "hlvae_gp_gemm": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, C.c_int64, _vp, C.c_int, C.c_int64, _vp, C.c_int,
                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
+    "hlvae_gp_gemm_acc": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, C.c_int64, _vp, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_double, _vp]),
     "hlvae_gp_bmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
     "hlvae_gp_resid": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_gemv_t_f32": (C.c_int, [_vp, _vp, C.c_long, C.c_long, _vp, C.c_int, C.c_int, C.c_int, _vp]),

@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_gp_bmm(const double* __restrict__ A, co
 template <int TM, int TA>
 __global__ __launch_bounds__(256) void k_gp_gemm(const double* __restrict__ A, int lda, long sA, const double* __restrict__ B, int ldb,
                                                  long sB, const double* D, int ldd, long sD, double* C, int ldc, long sC, int M,
-                                                 int N, int K, int tiles_n, int ksplit, double alpha, double beta) {
+                                                 int N, int K, int tiles_n, int ksplit, int atomic, double alpha, double beta) {
     constexpr int LA = GP_GK + 1, LB = 32 + 1;
     __shared__ double As[TM * LA], Bs[GP_GK * LB];
     const int l = blockIdx.z, ks = blockIdx.y;
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_gp_gemm(const double* __restrict__ A, i
             const int row = m0 + wr * 16 + (lane >> 4) + 4 * r, col = n0 + wc * 16 + 16 * j + (lane & 15);
             if (row < M && col < N) {
                 double v = alpha * acc[j][r];
-                if (ksplit > 1) {
+                if (atomic) {       // split-K slices, or the caller's C accumulates (hlvae_gp_gemm_acc)
                     if (ks == 0 && Dl != nullptr) v += beta * Dl[(size_t)row * ldd + col];
                     atomicAdd(Cl + (size_t)row * ldc + col, v);
                 } else {
@@ -1968,9 +1968,9 @@ int hlvae_gp_spd_inv2(const double* A, int n, int N, double* inv, double* logdet
     return 0;
 }
 
-int hlvae_gp_gemm(const double* A, int lda, int64_t strideA, int transA, const double* B, int ldb, int64_t strideB, const double* D,
-                  int ldd, int64_t strideD, double* C, int ldc, int64_t strideC, int M, int N, int K, int batch, double alpha,
-                  double beta, hlvae_stream s) {
+static int hl_gp_gemm_impl(const double* A, int lda, int64_t strideA, int transA, const double* B, int ldb, int64_t strideB, const double* D,
+                           int ldd, int64_t strideD, double* C, int ldc, int64_t strideC, int M, int N, int K, int batch, double alpha,
+                           double beta, hlvae_stream s, bool acc) {
     HL_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && batch >= 1, HLVAE_EINVAL, "gp_gemm: M=%d N=%d K=%d batch=%d", M, N, K, batch);
     HL_REQUIRE(lda >= (transA ? M : K) && ldb >= N && ldc >= N && (D == nullptr || ldd >= N), HLVAE_ESHAPE, "gp_gemm: leading dimensions");
     hipStream_t st = (hipStream_t)s;
@@ -1982,17 +1982,31 @@ int hlvae_gp_gemm(const double* A, int lda, int64_t strideA, int transA, const d
     if (ksplit > 1) {
         HL_REQUIRE(D == nullptr || D != C, HLVAE_EINVAL, "gp_gemm: D aliasing C is not available with split-K");
         HL_REQUIRE(ldc == N && strideC == (int64_t)M * N, HLVAE_ESHAPE, "gp_gemm: split-K needs a dense C");
-        HL_CHECK(hipMemsetAsync(C, 0, sizeof(double) * (size_t)batch * M * N, st));
+        if (!acc) HL_CHECK(hipMemsetAsync(C, 0, sizeof(double) * (size_t)batch * M * N, st));
     }
+    const int atomic = (ksplit > 1 || acc) ? 1 : 0;
     HL_PROF("gp_gemm", st);
     const dim3 grid(tiles_m * tiles_n, ksplit, batch);
 #define HL_GG(TMv, TAv) k_gp_gemm<TMv, TAv><<<grid, 256, 0, st>>>(A, lda, strideA, B, ldb, strideB, D, ldd, strideD, C, ldc, strideC, M, \
-                                                                N, K, tiles_n, ksplit, alpha, beta)
+                                                                N, K, tiles_n, ksplit, atomic, alpha, beta)
     if (TM == 64) { if (transA) HL_GG(64, 1); else HL_GG(64, 0); }
     else { if (transA) HL_GG(32, 1); else HL_GG(32, 0); }
 #undef HL_GG
     HL_LAUNCH_CHECK();
     return 0;
+}
+
+int hlvae_gp_gemm(const double* A, int lda, int64_t strideA, int transA, const double* B, int ldb, int64_t strideB, const double* D,
+                  int ldd, int64_t strideD, double* C, int ldc, int64_t strideC, int M, int N, int K, int batch, double alpha,
+                  double beta, hlvae_stream s) {
+    return hl_gp_gemm_impl(A, lda, strideA, transA, B, ldb, strideB, D, ldd, strideD, C, ldc, strideC, M, N, K, batch, alpha, beta, s, false);
+}
+
+// C[l] += alpha op(A[l]) B[l]: the caller cleared (or pre-loaded) C -- no memset node in front of the launch (W = Kxz^T V heads the
+// critical chain of the GP step; its 7 us clear now rides with the state-only launches of prepare())
+int hlvae_gp_gemm_acc(const double* A, int lda, int64_t strideA, int transA, const double* B, int ldb, int64_t strideB, double* C, int ldc,
+                      int64_t strideC, int M, int N, int K, int batch, double alpha, hlvae_stream s) {
+    return hl_gp_gemm_impl(A, lda, strideA, transA, B, ldb, strideB, nullptr, 0, 0, C, ldc, strideC, M, N, K, batch, alpha, 0.0, s, true);
 }
 
 int hlvae_gp_bmv(const double* A, const double* x, const double* y, double* out, int N, int batch, double alpha, double beta,

@@ -334,6 +334,7 @@ class GPPriorHIP:
         # fork 0.610).  Inside a capture with the deferred state update only the second form survives hipStreamEndCapture.
         self._fork_direct = _os.environ.get("HL_GP_FORK_DIRECT", "1") != "0"
         self._defer_capture = False
+        self._a_first = _os.environ.get("HL_GP_A_FIRST", "1") != "0"       # chain A queued before chain C (kl_and_grads)
         self._early = _os.environ.get("HL_GP_EARLY", "1") != "0"          # per-subject kernel forked behind the ENCODER (kl_and_grads(after=...))
         self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
@@ -541,7 +542,7 @@ class GPPriorHIP:
         N1 = self._bmm_into(iK, HiK, mm["N1"], D=iK, alpha=-1.0, beta=1.0)   # iK - iK H iK
         if self._fuse_sums:
             LMM, LM = L * M * M, L * M
-            self._xchg[LMM:LMM + 2 * LM].zero_()                             # P1, u: accumulated by the per-subject kernel
+            self._xchg[:LMM + 2 * LM].zero_()                                # W (hlvae_gp_gemm_acc), P1, u (the per-subject kernel) accumulate
         return buf, hyp, Kxz, iKm, HiK, N1
 
     def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None, join=True, after=None):
@@ -638,79 +639,98 @@ class GPPriorHIP:
         world = 1 if self.dp is None else self.dp.world
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
         balance = self._balance if (self._chain and M % 4 == 0) else 0
-        with torch.cuda.stream(sC):      # chain C: gradient w.r.t. K0xz and the subject blocks
-            st = self._stream()
-            Y = self._gemm(V, False, N1, buf["Y"], B, M, M)                  # V (iK - Q)   [L,B,M]  (local rows)
-            if balance == 1:
-                # round 3: the chain rule through K0xz forms G_Kxz = c [ v (iK m)^T - Y ] on the fly (no k_gp_gkxz launch, no 31 MB
-                # matrix written and read back) and may run on chain A behind the M x M algebra (HL_GP_BALANCE=1) or here behind
-                # the per-subject kernel (=2)
-                evY = torch.cuda.Event()
-                evY.record(sC)
-            elif balance == 2:
-                pass
-            else:
-                G_Kxz = buf["G_Kxz"]                                         # c [ v (iK m)^T + V (Q - iK) ]
-                _lib.check(lib.hlvae_gp_gkxz(_lib.ptr(Y), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), L, B, M, _lib.ptr(G_Kxz), st), "gp_gkxz")
-                _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
-                                                   _lib.ptr(G_Kxz), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
-                           "gp_param_grad(Kxz)")
-            _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
-                                                S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y),
-                                                _lib.ptr(log_v), _C.c_double(c), _lib.ptr(gprm), st), "gp_subject_bwd")
-            if balance == 2:
-                _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
-                                                   _lib.ptr(Y), _lib.ptr(gprm), _lib.ptr(gz), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), st),
-                           "gp_param_grad(Kxz)")
-        with torch.cuda.stream(sA):      # chain A: the sums over subjects, the bound, natural gradient, gradient w.r.t. K0zz
-            st = self._stream()
-            self._gemm(Kxz, True, V, W, M, M, B)                             # sum_s Ks^T iB Ks = Kxz^T V   [L,M,M]
-            # P1 = V^T mu (natural-gradient term, elbo_functions.py:262-266) and u = Kxz^T v: one streaming pass per latent each
-            if not fused:
-                _lib.check(lib.hlvae_gp_gemv_t_f32(_lib.ptr(V), _lib.ptr(mu), 1, L, _lib.ptr(P1), L, B, M, st), "gp_gemv_t_f32")
-                _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(Kxz), _lib.ptr(v), v.stride(0), v.stride(1), _lib.ptr(u), L, B, M, st), "gp_gemv_t")
-            _lib.check(lib.hlvae_gp_bound(_lib.ptr(part), S, _lib.ptr(W), _lib.ptr(iK), _lib.ptr(N1), _lib.ptr(self.H), _lib.ptr(self.m),
-                                          _lib.ptr(iKm), _lib.ptr(ldK), _lib.ptr(ldH), _lib.ptr(log_v), B, L, M, _C.c_double(c),
-                                          _C.c_double(float(self.N_total)), _C.c_double(1.0 / world), _lib.ptr(self.last_kld), st),
-                       "gp_bound")
-            if self.dp is not None:
-                self.dp.allreduce_(self._xchg)                               # W, P1, u, bound of the GLOBAL batch
-            self._grad_m, self._grad_H, self._tmp = mm["grad_m"], mm["grad_H"], mm["tmp"]
-            Rs, G_Kzz_s = mm["Rs"], mm["G_Kzz"]
-            if self._chain and M % 4 == 0:
-                # the M x M algebra behind W as ONE launch (csrc/gp.hip k_gp_chain, round 3): natural-gradient terms
-                # (elbo_functions.py:279-283) and the symmetrised K0zz gradient (G + G^T), G = -(iK R iK) + iK / 2,
-                # R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T) -- built from global sums only, i.e. replicated:
-                # each rank contributes 1 / world of it
-                if self._chain == 2:
-                    # by 32-row blocks, two launches (k_gp_chain_rb): 2 x 128 workgroups that never wait for each other
-                    _lib.check(lib.hlvae_gp_chain_rb(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(HiK), _lib.ptr(self.H), _lib.ptr(iH), _lib.ptr(self.m),
-                                                     _lib.ptr(P1), _lib.ptr(u), _C.c_double(self.ng_lr), _C.c_double(c),
-                                                     _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(self._grad_m),
-                                                     _lib.ptr(self._grad_H), _lib.ptr(self._tmp), _lib.ptr(Rs), _lib.ptr(G_Kzz_s), st),
-                               "gp_chain_rb")
-                else:
-                    _lib.check(lib.hlvae_gp_chain(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(HiK), _lib.ptr(self.H), _lib.ptr(iH), _lib.ptr(self.m),
-                                                  _lib.ptr(P1), _lib.ptr(u), _C.c_double(self.ng_lr), _C.c_double(c),
-                                                  _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(mm["T1"]),
-                                                  _lib.ptr(mm["Bm"]), _lib.ptr(self._grad_m), _lib.ptr(self._grad_H), _lib.ptr(self._tmp),
-                                                  _lib.ptr(mm["HiKW"]), _lib.ptr(Rs), _lib.ptr(mm["T1b"]), _lib.ptr(G_Kzz_s), st), "gp_chain")
-                _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
-                                                   _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
-                           "gp_param_grad(Kzz)")
+        evW = evY = None
+        Rs, G_Kzz_s = mm["Rs"], mm["G_Kzz"]
+
+        def chain_c():
+            nonlocal evY
+            with torch.cuda.stream(sC):      # chain C: gradient w.r.t. K0xz and the subject blocks
+                st = self._stream()
+                Y = self._gemm(V, False, N1, buf["Y"], B, M, M)                  # V (iK - Q)   [L,B,M]  (local rows)
                 if balance == 1:
-                    sA.wait_event(evY)
+                    # round 3: the chain rule through K0xz forms G_Kxz = c [ v (iK m)^T - Y ] on the fly (no k_gp_gkxz launch, no 31 MB
+                    # matrix written and read back) and may run on chain A behind the M x M algebra (HL_GP_BALANCE=1) or here behind
+                    # the per-subject kernel (=2)
+                    evY = torch.cuda.Event()
+                    evY.record(sC)
+                elif balance == 2:
+                    pass
+                else:
+                    G_Kxz = buf["G_Kxz"]                                         # c [ v (iK m)^T + V (Q - iK) ]
+                    _lib.check(lib.hlvae_gp_gkxz(_lib.ptr(Y), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), L, B, M, _lib.ptr(G_Kxz), st), "gp_gkxz")
+                    _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
+                                                       _lib.ptr(G_Kxz), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
+                               "gp_param_grad(Kxz)")
+                _lib.check(lib.hlvae_gp_subject_bwd(_C.byref(k0), _C.byref(k1), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), _lib.ptr(idx),
+                                                    S, T, B, M, _lib.ptr(iB), _lib.ptr(K0s), _lib.ptr(V), _lib.ptr(v), _lib.ptr(Y),
+                                                    _lib.ptr(log_v), _C.c_double(c), _lib.ptr(gprm), st), "gp_subject_bwd")
+                if balance == 2:
                     _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
                                                        _lib.ptr(Y), _lib.ptr(gprm), _lib.ptr(gz), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), st),
                                "gp_param_grad(Kxz)")
-            else:
-                evW = torch.cuda.Event()
-                evW.record(sA)                                               # W, P1, u of the global batch are final
-                T1 = self._bmm_into(iK, W, mm["T1"])
-                Bm = self._bmm_into(T1, iK, mm["Bm"], D=iK)                  # iK W iK + iK
-                _lib.check(lib.hlvae_gp_natgrad(_lib.ptr(Bm), _lib.ptr(iK), _lib.ptr(iH), _lib.ptr(self.m), _lib.ptr(P1),
-                                                _C.c_double(self.ng_lr), M, L, _lib.ptr(self._grad_m), _lib.ptr(self._grad_H),
-                                                _lib.ptr(self._tmp), st), "gp_natgrad")
+        def chain_a():
+            nonlocal evW
+            with torch.cuda.stream(sA):      # chain A: the sums over subjects, the bound, natural gradient, gradient w.r.t. K0zz
+                st = self._stream()
+                if fused:     # W was cleared with P1 and u by prepare(): no memset node in front of the chain's first launch
+                    _lib.check(lib.hlvae_gp_gemm_acc(_lib.ptr(Kxz), Kxz.shape[2], Kxz.stride(0), 1, _lib.ptr(V), V.shape[2], V.stride(0),
+                                                     _lib.ptr(W), M, W.stride(0), M, M, B, L, _C.c_double(1.0), st), "gp_gemm_acc")
+                else:
+                    self._gemm(Kxz, True, V, W, M, M, B)                         # sum_s Ks^T iB Ks = Kxz^T V   [L,M,M]
+                # P1 = V^T mu (natural-gradient term, elbo_functions.py:262-266) and u = Kxz^T v: one streaming pass per latent each
+                if not fused:
+                    _lib.check(lib.hlvae_gp_gemv_t_f32(_lib.ptr(V), _lib.ptr(mu), 1, L, _lib.ptr(P1), L, B, M, st), "gp_gemv_t_f32")
+                    _lib.check(lib.hlvae_gp_gemv_t(_lib.ptr(Kxz), _lib.ptr(v), v.stride(0), v.stride(1), _lib.ptr(u), L, B, M, st), "gp_gemv_t")
+                _lib.check(lib.hlvae_gp_bound(_lib.ptr(part), S, _lib.ptr(W), _lib.ptr(iK), _lib.ptr(N1), _lib.ptr(self.H), _lib.ptr(self.m),
+                                              _lib.ptr(iKm), _lib.ptr(ldK), _lib.ptr(ldH), _lib.ptr(log_v), B, L, M, _C.c_double(c),
+                                              _C.c_double(float(self.N_total)), _C.c_double(1.0 / world), _lib.ptr(self.last_kld), st),
+                           "gp_bound")
+                if self.dp is not None:
+                    self.dp.allreduce_(self._xchg)                               # W, P1, u, bound of the GLOBAL batch
+                self._grad_m, self._grad_H, self._tmp = mm["grad_m"], mm["grad_H"], mm["tmp"]
+                if self._chain and M % 4 == 0:
+                    # the M x M algebra behind W as ONE launch (csrc/gp.hip k_gp_chain, round 3): natural-gradient terms
+                    # (elbo_functions.py:279-283) and the symmetrised K0zz gradient (G + G^T), G = -(iK R iK) + iK / 2,
+                    # R = c/2 (2 u m^T - W + HiKW + HiKW^T) + 1/2 (H + m m^T) -- built from global sums only, i.e. replicated:
+                    # each rank contributes 1 / world of it
+                    if self._chain == 2:
+                        # by 32-row blocks, two launches (k_gp_chain_rb): 2 x 128 workgroups that never wait for each other
+                        _lib.check(lib.hlvae_gp_chain_rb(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(HiK), _lib.ptr(self.H), _lib.ptr(iH), _lib.ptr(self.m),
+                                                         _lib.ptr(P1), _lib.ptr(u), _C.c_double(self.ng_lr), _C.c_double(c),
+                                                         _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(self._grad_m),
+                                                         _lib.ptr(self._grad_H), _lib.ptr(self._tmp), _lib.ptr(Rs), _lib.ptr(G_Kzz_s), st),
+                                   "gp_chain_rb")
+                    else:
+                        _lib.check(lib.hlvae_gp_chain(_lib.ptr(iK), _lib.ptr(W), _lib.ptr(HiK), _lib.ptr(self.H), _lib.ptr(iH), _lib.ptr(self.m),
+                                                      _lib.ptr(P1), _lib.ptr(u), _C.c_double(self.ng_lr), _C.c_double(c),
+                                                      _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(mm["T1"]),
+                                                      _lib.ptr(mm["Bm"]), _lib.ptr(self._grad_m), _lib.ptr(self._grad_H), _lib.ptr(self._tmp),
+                                                      _lib.ptr(mm["HiKW"]), _lib.ptr(Rs), _lib.ptr(mm["T1b"]), _lib.ptr(G_Kzz_s), st), "gp_chain")
+                    _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
+                                                       _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
+                               "gp_param_grad(Kzz)")
+                    if balance == 1:
+                        sA.wait_event(evY)
+                        _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,
+                                                           _lib.ptr(buf["Y"]), _lib.ptr(gprm), _lib.ptr(gz), _lib.ptr(v), _lib.ptr(iKm), _C.c_double(c), st),
+                                   "gp_param_grad(Kxz)")
+                else:
+                    evW = torch.cuda.Event()
+                    evW.record(sA)                                               # W, P1, u of the global batch are final
+                    T1 = self._bmm_into(iK, W, mm["T1"])
+                    Bm = self._bmm_into(T1, iK, mm["Bm"], D=iK)                  # iK W iK + iK
+                    _lib.check(lib.hlvae_gp_natgrad(_lib.ptr(Bm), _lib.ptr(iK), _lib.ptr(iH), _lib.ptr(self.m), _lib.ptr(P1),
+                                                    _C.c_double(self.ng_lr), M, L, _lib.ptr(self._grad_m), _lib.ptr(self._grad_H),
+                                                    _lib.ptr(self._tmp), st), "gp_natgrad")
+        # chain A (W -> bound -> M x M algebra -> K0zz gradient -> state update) is the step's critical path: queued FIRST, its first
+        # launch is the per-subject kernel's first child and stays on its hardware queue (the others start behind a cross-queue
+        # signal: 26 us in the round-3 trace); HL_GP_BALANCE=1 needs chain C's event first
+        if balance == 1 or not self._a_first:
+            chain_c()
+            chain_a()
+        else:
+            chain_a()
+            chain_c()
         if not (self._chain and M % 4 == 0):
             # separate launches (HL_GP_CHAIN=0): K0zz's gradient needs W but none of the natural-gradient products; it goes BEHIND
             # chain C (HL_GP_SPLIT=0: behind the natural-gradient launches on chain A, the round-2 order)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 33
+#define HLVAE_ABI_VERSION 34
 #define HLVAE_STAT_CHUNKS 16
 /* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
 #define HLVAE_HEAD_ACC 95
@@ -394,6 +394,10 @@ int hlvae_gp_spd_inv2(const double* A, int n, int N, double* inv, double* logdet
 int hlvae_gp_gemm(const double* A, int lda, int64_t strideA, int transA, const double* B, int ldb, int64_t strideB, const double* D,
                   int ldd, int64_t strideD, double* C, int ldc, int64_t strideC, int M, int N, int K, int batch, double alpha,
                   double beta, hlvae_stream s);
+/* C[l] += alpha op(A[l]) B[l]: as hlvae_gp_gemm without D, adding into C as the caller left it (cleared beforehand: no memset in
+ * front of the launch that heads the GP step's critical chain) */
+int hlvae_gp_gemm_acc(const double* A, int lda, int64_t strideA, int transA, const double* B, int ldb, int64_t strideB, double* C,
+                      int ldc, int64_t strideC, int M, int N, int K, int batch, double alpha, hlvae_stream s);
 /* out[l] = alpha A[l] x[l] + beta y[l]  (A [batch][N][N] row-major; x, y, out [batch][N]; y may be NULL or alias out) */
 int hlvae_gp_bmv(const double* A, const double* x, const double* y, double* out, int N, int batch, double alpha, double beta,
                  hlvae_stream s);
