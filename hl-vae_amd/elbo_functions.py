@@ -334,7 +334,7 @@ class GPPriorHIP:
         # fork 0.610).  Inside a capture with the deferred state update only the second form survives hipStreamEndCapture.
         self._fork_direct = _os.environ.get("HL_GP_FORK_DIRECT", "1") != "0"
         self._defer_capture = False
-        self._a_first = _os.environ.get("HL_GP_A_FIRST", "1") != "0"       # chain A queued before chain C (kl_and_grads)
+        self._a_first = _os.environ.get("HL_GP_A_FIRST", "0") != "0"       # chain A queued before chain C (kl_and_grads)
         self._early = _os.environ.get("HL_GP_EARLY", "1") != "0"          # per-subject kernel forked behind the ENCODER (kl_and_grads(after=...))
         self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
         self._split_kzz = _os.environ.get("HL_GP_SPLIT", "1") != "0"   # K0zz gradient behind chain C (kl_and_grads)
@@ -722,9 +722,9 @@ class GPPriorHIP:
                     _lib.check(lib.hlvae_gp_natgrad(_lib.ptr(Bm), _lib.ptr(iK), _lib.ptr(iH), _lib.ptr(self.m), _lib.ptr(P1),
                                                     _C.c_double(self.ng_lr), M, L, _lib.ptr(self._grad_m), _lib.ptr(self._grad_H),
                                                     _lib.ptr(self._tmp), st), "gp_natgrad")
-        # chain A (W -> bound -> M x M algebra -> K0zz gradient -> state update) is the step's critical path: queued FIRST, its first
-        # launch is the per-subject kernel's first child and stays on its hardware queue (the others start behind a cross-queue
-        # signal: 26 us in the round-3 trace); HL_GP_BALANCE=1 needs chain C's event first
+        # chain A (W -> bound -> M x M algebra -> K0zz gradient -> state update) is the step's critical path; queued FIRST its first
+        # launch would be the per-subject kernel's first child and stay on its hardware queue (HL_GP_A_FIRST=1) -- measured 0.592 vs
+        # 0.588 ms at configs[4], three alternating pairs: chain C first stays.  HL_GP_BALANCE=1 needs chain C's event first
         if balance == 1 or not self._a_first:
             chain_c()
             chain_a()
