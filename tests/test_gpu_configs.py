@@ -368,8 +368,9 @@ def test_conv_backward_against_oracle(B, hid_e, hid_d):
         assert e < tol, (k, e)
 
 
-@pytest.mark.parametrize("hid_e,hid_d", [([500], [500]), ([500, 132], [260, 500])])
-def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d):
+@pytest.mark.parametrize("hid_e,hid_d,conv", [([500], [500], False), ([500, 132], [260, 500], False), ([500], [500], True),
+                                              ([500, 132], [260, 500], True)], ids=["mlp", "deep", "conv", "conv-deep"])
+def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d, conv):
     """The data-parallel optimiser path at world size 1 (flat Adam on the whole dense region -> bf16 copy -> shadows rebuilt
     from it; hl-vae_amd/parallel.py with the collectives skipped) against the fused tile Adam of the single-process step: D4,
     512 rows, three steps with the same noise -- same arithmetic, so the parameters agree to fp32 atomics' reordering and the
@@ -387,7 +388,7 @@ def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d):
     res = []
     for dp in (None, DataParallel.single()):
         torch.manual_seed(5)
-        model = HLVAE(dims, src.types_info, src.n_variables, conv=False, max_batch=512, materialize_samples=False).to(dev)
+        model = HLVAE(dims, src.types_info, src.n_variables, conv=conv, max_batch=512, materialize_samples=False).to(dev)
         tr = ELBOTrainer(model, P_total=30, kl="normal", max_batch=512, dp=dp, metrics=True)
         nll = []
         tr.prime_rows(ds, rows[0])

@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests/test_gpu_configs.py -x -q -m gpu -k "sharded_optimizer" > gpurun_out/c51_tests.log 2>&1
+echo "exit $?" >> gpurun_out/c51_tests.log
+tail -30 gpurun_out/c51_tests.log | cut -c1-300
