@@ -406,10 +406,16 @@ def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d, conv):
                                                 if k in ("wys", "wyTs", "w1s", "w1Ts", "wds", "wdTs", "wmls", "wmlTs") or k.endswith(("_w", "_wT"))}))
     (nll_a, P_a, sh_a), (nll_b, P_b, sh_b) = res
     assert rel_err(np.array(nll_b), np.array(nll_a)) < 1e-6, (nll_a, nll_b)
-    assert rel_err(P_b, P_a) < 1e-6
+    # conv: the two paths fold the convolutions' per-workgroup partial gradient rows in different launches (k_conv_grad_finish before
+    # the tile Adam / before the flat Adam) and the feature gradient's atomics reorder; Adam's normalisation turns the last-bit noise
+    # of near-zero gradients into visible steps in the first updates (measured 8e-6 of the largest parameter after three steps)
+    p_tol, flip_tol = (5e-5, 2e-3) if conv else (1e-6, 1e-4)
+    _report("sharded_vs_fused_" + ("conv" if conv else "mlp") + ("_deep" if len(hid_e) > 1 else ""), params=rel_err(P_b, P_a),
+            nll=rel_err(np.array(nll_b), np.array(nll_a)), shadow_flips=max(float((sh_a[k] != sh_b[k]).float().mean()) for k in sh_a))
+    assert rel_err(P_b, P_a) < p_tol
     for k in sh_a:
         assert float((sh_a[k].float() - sh_b[k].float()).abs().max()) <= 2.0 ** -8 * float(sh_a[k].float().abs().max()), k
-        assert float((sh_a[k] != sh_b[k]).float().mean()) < 1e-4, k          # a last-bit difference of a master may flip a rounding
+        assert float((sh_a[k] != sh_b[k]).float().mean()) < flip_tol, k       # a last-bit difference of a master may flip a rounding
 
 
 def test_vy_fixed_parameters_stay_put_under_the_fused_optimiser():
