@@ -5,7 +5,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
-import synthetic
+from hlvae_amd import synthetic
 from hlvae_amd.HLVAE import HLVAE
 from hlvae_amd.training import ELBOTrainer
 from hlvae_amd.parallel import DataParallel
