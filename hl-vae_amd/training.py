@@ -66,7 +66,7 @@ class ShardedAdam:
         # its reduce-scatter overlaps the rest of the backward pass; the convolutional model's y_layer gradient is final only
         # after the transposed convolutions' backward, so its (smaller) dense region is one slice
         rest = 0x1e | sum(1 << (5 + i) for i in range(int(d.n_xe))) | sum(1 << (5 + _lib.MAX_EXTRA + j) for j in range(int(d.n_xd)))
-        ranges = [(a0, end, 0x1f)] if model.conv else [(o_wy, end, 0x01), (a0, o_wy, rest)]
+        ranges = [(a0, end, 0x01 | rest)] if model.conv else [(o_wy, end, 0x01), (a0, o_wy, rest)]
         self.plan = ShardPlan(ranges, dp.world, dp.rank)
         if self.plan.pad > GRAD_SLACK:
             raise ValueError(f"world size {dp.world}: slice padding {self.plan.pad} exceeds the gradient arena's slack")
