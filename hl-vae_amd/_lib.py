@@ -94,7 +94,6 @@ _SIGS = {
     "hlvae_step_metrics": (C.c_int, [_vp, C.POINTER(HlvaeWs), C.c_int, _vp, _vp]),
     "hlvae_join": (C.c_int, [_vp, _vp]),
     "hlvae_set_defer_join": (C.c_int, [_vp, C.c_int]),
-    "hlvae_set_optimizer_gate": (C.c_int, [_vp, _vp]),
     "hlvae_scale_dy": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, C.c_int, _vp]),
     "hlvae_backward": (C.c_int, [_vp, C.POINTER(HlvaeWs), _vp, _vp, C.c_float, C.c_int, C.c_int, _vp]),
     "hlvae_backward_wy": (C.c_int, [_vp, C.POINTER(HlvaeWs), C.c_int, _vp]),

@@ -248,7 +248,6 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     p->kmax = 2;
     p->pend_flags = 0;
     p->defer_join = 0;
-    p->opt_gate = nullptr;
     for (int i = 0; i < d.D; ++i)
         if ((vars[i].kind == HLVAE_CAT || vars[i].kind == HLVAE_ORDINAL) && vars[i].ncls > p->kmax) p->kmax = vars[i].ncls;
     for (auto& st : p->side) st = nullptr;
@@ -542,12 +541,6 @@ int hlvae_set_defer_join(const hlvae_plan* p, int on) {
     return 0;
 }
 
-int hlvae_set_optimizer_gate(const hlvae_plan* p, void* event) {
-    HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
-    p->opt_gate = (hipEvent_t)event;
-    return 0;
-}
-
 int hlvae_reset_pending(const hlvae_plan* p) {
     HL_REQUIRE(p, HLVAE_EINVAL, "null plan");
     p->pend_flags = 0;          // deferred side work recorded against a capture that failed: dropped
@@ -704,9 +697,6 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         const long bias_lo = d.o_bd, bias_n = d.atomic_region - d.o_bd;
         HL_REQUIRE(d.o_bd % 4 == 0 && bias_n % 4 == 0 && d.o_bmu > d.o_bd && d.o_blv > d.o_bd && d.o_b1 > d.o_bd && d.o_by < d.o_bd,
                    HLVAE_EINVAL, "backward_adam: the arena must end its small region with [bd | bmu | blv | b1]");
-        // (host-provided gate: the HBM-streaming optimiser launches wait for an event of the host's -- the GP prior's critical chain,
-        //  whose L2-resident M x M kernels ran at half speed beside them; the window behind that chain is nearly idle)
-        if (p->opt_gate != nullptr) HL_CHECK(hipStreamWaitEvent(st, p->opt_gate, 0));
         if ((rc = hl_launch_gemm_adam(g_rest, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
                                       tickets, "dW1_dWd_dWmu_adam", st, ws->G, bias_lo, bias_n, p->tick_dev))) return rc;
         HL_CHECK(hipStreamWaitEvent(s0, p->ev[0], 0));
@@ -720,7 +710,6 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         // the middle kernel has 256 workgroups; there the launch starts with the head kernel's end when it may (0.485 vs 0.522 ms)
         const bool small_batch = Bp < 2048;
         if (g_wy.p[0].sh == ws->wys || small_batch) HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
-        if (p->opt_gate != nullptr) HL_CHECK(hipStreamWaitEvent(s0, p->opt_gate, 0));
         if ((rc = hl_launch_gemm_adam(g_wy, ws->P, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale,
                                       tickets, "dWy_adam", s0, nullptr, 0, 0, p->tick_dev + HL_TICK_WORDS))) return rc;
 
@@ -798,7 +787,6 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
             HL_REQUIRE(ws->wys_next == nullptr, HLVAE_EINVAL, "backward_adam: ws->wys_next is honoured by the fused-optimiser step only "
                        "(hlvae_backward_adam_fused() says when)");
             HL_CHECK(hipStreamWaitEvent(s0, p->ev[2], 0));
-            if (p->opt_gate != nullptr) HL_CHECK(hipStreamWaitEvent(s0, p->opt_gate, 0));
             if ((rc = hl_adam_part(p, ws, opt->m1, opt->m2, opt->step_count, opt->lr, opt->b1, opt->b2, opt->eps, opt->gscale, 0x01, 0,
                                    0u, "adam_wy_early", s0))) return rc;
             if (conv_opt) {     // convolutional model: the other dense matrices too, under the 56 us of the encoder's backward

@@ -137,7 +137,6 @@ struct hlvae_plan {
     // launches are queued on a side stream by the next hlvae_backward* / hlvae_join (cabi.hip: hl_flush_deferred)
     mutable int pend_flags;        // HL_PEND_*
     mutable int defer_join;        // hlvae_set_defer_join: hlvae_backward* return without joining the deferred side chain
-    mutable hipEvent_t opt_gate;   // hlvae_set_optimizer_gate: the optimiser launches of hlvae_backward_adam wait for this event (null: none)
     mutable hlvae_ws pend_ws, pend_fin_ws;
     mutable int pend_B, pend_fin_B;
     mutable float* pend_err;

@@ -334,10 +334,6 @@ class GPPriorHIP:
         # fork 0.610).  Inside a capture with the deferred state update only the second form survives hipStreamEndCapture.
         self._fork_direct = _os.environ.get("HL_GP_FORK_DIRECT", "1") != "0"
         self._defer_capture = False
-        # event for the VAE's optimiser launches to wait on (ELBOTrainer -> hlvae_set_optimizer_gate): 0 none, 1 behind the first
-        # row-block launch of the M x M chain, 2 behind chain A's last launch
-        self._gate = int(_os.environ.get("HL_GP_GATE", "0"))
-        self.gate_event = None
         self._a_first = _os.environ.get("HL_GP_A_FIRST", "0") != "0"       # chain A queued before chain C (kl_and_grads)
         self._early = _os.environ.get("HL_GP_EARLY", "1") != "0"          # per-subject kernel forked behind the ENCODER (kl_and_grads(after=...))
         self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
@@ -563,7 +559,6 @@ class GPPriorHIP:
         dev = mu.device
         c = float(P_total) / float(P_batch)
         prep, self._prep = self._prep, None
-        self.gate_event = None
         early = False
         if prep is not None and (train_x is None or train_x is prep[0]):
             x, idx, buf, hyp, Kxz, iKm, HiK, N1 = prep
@@ -711,15 +706,9 @@ class GPPriorHIP:
                                                       _C.c_double(-1.0 / world), _C.c_double(1.0 / world), M, L, _lib.ptr(mm["T1"]),
                                                       _lib.ptr(mm["Bm"]), _lib.ptr(self._grad_m), _lib.ptr(self._grad_H), _lib.ptr(self._tmp),
                                                       _lib.ptr(mm["HiKW"]), _lib.ptr(Rs), _lib.ptr(mm["T1b"]), _lib.ptr(G_Kzz_s), st), "gp_chain")
-                    if self._gate == 1 and self.dp is None:
-                        self.gate_event = torch.cuda.Event()
-                        self.gate_event.record(sA)
                     _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(z), M, 1, _lib.ptr(z), M, 1,
                                                        _lib.ptr(G_Kzz_s), _lib.ptr(gprm), _lib.ptr(gz), None, None, _C.c_double(0.0), st),
                                "gp_param_grad(Kzz)")
-                    if self._gate == 2 and self.dp is None:
-                        self.gate_event = torch.cuda.Event()
-                        self.gate_event.record(sA)
                     if balance == 1:
                         sA.wait_event(evY)
                         _lib.check(lib.hlvae_gp_param_grad(_C.byref(k0), _lib.ptr(hyp), self.n_slots, L, Q, _lib.ptr(x), B, 0, _lib.ptr(z), M, 0,

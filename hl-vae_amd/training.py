@@ -367,16 +367,11 @@ class ELBOTrainer:
             late_join = self.kl == "gp" and hasattr(self.gp, "join") and os.environ.get("HL_GP_LATE_JOIN", "1") != "0"
             if late_join:
                 _lib.check(lib.hlvae_set_defer_join(m._plan_handle, 2 if self._gp_defer else 1), "set_defer_join")
-            gate = getattr(self.gp, "gate_event", None) if self.kl == "gp" else None
-            if gate is not None:       # the streaming optimiser launches wait for the prior's M x M chain (hlvae_set_optimizer_gate)
-                _lib.check(lib.hlvae_set_optimizer_gate(m._plan_handle, C.c_void_p(gate.cuda_event)), "set_optimizer_gate")
             try:
                 _lib.check(lib.hlvae_backward_adam(m._plan_handle, ws, _lib.ptr(g_mu), _lib.ptr(g_lv), C.c_float(kl_w), B, _lib.ptr(o.m1),
                                                    _lib.ptr(o.m2), _lib.ptr(o.step_count), C.c_float(o.lr), C.c_float(o.betas[0]),
                                                    C.c_float(o.betas[1]), C.c_float(o.eps), C.c_float(1.0), s), "backward_adam")
             finally:
-                if gate is not None:
-                    lib.hlvae_set_optimizer_gate(m._plan_handle, None)
                 if late_join:
                     lib.hlvae_set_defer_join(m._plan_handle, 0)
                 if dbuf:

@@ -272,10 +272,6 @@ int hlvae_join(const hlvae_plan* p, hlvae_stream s);
  * on == 2: as 1, and the deferred work is queued on the CALLER's stream behind the backward pass's last launch of its own instead
  * of on the library's side stream (a host whose own side streams own the hardware queues: the GP prior with a deferred update). */
 int hlvae_set_defer_join(const hlvae_plan* p, int on);
-/* event (hipEvent_t, recorded by the host on one of ITS streams before the call; NULL: none): the HBM-streaming optimiser launches of
- * the next hlvae_backward_adam calls wait for it -- the rest of the backward pass does not.  The GP prior gates them behind its
- * M x M chain (L2-resident operands, half speed beside 100 MB streaming launches); the window behind that chain is nearly idle. */
-int hlvae_set_optimizer_gate(const hlvae_plan* p, void* event);
 
 /* rescale ws->dy by a per-element upstream gradient after the fact (autograd path) */
 int hlvae_scale_dy(const hlvae_plan* p, const hlvae_ws* ws, const float* g_logpx, int B, hlvae_stream s);
