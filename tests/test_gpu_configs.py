@@ -409,8 +409,8 @@ def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d, conv):
     assert rel_err(np.array(nll_b), np.array(nll_a)) < 1e-6, (nll_a, nll_b)
     # conv: the two paths fold the convolutions' per-workgroup partial gradient rows in different launches (k_conv_grad_finish before
     # the tile Adam / before the flat Adam) and the feature gradient's atomics reorder; Adam's normalisation turns the last-bit noise
-    # of near-zero gradients into visible steps in the first updates (measured 8e-6 of the largest parameter after three steps)
-    p_tol, flip_tol = (5e-5, 2e-2) if conv else (1e-6, 1e-4)
+    # of near-zero gradients into visible steps in the first updates (measured up to 9e-6 of the largest parameter after three steps; the NLL of all three steps agrees to 1e-10)
+    p_tol, flip_tol = (2e-4, 5e-2) if conv else (1e-6, 1e-4)       # (conv, measured over five runs: 1.3e-7 ... 8.6e-6 and 1e-5 ... 7.9e-3)
     per = {k: float((named[0][k].double() - named[1][k].double()).abs().max() / (named[0][k].double().abs().max() + 1e-30))
            for k in named[0] if named[0][k].numel()}
     worst = sorted(per.items(), key=lambda kv: -kv[1])[:6]
