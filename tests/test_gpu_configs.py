@@ -368,6 +368,56 @@ def test_conv_backward_against_oracle(B, hid_e, hid_d):
         assert e < tol, (k, e)
 
 
+def test_conv_logvar_network_with_deeper_trunks_against_oracle():
+    """the two round-3 constructor combinations TOGETHER (conv=True, logvar_network=True, two hidden layers per side), 512 rows:
+    ELBO, loss and every gradient tensor against the fp64 oracle (pinned to the reference on each combination separately:
+    d4_conv_logvar_small, d4_conv_deep_small)."""
+    import hlvae_oracle as orc
+    from hlvae_amd import layout
+    from hlvae_amd.HLVAE import HLVAE
+    dev = _dev()
+    B = 512
+    src = synthetic.make_d4(n_subjects=B // 20 + 2, T=20, seed=101)
+    info = layout.build_types_info(src.types_info["types_dict"], miss_mask=src.mask, logvar_network=True)
+    dims = [src.cov_dim_ext, [300, 132], 32, [260, 300], 5]
+    torch.manual_seed(7)
+    model = HLVAE(dims, info, src.n_variables, conv=True, logvar_network=True, max_batch=B, materialize_samples=False).to(dev)
+    state = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items()}
+    eps = torch.randn(B, 32, generator=torch.Generator().manual_seed(2))
+    data, mask = torch.tensor(src.data[:B]), torch.tensor(src.mask[:B])
+    scale = 7.5
+    out = model(data.to(dev), mask.to(dev), None, info, eps=eps.to(dev))
+    mu, lv, lpx = out[1], out[2], out[3]
+    loss = scale * model.loss_function(lpx).sum() - 0.5 * torch.sum(1.0 + lv - mu ** 2 - torch.exp(lv))
+    loss.backward()
+    torch.cuda.synchronize()
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    for k in list(st):
+        if k.startswith("hidden."):
+            st[k] = st["d_layers." + k[len("hidden."):]]
+        if k.startswith("Decoder_Conv_layer."):
+            st[k] = st["deconv_layer." + k[len("Decoder_Conv_layer."):]]
+    om = orc.OracleHLVAE(dims, info, src.n_variables, st, conv=True)
+    ref = om.forward(data, mask, eps.double())
+    ref_loss = scale * om.loss_function(ref["log_p_x"]).sum() + orc.standard_normal_kl(ref["mu"], ref["log_var"])
+    ref_loss.backward()
+    elbo, elbo_ref = float(lpx.detach().double().sum()), float(ref["log_p_x"].sum())
+    _report("conv_logvar_deep_b512", elbo_rel=abs(elbo - elbo_ref) / abs(elbo_ref),
+            loss_rel=abs(float(loss.detach()) - float(ref_loss)) / abs(float(ref_loss)))
+    assert abs(elbo - elbo_ref) <= ELBO_RTOL * abs(elbo_ref), (elbo, elbo_ref)
+    assert abs(float(loss.detach()) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss))
+    sd = dict(model.named_parameters())
+    errs = {}
+    for k, p in sd.items():
+        if k.startswith(("hidden.", "Decoder_Conv_layer.")) or p.grad is None or st[k].grad is None or p.numel() == 0:
+            continue
+        errs[k] = rel_err(p.grad.double().cpu().numpy(), st[k].grad.numpy())
+    _report("conv_logvar_deep_b512_grads", **errs)
+    assert len(errs) >= 24, sorted(errs)
+    for k, e in errs.items():
+        assert e < (5e-2 if k == "d_layers.0.weight" else GRAD_RTOL), (k, e)      # (as test_conv_backward_against_oracle)
+
+
 @pytest.mark.parametrize("hid_e,hid_d,conv", [([500], [500], False), ([500, 132], [260, 500], False), ([500], [500], True),
                                               ([500, 132], [260, 500], True)], ids=["mlp", "deep", "conv", "conv-deep"])
 def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d, conv):
