@@ -114,13 +114,21 @@ class HLVAE(nn.Module):
         if conv and (n_variables != 36 * 36 or y_dim != 5):
             raise ValueError("conv=True views the variables as one 36 x 36 image with y_dim = 5 output channels "
                              "(reference HLVAE.py:305, 257-258)")
+        # the reference's "no hidden layer" spellings (HLVAE.py:128, 233): None, [], 0, [0]
+        h_dim_e = [] if h_dim_e in (None, 0, [0]) else h_dim_e
+        h_dim_d = [] if h_dim_d in (None, 0, [0]) else h_dim_d
         if not (isinstance(h_dim_e, (list, tuple)) and isinstance(h_dim_d, (list, tuple))
-                and 1 <= len(h_dim_e) <= 1 + _lib.MAX_EXTRA and 1 <= len(h_dim_d) <= 1 + _lib.MAX_EXTRA
+                and len(h_dim_e) <= 1 + _lib.MAX_EXTRA and len(h_dim_d) <= 1 + _lib.MAX_EXTRA
                 and all(int(w) > 0 for w in list(h_dim_e) + list(h_dim_d))):
-            raise NotImplementedError(f"dims[1] / dims[3] must list 1..{1 + _lib.MAX_EXTRA} positive hidden widths per side (reference "
-                                      "config: [500]; the reference's h_dim = [] / 0 'no hidden layer' variants are not built)")
+            raise NotImplementedError(f"dims[1] / dims[3] must list 0..{1 + _lib.MAX_EXTRA} positive hidden widths per side (reference "
+                                      "config: [500])")
         h_dim_e = [int(w) for w in h_dim_e]
         h_dim_d = [int(i) for i in reversed(h_dim_d)]                               # HLVAE.py:113
+        # no hidden layer on a side (round 3): the kernels keep their one-hidden-layer shape with a LINEAR "hidden layer" -- encoder:
+        # [mean_layer.weight; log_var_layer.weight] is the kernels' first Linear (width 2 z_dim) and their mean / log-var heads hold an
+        # identity that is never trained; decoder: the kernels' decoder trunk is an identity on the latent (include/hlvae_hip.h:
+        # hlvae_dims.lin_e / lin_d)
+        self._lin_e, self._lin_d = len(h_dim_e) == 0, len(h_dim_d) == 0
         self.z_dim, self.num_dim, self.y_dim = z_dim, n_variables, y_dim
         self.logvar_network, self.conv = logvar_network, conv
         self.tau = 1e-3
@@ -134,7 +142,8 @@ class HLVAE(nn.Module):
             raise ValueError(f"dims[0]={x_dim}/n_variables={n_variables} do not match types_info "
                              f"(X={self.plan.X}, D={self.plan.D})")
         # h_e: the LAST encoder layer (feeds mean / log-var); h_d: the LAST decoder layer (y_layer's input); h_d0: the first
-        self.h_e, self.h_d, self.h_d0 = h_dim_e[-1], h_dim_d[-1], h_dim_d[0]
+        self.h_e = 2 * z_dim if self._lin_e else h_dim_e[-1]
+        self.h_d, self.h_d0 = (z_dim, z_dim) if self._lin_d else (h_dim_d[-1], h_dim_d[0])
         self._h_dim_e, self._h_dim_d = h_dim_e, h_dim_d
         pl = self.plan
         # bookkeeping attributes the reference exposes (HLVAE.py:180-201)
@@ -162,8 +171,8 @@ class HLVAE(nn.Module):
             e_layers += [nn.Linear(n_in, w), nn.ReLU()]
             n_in = w
         self.VAE_encoder_common_layers = nn.Sequential(*e_layers)
-        self.mean_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
-        self.log_var_layer = nn.Sequential(nn.Linear(self.h_e, z_dim))
+        self.mean_layer = nn.Sequential(nn.Linear(n_in, z_dim))                     # (n_in: the last hidden width, or the input's)
+        self.log_var_layer = nn.Sequential(nn.Linear(n_in, z_dim))
         if logvar_network:                                                           # HLVAE.py:219-222: plain None attributes
             self._log_vy_real = self._log_vy_pos = None
         else:
@@ -209,23 +218,44 @@ class HLVAE(nn.Module):
         # the fused kernels' "first encoder Linear" is the LAST of the stack, their decoder trunk the FIRST decoder Linear;
         # the other hidden layers are the "extra" ones (include/hlvae_hip.h: hlvae_layer)
         # (plain attribute slots: assigning a Module to self would register it under a second state_dict key)
-        object.__setattr__(self, "_enc_last", self.VAE_encoder_common_layers[2 * (len(h_dim_e) - 1)])
         object.__setattr__(self, "_extra_enc", [self.VAE_encoder_common_layers[2 * i] for i in range(len(h_dim_e) - 1)])
         object.__setattr__(self, "_extra_dec", [self.d_layers[2 * j] for j in range(1, len(h_dim_d))])
-        order += [self.y_layer[0].bias, self.d_layers[0].bias, self.mean_layer[0].bias, self.log_var_layer[0].bias,
-                  self._enc_last.bias] + [m.bias for m in self._extra_enc + self._extra_dec]
+
+        def hidden_param(*shape):      # a tensor of the arena that is NOT a parameter of the model (no state_dict key, never trained)
+            return nn.Parameter(torch.empty(*shape), requires_grad=False)
+        glue = set()                   # parameters that the next one follows without padding (one matrix for the kernels)
+        if self._lin_e:
+            # kernels' "first Linear" = [mean ; log-var] rows, their heads = identity
+            k_w1, k_b1 = [self.mean_layer[0].weight, self.log_var_layer[0].weight], [self.mean_layer[0].bias, self.log_var_layer[0].bias]
+            glue |= {id(k_w1[0]), id(k_b1[0])}
+            object.__setattr__(self, "_id_enc", (hidden_param(z_dim, 2 * z_dim), hidden_param(z_dim, 2 * z_dim), hidden_param(z_dim),
+                                                 hidden_param(z_dim)))
+            k_wmu, k_wlv, k_bmu, k_blv = self._id_enc
+        else:
+            enc_last = self.VAE_encoder_common_layers[2 * (len(h_dim_e) - 1)]
+            k_w1, k_b1 = [enc_last.weight], [enc_last.bias]
+            k_wmu, k_wlv, k_bmu, k_blv = (self.mean_layer[0].weight, self.log_var_layer[0].weight, self.mean_layer[0].bias,
+                                          self.log_var_layer[0].bias)
+            object.__setattr__(self, "_id_enc", ())
+        if self._lin_d:
+            object.__setattr__(self, "_id_dec", (hidden_param(z_dim, z_dim), hidden_param(z_dim)))
+            k_wd, k_bd = self._id_dec
+        else:
+            k_wd, k_bd = self.d_layers[0].weight, self.d_layers[0].bias
+            object.__setattr__(self, "_id_dec", ())
+        object.__setattr__(self, "_kernel_params", dict(w1=k_w1[0], b1=k_b1[0], wmu=k_wmu, wlv=k_wlv, bmu=k_bmu, blv=k_blv, wd=k_wd, bd=k_bd))
+        order += [self.y_layer[0].bias, k_bd, k_bmu, k_blv] + k_b1 + [m.bias for m in self._extra_enc + self._extra_dec]
         n_small = len(order)
         # y_layer's weight LAST: its gradient is final first and is all-reduced on its own while the rest of the backward
         # pass runs; everything before it is then ONE contiguous slice for the second all-reduce
-        order += ([self.d_layers[0].weight, self.mean_layer[0].weight, self.log_var_layer[0].weight, self._enc_last.weight]
-                  + [m.weight for m in self._extra_enc + self._extra_dec] + [self.y_layer[0].weight])
+        order += ([k_wd, k_wmu, k_wlv] + k_w1 + [m.weight for m in self._extra_enc + self._extra_dec] + [self.y_layer[0].weight])
         self._order = order
         offs, o = [], 0
         for i, p in enumerate(order):
             if i == n_small:
                 self._atomic_region = o
             offs.append(o)
-            o = _ru(o + p.numel(), 32)
+            o = o + p.numel() if id(p) in glue else _ru(o + p.numel(), 32)
         self._offsets = offs
         self._arena_size = _ru(o, 64)
         arena = torch.zeros(self._arena_size, dtype=torch.float32)
@@ -271,6 +301,20 @@ class HLVAE(nn.Module):
                 self._log_vy_real.fill_(float(torch.log(vy_init[0] - torch.exp(min_log_vy))))
                 self._log_vy_pos.fill_(float(torch.log(vy_init[1] - torch.exp(min_log_vy))))
             self._disp_param.fill_(1.0)
+            self._fill_identities()
+
+    def _fill_identities(self):
+        """the never-trained tensors of a model without hidden layers (see __init__): [Wmu; Wlv] = I, Wd = I, their biases 0"""
+        with torch.no_grad():
+            if self._id_enc:
+                wmu, wlv, bmu, blv = self._id_enc
+                L = self.z_dim
+                wmu.zero_(); wlv.zero_(); bmu.zero_(); blv.zero_()
+                wmu[:, :L] = torch.eye(L, device=wmu.device)
+                wlv[:, L:] = torch.eye(L, device=wlv.device)
+            if self._id_dec:
+                wd, bd = self._id_dec
+                wd.copy_(torch.eye(self.z_dim, device=wd.device)); bd.zero_()
 
     def _apply(self, fn, *a, **k):
         """``.to(device)`` / ``.cuda()`` move the arena as ONE tensor and re-bind the parameter views;
@@ -338,10 +382,12 @@ class HLVAE(nn.Module):
             first = self.representation_layer[0].weight if len(self.representation_layer) else self.conv1.weight
             d.o_cv_lo = ao(first)                         # the arena order puts these tensors back to back (see __init__)
             d.cv_n = ao(self.y_layer[0].bias) + self.y_layer[0].bias.numel() - d.o_cv_lo
-        d.o_w1, d.o_b1 = ao(self._enc_last.weight), ao(self._enc_last.bias)
-        d.o_wmu, d.o_bmu = ao(self.mean_layer[0].weight), ao(self.mean_layer[0].bias)
-        d.o_wlv, d.o_blv = ao(self.log_var_layer[0].weight), ao(self.log_var_layer[0].bias)
-        d.o_wd, d.o_bd = ao(self.d_layers[0].weight), ao(self.d_layers[0].bias)
+        kp = self._kernel_params
+        d.o_w1, d.o_b1 = ao(kp["w1"]), ao(kp["b1"])
+        d.o_wmu, d.o_bmu = ao(kp["wmu"]), ao(kp["bmu"])
+        d.o_wlv, d.o_blv = ao(kp["wlv"]), ao(kp["blv"])
+        d.o_wd, d.o_bd = ao(kp["wd"]), ao(kp["bd"])
+        d.lin_e, d.lin_d = int(self._lin_e), int(self._lin_d)
         d.o_wy, d.o_by = ao(self.y_layer[0].weight), ao(self.y_layer[0].bias)
         d.n_xe, d.n_xd, d.h_d0 = len(self._extra_enc), len(self._extra_dec), self.h_d0
         for arr, mods in ((d.xe, self._extra_enc), (d.xd, self._extra_dec)):

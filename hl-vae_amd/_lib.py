@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HLVAE_LIB_PATH", os.path.join(_HERE, "libhlvae_hip.so"))      # (override: diagnostic builds)
-ABI_VERSION = 34
+ABI_VERSION = 35
 STAT_CHUNKS = 16
 HEAD_ACC = 95
 
@@ -40,7 +40,8 @@ class HlvaeDims(C.Structure):
                                             "o_wy", "o_by", "o_c1w", "o_c1b", "o_c2w", "o_c2b", "o_t1w", "o_t1b", "o_t2w", "o_t2b",
                                             "o_cv_lo", "cv_n", "arena_size", "atomic_region", "frozen_lo", "frozen_hi")]
                 + [(n, C.c_int32) for n in ("n_xe", "n_xd", "h_d0", "K1", "K1p", "hd0p")]
-                + [("xe", HlvaeLayer * MAX_EXTRA), ("xd", HlvaeLayer * MAX_EXTRA), ("o_xw", C.c_int64)])
+                + [("xe", HlvaeLayer * MAX_EXTRA), ("xd", HlvaeLayer * MAX_EXTRA), ("o_xw", C.c_int64),
+                   ("lin_e", C.c_int32), ("lin_d", C.c_int32)])
 
 
 WS_POINTERS = ("P", "G", "w1s", "wmls", "wmlTs", "wds", "wdTs", "wys", "wyTs", "sums", "norm", "xn", "xnT", "xt", "m8",

@@ -174,6 +174,10 @@ int hlvae_plan_create(hlvae_plan** out, const hlvae_dims* dims, const hlvae_var*
     }
     HL_REQUIRE(d.n_xd == 0 || d.xd[d.n_xd - 1].n_out == d.h_d, HLVAE_EINVAL, "plan_create: the last decoder layer must have h_d = %d outputs", d.h_d);
     HL_REQUIRE(d.o_xw > d.o_w1 && d.o_xw <= d.o_wy, HLVAE_EINVAL, "plan_create: o_xw outside (o_w1, o_wy]");
+    HL_REQUIRE(!d.lin_e || (d.n_xe == 0 && d.h_e == 2 * d.L), HLVAE_EINVAL, "plan_create: lin_e (no encoder hidden layer) needs h_e = 2 L = %d "
+               "and no extra encoder layers (h_e = %d)", 2 * d.L, d.h_e);
+    HL_REQUIRE(!d.lin_d || (d.n_xd == 0 && d.h_d == d.L), HLVAE_EINVAL, "plan_create: lin_d (no decoder hidden layer) needs h_d = L = %d and no "
+               "extra decoder layers (h_d = %d)", d.L, d.h_d);
     HL_REQUIRE(!d.conv || d.D == 36 * 36, HLVAE_EINVAL, "plan_create: the convolutional model needs 36 x 36 = 1296 variables "
                "(HLVAE.py:305), got %d", d.D);
     if (d.conv) {
@@ -564,7 +568,7 @@ int hlvae_backward_wy(const hlvae_plan* p, const hlvae_ws* ws, int B, hlvae_stre
 
 // does hlvae_backward_adam apply the optimiser step in the epilogue of the weight-gradient GEMMs for this model and batch?
 static bool hl_fused_optimiser(const hlvae_dims& d, int Bp) {
-    return !d.conv && d.n_xe == 0 && d.n_xd == 0 && getenv("HL_NO_FUSED_ADAM") == nullptr && hl_gemm_adam_ok(d.NYl, d.h_d, Bp, false) &&
+    return !d.conv && d.n_xe == 0 && d.n_xd == 0 && !d.lin_e && !d.lin_d && getenv("HL_NO_FUSED_ADAM") == nullptr && hl_gemm_adam_ok(d.NYl, d.h_d, Bp, false) &&
            hl_gemm_adam_ok(d.h_e, d.K1, Bp, false) && hl_gemm_adam_ok(d.h_d0, d.L, Bp, true) && hl_gemm_adam_ok(2 * d.Lp, d.h_e, Bp, true);
 }
 
@@ -733,17 +737,17 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
     const bf16_t* w1_inT = d.n_xe > 0 ? ws->xe[d.n_xe - 1].aT : ws->xnT;
     // d W1 = dT^T Xn [h_e][X] (no input gradient for layer 1);  d Wd = dU^T z [h_d][L];  d [Wmu; Wlv] = dml^T T 2 x [L][h_e]
     GemmGroup g{};
-    g.n = 3;
+    g.n = 1;
     g.K = Bp;
     g.p[0] = GemmProb{ws->dtT, w1_inT, ws->G + d.o_w1, nullptr, Bp, Bp, d.K1, d.h_e, d.K1, 0, 0};
-    g.p[1] = GemmProb{ws->duT, ws->zbT, ws->G + d.o_wd, nullptr, Bp, Bp, d.L, d.h_d0, d.L, 0, 0};
-    g.p[2] = GemmProb{ws->dmlT, ws->tT, ws->G + d.o_wmu, ws->G + d.o_wlv, Bp, Bp, d.h_e, 2 * d.Lp, d.h_e, d.Lp, d.L};
+    // (dims without hidden layers: Wd / [Wmu; Wlv] are identities nobody trains -- their gradients are not formed and stay zero)
+    if (!d.lin_d) g.p[g.n++] = GemmProb{ws->duT, ws->zbT, ws->G + d.o_wd, nullptr, Bp, Bp, d.L, d.h_d0, d.L, 0, 0};
+    if (!d.lin_e) g.p[g.n++] = GemmProb{ws->dmlT, ws->tT, ws->G + d.o_wmu, ws->G + d.o_wlv, Bp, Bp, d.h_e, 2 * d.Lp, d.h_e, d.Lp, d.L};
     // few output tiles and a long batch axis (a 64-feature model at 4096 rows: 24 tiles x 64 k-steps): split-K with fp32 atomics
     // into the (cleared) gradient slices -- they are neighbours in the arena: [Wd | Wmu | Wlv | W1]
     if (wy_in_group) {      // (rows of dY^T are in the head kernel's variable order: stored through the row map)
-        g.n = 4;
-        g.p[3] = GemmProb{dylT, ws->uT, ws->G + d.o_wy, nullptr, Bp, Bp, d.h_d, d.NYl, d.h_d, 0, 0};
-        g.p[3].rowmap = p->wy_rowsrc_dev;
+        g.p[g.n] = GemmProb{dylT, ws->uT, ws->G + d.o_wy, nullptr, Bp, Bp, d.h_d, d.NYl, d.h_d, 0, 0};
+        g.p[g.n++].rowmap = p->wy_rowsrc_dev;
     }
     g.ksplit = wg_ksplit;
     if (g.ksplit > 1 && !clear_in_mid) HL_CHECK(hipMemsetAsync(ws->G + d.o_wd, 0, sizeof(float) * (size_t)clear_n, st));

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
     bf16_t* __restrict__ zbT, int L, double* __restrict__ klpart,
     const bf16_t* __restrict__ wd, int hdp, int h_d, const float* __restrict__ bd, bf16_t* __restrict__ u_out,
     bf16_t* __restrict__ uT_out, int B, const bf16_t* __restrict__ xin, int K1p, const bf16_t* __restrict__ w1,
-    unsigned long long* stamp) {
+    unsigned long long* stamp, int lin_e, int lin_d) {
+    // lin_e / lin_d (dims without hidden layers, reference HLVAE.py:128, 233: h_dim = []): stage 1 / stage 4 without their ReLU --
+    // the "hidden layer" is then the mean / log-var Linear itself ([Wmu; Wlv] = identity) / the latent (Wd = identity)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     HL_STAMP_T0(stamp);
     const int lda = hep + 8;                                     // bf16 elements
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
             for (int r = 0; r < 4; ++r) {
                 const int row = (lane >> 4) * 4 + r;
                 float x = acc[r] + bias;
-                x = (x > 0.f && col < h_e && row < MR && m0 + row < B) ? x : 0.f;
+                x = ((x > 0.f || lin_e) && col < h_e && row < MR && m0 + row < B) ? x : 0.f;
                 Ta[row * lda + col] = f2bf(x);
             }
         }
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float x = (c4 + k < h_e) ? vv[k] + b1[c4 + k] : 0.f;
-                vv[k] = x > 0.f ? x : 0.f;
+                vv[k] = (x > 0.f || lin_e) ? x : 0.f;
             }
         }
         uint2 pk;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_fwd_fused(
         for (int r = 0; r < 4; ++r) {
             const int row = (lane >> 4) * 4 + r;
             float x = acc[r] + bias;
-            x = (x > 0.f && col < h_d && row < MR && m0 + row < B) ? x : 0.f;
+            x = ((x > 0.f || lin_d) && col < h_d && row < MR && m0 + row < B) ? x : 0.f;
             o4[r] = x;
             Ct[row * cmax + col] = x;
         }
@@ -270,7 +272,9 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
     bf16_t* __restrict__ dmlT_out, float* __restrict__ gbmu, float* __restrict__ gblv,
     const bf16_t* __restrict__ wmlT, int hep, int h_e, const bf16_t* __restrict__ t, bf16_t* __restrict__ dtT_out,
     float* __restrict__ gb1, int B, bf16_t* __restrict__ dt_out, const bf16_t* __restrict__ dyin, int NYp,
-    const bf16_t* __restrict__ wyT, float* __restrict__ zero_ptr, long zero_n4, unsigned long long* stamp) {
+    const bf16_t* __restrict__ wyT, float* __restrict__ zero_ptr, long zero_n4, unsigned long long* stamp, int lin_e, int lin_d) {
+    // lin_e / lin_d: no ReLU gate on dT / dU (see the forward kernel); gbd / gbmu / gblv null: those biases belong to an identity
+    // layer that is not trained
     extern __shared__ __attribute__((aligned(16))) char smem[];
     HL_STAMP_T0(stamp);
     // (the weight-gradient GEMMs that follow on this stream add split-K slices with atomics: their output region is cleared
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = (lane >> 4) * 4 + r;
-                const float x = (col < h_d && bf2f(gate[r]) > 0.f) ? acc[r] : 0.f;
+                const float x = (col < h_d && (bf2f(gate[r]) > 0.f || lin_d)) ? acc[r] : 0.f;
                 Ua[row * lda + col] = f2bf(x);
             }
         }
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
             const bf16_t rr[4] = {(bf16_t)(rf.x & 0xffff), (bf16_t)(rf.x >> 16), (bf16_t)(rf.y & 0xffff), (bf16_t)(rf.y >> 16)};
             float* vv = &v.x;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) vv[k] = (c4 + k < h_d && bf2f(rr[k]) > 0.f) ? vv[k] : 0.f;
+            for (int k = 0; k < 4; ++k) vv[k] = (c4 + k < h_d && (bf2f(rr[k]) > 0.f || lin_d)) ? vv[k] : 0.f;
         }
         uint2 pk;
         pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
         float s = bf2f(a0) + bf2f(a1) + bf2f(a2) + bf2f(a3);                 // the MR / 4 lanes of a column are adjacent
         if (MR >= 8) s += __shfl_xor(s, 1, 64);
         if (MR == 16) s += __shfl_xor(s, 2, 64);
-        if ((idx % (MR / 4)) == 0 && c < h_d) atomicAdd(gbd + c, s);
+        if ((idx % (MR / 4)) == 0 && c < h_d && gbd != nullptr) atomicAdd(gbd + c, s);
     }
     // the ReLU gates (2-byte loads at row stride: four dependent-latency loads per lane and n-tile) are requested for the
     // wave's first TG n-tiles HERE, three stages ahead of their use (clock64() phase timing: this stage was 12.6 k of the kernel's 28 k clocks)
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < MID_ROWS; ++r) sum += Gs[r * 2 * LP + tid];
-            atomicAdd((tid < LP ? gbmu : gblv) + j, sum);
+            if (gbmu != nullptr) atomicAdd((tid < LP ? gbmu : gblv) + j, sum);
         }
     }
     // ---- stage 4: dT = dml * Wml * relu'(T)   (K = 2*LP, N = hep); only the transposed copy is needed
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(MID_THREADS) void k_mid_bwd_fused(
             } else if (col < h_e && row < B && (lane >> 4) * 4 < MR) {
                 tv = t[(size_t)row * hep + col];
             }
-            const bool on = col < h_e && row < B && (lane >> 4) * 4 < MR && bf2f(tv) > 0.f;
+            const bool on = col < h_e && row < B && (lane >> 4) * 4 < MR && (bf2f(tv) > 0.f || lin_e);
             o4[r] = on ? acc[r] : 0.f;
             s += o4[r];
         }
@@ -507,7 +511,7 @@ int hl_launch_mid_fwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
             ws->slab, ws->splitk_enc, Bp, d.hep, d.h_e, ws->P + d.o_b1, ws->t, ws->tT, ws->wmls, ws->P + d.o_bmu,       \
             ws->P + d.o_blv, sample ? eps : nullptr, ws->eps, sample ? ws->rng : nullptr, rng_off, ws->mu, ws->lv,     \
             ws->z, ws->zb, ws->zbT, d.L, ws->klpart, ws->wds, d.hd0p, d.h_d0, ws->P + d.o_bd, ws->u0, ws->u0T, B,       \
-            xin, d.K1p, ws->w1s, hl_stamp_slot(HL_ST_MID_FWD));                                                          \
+            xin, d.K1p, ws->w1s, hl_stamp_slot(HL_ST_MID_FWD), d.lin_e, d.lin_d);                                        \
     }
     // fewer than 128 sixteen-row workgroups (batches below 2048 rows) leave most CUs idle: eight rows per workgroup then
     // (four rows measured too: 0.1585 vs 0.1567 ms/step at 512 rows)
@@ -538,9 +542,9 @@ int hl_launch_mid_bwd_fused(const hlvae_plan* p, const hlvae_ws* ws, const float
             attr_max = smem;                                                                                           \
         }                                                                                                              \
         k_mid_bwd_fused<LPv, MRv><<<Bp / MRv, MID_THREADS, smem, s>>>(                                                    \
-            ws->slab, S, Bp, d.hd0p, d.h_d0, ws->u0, ws->duT, ws->G + d.o_bd, ws->wdTs, ws->eps, ws->lv,             \
-            ws->mu, g_mu, g_lv, kl_w, d.L, ws->dmlT, ws->G + d.o_bmu, ws->G + d.o_blv, ws->wmlTs, d.hep, d.h_e, ws->t, \
-            ws->dtT, ws->G + d.o_b1, B, (d.conv || d.n_xe > 0) ? ws->dt : nullptr, dyin, d.NYlp, ws->wyTs, zero_ptr, zero_n / 4, hl_stamp_slot(HL_ST_MID_BWD)); \
+            ws->slab, S, Bp, d.hd0p, d.h_d0, ws->u0, ws->duT, d.lin_d ? nullptr : ws->G + d.o_bd, ws->wdTs, ws->eps, ws->lv, \
+            ws->mu, g_mu, g_lv, kl_w, d.L, ws->dmlT, d.lin_e ? nullptr : ws->G + d.o_bmu, ws->G + d.o_blv, ws->wmlTs, d.hep, d.h_e, ws->t, \
+            ws->dtT, ws->G + d.o_b1, B, (d.conv || d.n_xe > 0) ? ws->dt : nullptr, dyin, d.NYlp, ws->wyTs, zero_ptr, zero_n / 4, hl_stamp_slot(HL_ST_MID_BWD), d.lin_e, d.lin_d); \
     }
     const int mr = Bp / MID_ROWS < 128 ? 8 : 16;
     if (d.Lp == 32) { if (mr == 8) HL_MB(32, 8) else HL_MB(32, 16) }

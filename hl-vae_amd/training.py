@@ -174,7 +174,9 @@ class ELBOTrainer:
         self.model, self.P_total, self.kl, self.gp, self.dp, self.metrics = model, P_total, kl, gp, dp, metrics
         model._max_batch = max(model._max_batch, max_batch)
         model._ensure_device_state(max_batch)
-        frozen = [p for p in model._order if not p.requires_grad and p is not model._log_vy_real and p is not model._log_vy_pos]
+        hidden_ids = {id(t) for t in tuple(getattr(model, "_id_enc", ())) + tuple(getattr(model, "_id_dec", ()))}   # identity layers of h_dim = []
+        frozen = [p for p in model._order if not p.requires_grad and p is not model._log_vy_real and p is not model._log_vy_pos
+                  and id(p) not in hidden_ids]
         if frozen or (model._log_vy_real is not None and model._log_vy_real.requires_grad != model._log_vy_pos.requires_grad):
             raise ValueError("the fused optimiser step freezes _log_vy_real / _log_vy_pos together (vy_fixed) and trains every other "
                              "parameter, as the reference does (HLVAE.py:209-216)")

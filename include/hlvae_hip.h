@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLVAE_ABI_VERSION 34
+#define HLVAE_ABI_VERSION 35
 #define HLVAE_STAT_CHUNKS 16
 /* accumulators per variable in ws->hgpart for the largest head instance: (y_dim + 1) (K - 1) + y_dim with K <= 16, y_dim = 5 */
 #define HLVAE_HEAD_ACC 95
@@ -102,6 +102,11 @@ typedef struct {
     hlvae_layer xe[HLVAE_MAX_EXTRA];   /* VAE_encoder_common_layers.{0, 2, ..}: X -> .. (all but the last Linear)         */
     hlvae_layer xd[HLVAE_MAX_EXTRA];   /* d_layers.{2, 4, ..}: h_d0 -> .. -> h_d                                          */
     int64_t o_xw;                /* start of the extra layers' weights in the arena (they sit between W1 and Wy); o_wy when none */
+    /* dims without hidden layers (reference HLVAE.py:128, 233: h_dim = [] / 0).  lin_e: "W1" [h_e = 2L][X] IS [mean_layer.weight;
+     * log_var_layer.weight] (b1 the two biases), its activation is linear, and [Wmu; Wlv] / bmu / blv hold an identity / zeros
+     * that the library never trains (their gradients are not formed).  lin_d: "Wd" [h_d0 = L][L] is an identity, bd zeros, the
+     * activation linear: y_layer reads the latent.  The fused-optimiser step is not used with either. */
+    int32_t lin_e, lin_d;
 } hlvae_dims;
 
 void hlvae_dims_fill(hlvae_dims* d);   /* fills the derived fields from D,X,y_dim,h_e,h_d,L,n_real,n_pos */

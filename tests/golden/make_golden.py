@@ -165,6 +165,25 @@ def case_mix_logvar_deep():
         print(name, "loss", out["loss"])
 
 
+def case_mix_no_hidden():
+    """dims without hidden layers (HLVAE.py:128, 233: h_dim = [] -- mean / log-var heads on the input, y_layer on the latent): one side,
+    the other, both.  Same data, seeds and file format as case_mix_logvar_deep."""
+    src = synthetic.make_tabular(n_rows=24, T=6, seed=7, spec=MIX_SPEC)
+    for name, hid_e, hid_d in (("mix_nohid_e", [], [16]), ("mix_nohid_d", [16], []), ("mix_nohid", [], [])):
+        dims = [src.cov_dim_ext, hid_e, 4, hid_d, 5]
+        info = src.types_info
+        state = orc.init_state(dims, info, src.n_variables, seed=17, std=0.2)
+        out, grads = run_reference_model(src, np.arange(24), dims, state, seed=13, nll_scale=3.0)
+        for k, g in grads.items():
+            out["grad__" + k] = np64(g)
+        for k, v in state.items():
+            out["state__" + k] = np64(v)
+        out["hid_e"], out["hid_d"], out["logvar_network"] = np.array(hid_e, dtype=np.int64), np.array(hid_d, dtype=np.int64), np.array([0])
+        out["param_indexes"] = np.asarray(info["param_indexes"])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "loss", out["loss"])
+
+
 def case_d4():
     src = synthetic.make_d4(n_subjects=2, T=4, seed=5)
     dims = [src.cov_dim_ext, [32], 8, [32], 5]
@@ -478,3 +497,4 @@ if __name__ == "__main__":
     case_mix_logvar_deep()
     case_d4_conv_logvar()
     case_d4_conv_deep()
+    case_mix_no_hidden()

@@ -501,7 +501,7 @@ def test_vy_fixed_parameters_stay_put_under_the_fused_optimiser():
     assert float(model._grad_arena[int(d.frozen_lo):int(d.frozen_hi)].abs().max()) == 0.0      # cleared for the next step's atomics
 
 
-@pytest.mark.parametrize("name", ["mix_logvar", "mix_deep", "mix_logvar_deep"])
+@pytest.mark.parametrize("name", ["mix_logvar", "mix_deep", "mix_logvar_deep", "mix_nohid_e", "mix_nohid_d", "mix_nohid"])
 def test_constructor_modes_against_reference_fixture(golden_dir, name):
     """The two constructor modes the shipped configuration does not use, against outputs of the reference itself
     (tests/golden/make_golden.py: case_mix_logvar_deep): logvar_network=True -- the variance of every real / pos ENTRY comes
@@ -561,6 +561,18 @@ def test_constructor_modes_against_reference_fixture(golden_dir, name):
         tr.step(data, mask, 4)
         nll.append(float(tr.scalars()["nll_sum"]))
     assert np.isfinite(nll).all() and nll[-1] < nll[0], nll
+    # dims without hidden layers: the kernels' identity "layers" are not parameters and must come out of training untouched
+    torch.cuda.synchronize()
+    L = int(dims[2])
+    eye = torch.eye(L, device=dev)
+    if model._id_enc:
+        wmu, wlv, bmu, blv = model._id_enc
+        assert torch.equal(wmu, torch.cat([eye, torch.zeros_like(eye)], 1)) and torch.equal(wlv, torch.cat([torch.zeros_like(eye), eye], 1))
+        assert float(bmu.abs().max()) == 0.0 and float(blv.abs().max()) == 0.0
+    if model._id_dec:
+        assert torch.equal(model._id_dec[0], eye) and float(model._id_dec[1].abs().max()) == 0.0
+    moved = {k: not torch.equal(v.detach().cpu().double(), state[k].double()) for k, v in model.state_dict().items() if v.numel()}
+    assert all(moved[k] for k in ("mean_layer.0.weight", "log_var_layer.0.weight", "mean_layer.0.bias", "y_layer.0.weight")), moved
 
 
 @pytest.mark.parametrize("workload", ["d4", "tabular"])

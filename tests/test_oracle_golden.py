@@ -242,7 +242,7 @@ def test_gp_predict(golden_dir):
     assert rel_err(Zp.numpy(), g["Z_pred"]) < 1e-9
 
 
-@pytest.mark.parametrize("name", ["mix_logvar", "mix_deep", "mix_logvar_deep"])
+@pytest.mark.parametrize("name", ["mix_logvar", "mix_deep", "mix_logvar_deep", "mix_nohid_e", "mix_nohid_d", "mix_nohid"])
 def test_constructor_modes(golden_dir, name):
     """logvar_network=True (HLVAE.py:25-51; loglik.py:45-47, 105) and two hidden layers per side (HLVAE.py:113, 125-137, 232-242):
     forward, every gradient, get_test_samples and the per-step metrics against the reference's own outputs."""
