@@ -61,7 +61,9 @@ def _adam_reference(st):
     return names, [st[k] for k in names]
 
 
-@pytest.mark.parametrize("B,hid_e,hid_d", [(1024, [500], [500]), (4096, [500], [500]), (1024, [500, 260], [132, 260, 500])])
+@pytest.mark.parametrize("B,hid_e,hid_d", [(1024, [500], [500]), (4096, [500], [500]), (1024, [500, 260], [132, 260, 500]),
+                                           (1024, [], []), (512, [], [500]), (512, [500], [])],
+                         ids=["1024", "4096", "1024-deep", "1024-nohid", "512-nohid_e", "512-nohid_d"])
 def test_d4_large_batch_against_oracle(B, hid_e, hid_d):
     """BASELINE configs[2] (global batch 4096) and configs[4] (batch 1024) on the D4 layout, MLP [5184,[500],32,[500],5]; and the
     same layout with deeper trunks at model scale (two encoder layers, three decoder layers, widths that need padding:
@@ -99,7 +101,8 @@ def test_d4_large_batch_against_oracle(B, hid_e, hid_d):
     ref_loss.backward()
     elbo, elbo_ref = float(lpx.double().sum()), float(ref["log_p_x"].sum())
     rel = abs(elbo - elbo_ref) / abs(elbo_ref)
-    key = f"d4_b{B}" + ("" if len(hid_e) + len(hid_d) == 2 else "_deep")
+    key = f"d4_b{B}" + ("_nohid" + "e" * (not hid_e) + "d" * (not hid_d) if not (hid_e and hid_d) else
+                         "" if len(hid_e) + len(hid_d) == 2 else "_deep")
     _report(key, elbo_rel=rel, loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
             mu=max_abs_err(mu.cpu(), ref["mu"].detach()), lv=max_abs_err(lv.cpu(), ref["log_var"].detach()),
             lpx_max=max_abs_err(lpx.cpu(), ref["log_p_x"].detach()))
@@ -314,8 +317,8 @@ def test_gp_prior_hip_against_reference_fixture(golden_dir):
     assert rel_err(gp.m, g["m_new"]) < 1e-9 and rel_err(gp.H, g["H_new"]) < 1e-10      # measured 7e-12 / 5e-16
 
 
-@pytest.mark.parametrize("B,hid_e,hid_d", [(512, [500], [500]), (1024, [500], [500]), (512, [500, 132], [260, 500])],
-                         ids=["512", "1024", "512-deep"])
+@pytest.mark.parametrize("B,hid_e,hid_d", [(512, [500], [500]), (1024, [500], [500]), (512, [500, 132], [260, 500]), (512, [], [])],
+                         ids=["512", "1024", "512-deep", "512-nohid"])
 def test_conv_backward_against_oracle(B, hid_e, hid_d):
     """convolutional model (what config/hlvae_config_file.txt:51 selects) at 512 and 1024 rows, hidden 500, latent 32 -- and
     (round 3) with two hidden layers either side of the convolutional stages: ELBO, loss and EVERY gradient tensor against
@@ -348,7 +351,7 @@ def test_conv_backward_against_oracle(B, hid_e, hid_d):
     ref_loss = scale * om.loss_function(ref["log_p_x"]).sum() + orc.standard_normal_kl(ref["mu"], ref["log_var"])
     ref_loss.backward()
     elbo, elbo_ref = float(lpx.double().sum()), float(ref["log_p_x"].sum())
-    key = f"conv_b{B}" + ("_deep" if len(hid_e) > 1 else "")
+    key = f"conv_b{B}" + ("_deep" if len(hid_e) > 1 else "_nohid" if not hid_e else "")
     _report(key, elbo_rel=abs(elbo - elbo_ref) / abs(elbo_ref), loss_rel=abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)))
     assert abs(elbo - elbo_ref) <= ELBO_RTOL * abs(elbo_ref), (elbo, elbo_ref)
     assert abs(float(loss) - float(ref_loss)) <= ELBO_RTOL * abs(float(ref_loss))
@@ -422,7 +425,8 @@ def test_conv_logvar_network_with_deeper_trunks_against_oracle():
 
 
 @pytest.mark.parametrize("hid_e,hid_d,conv", [([500], [500], False), ([500, 132], [260, 500], False), ([500], [500], True),
-                                              ([500, 132], [260, 500], True)], ids=["mlp", "deep", "conv", "conv-deep"])
+                                              ([500, 132], [260, 500], True), ([], [], False), ([], [], True)],
+                         ids=["mlp", "deep", "conv", "conv-deep", "nohid", "conv-nohid"])
 def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d, conv):
     """The data-parallel optimiser path at world size 1 (flat Adam on the whole dense region -> bf16 copy -> shadows rebuilt
     from it; hl-vae_amd/parallel.py with the collectives skipped) against the fused tile Adam of the single-process step: D4,
@@ -469,7 +473,7 @@ def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d, conv):
     worst = sorted(per.items(), key=lambda kv: -kv[1])[:6]
     flips = {k: float((sh_a[k] != sh_b[k]).float().mean()) for k in sh_a}
     print("sharded-vs-fused worst tensors", worst, "shadow flips", flips)
-    _report("sharded_vs_fused_" + ("conv" if conv else "mlp") + ("_deep" if len(hid_e) > 1 else ""), params=rel_err(P_b, P_a),
+    _report("sharded_vs_fused_" + ("conv" if conv else "mlp") + ("_deep" if len(hid_e) > 1 else "_nohid" if not hid_e else ""), params=rel_err(P_b, P_a),
             nll=rel_err(np.array(nll_b), np.array(nll_a)), shadow_flips=max(float((sh_a[k] != sh_b[k]).float().mean()) for k in sh_a))
     assert rel_err(P_b, P_a) < p_tol
     for k in sh_a:
