@@ -477,7 +477,8 @@ def test_sharded_optimizer_path_matches_fused_path(hid_e, hid_d, conv):
             nll=rel_err(np.array(nll_b), np.array(nll_a)), shadow_flips=max(float((sh_a[k] != sh_b[k]).float().mean()) for k in sh_a))
     assert rel_err(P_b, P_a) < p_tol
     for k in sh_a:
-        assert float((sh_a[k].float() - sh_b[k].float()).abs().max()) <= 2.0 ** -8 * float(sh_a[k].float().abs().max()), k
+        # (at most ONE bf16 ulp: 2^-7 of the element at the top of its binade)
+        assert float((sh_a[k].float() - sh_b[k].float()).abs().max()) <= 2.0 ** -7 * float(sh_a[k].float().abs().max()), k
         assert float((sh_a[k] != sh_b[k]).float().mean()) < flip_tol, k       # a last-bit difference of a master may flip a rounding
 
 
