@@ -445,7 +445,8 @@ int hlvae_decoder_fwd(const hlvae_plan* p, const hlvae_ws* ws, const float* g_lo
     if (trunk) {   // U = relu(z Wd^T + bd) from ws->zb (HLVAE.py:336): only when z was set by the caller (decode(z));
                    // after hlvae_encoder_fwd the trunk is already in ws->u
         if ((rc = hl_check_extra(d, ws))) return rc;
-        if ((rc = hl_launch_gemm_act(0, ws->zb, d.Lp, ws->wds, d.Lp, Bp, d.hd0p, d.Lp, ws->P + d.o_bd, d.h_d0, nullptr, ws->u0,
+        // (no decoder hidden layer: the "trunk" is the identity on the latent -- bias-only epilogue)
+        if ((rc = hl_launch_gemm_act(d.lin_d ? 2 : 0, ws->zb, d.Lp, ws->wds, d.Lp, Bp, d.hd0p, d.Lp, ws->P + d.o_bd, d.h_d0, nullptr, ws->u0,
                                      d.hd0p, ws->u0T, Bp, B, nullptr, "dec1_relu", st))) return rc;
         if ((rc = hl_extra_decoder_fwd(p, ws, B, Bp, st))) return rc;
     }

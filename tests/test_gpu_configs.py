@@ -546,6 +546,10 @@ def test_constructor_modes_against_reference_fixture(golden_dir, name):
     loss.backward()
     torch.cuda.synchronize()
     assert abs(float(loss) - float(g["loss"][0])) <= ELBO_RTOL * abs(float(g["loss"][0]))
+    # row T (HLVAE.py:455-475): deterministic encode, decode(mean_qz) -- the decoder entered at the latent (its own trunk launch)
+    qs, qp, ps, pp, lpt, lpmt = model.get_test_samples(data, mask, None)
+    assert max_abs_err(qp["z"][0].cpu(), g["test_mu"]) < 2e-2
+    assert np.all(np.abs(lpt.detach().double().cpu().numpy() - g["test_log_p_x"]) <= 3e-2 + 2e-2 * np.abs(g["test_log_p_x"]))
     sd = dict(model.named_parameters())
     errs = {}
     for k in g.files:
