@@ -976,36 +976,20 @@ __device__ __forceinline__ void conv_rep_grad(int bx, int by, int ny, const floa
 // which on MI355X serialises in the fabric when 256 workgroups on 8 XCDs hit the same address
 __device__ __forceinline__ void conv_wgrad_reduce(int bx, int by, const float* __restrict__ part, int nrows, long n,
                                                   float* __restrict__ G) {
-    // (ceil(n / 256), 8) workgroups: workgroup (x, y) sums rows y, y + 8, ... of its 256 columns, then 8-way atomics.
-    // A wave owns the 256 columns as 64 float4 (n % 4 == 0, rows 16-byte aligned: plan_create), the workgroup's four waves take
-    // every fourth of its rows and meet in LDS: 4 x 16 B per lane in flight instead of 4 x 4 B (17.6 -> see DESIGN 4.3)
-    __shared__ float4 red[3][64];
-    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const long i = (long)bx * 256 + 4 * lane;
-    const bool in = i < n;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-    if (in) {
-        int r = by + 8 * sub;
-        for (; r + 96 < nrows; r += 128) {
-            const float4 a = *reinterpret_cast<const float4*>(part + (size_t)r * n + i);
-            const float4 b = *reinterpret_cast<const float4*>(part + (size_t)(r + 32) * n + i);
-            const float4 c = *reinterpret_cast<const float4*>(part + (size_t)(r + 64) * n + i);
-            const float4 d = *reinterpret_cast<const float4*>(part + (size_t)(r + 96) * n + i);
-            add(s0, a); add(s1, b); add(s2, c); add(s3, d);
-        }
-        for (; r < nrows; r += 32) add(s0, *reinterpret_cast<const float4*>(part + (size_t)r * n + i));
-        add(s0, s1); add(s2, s3); add(s0, s2);
+    // (ceil(n / 256), 8) workgroups: workgroup (x, y) sums rows y, y + 8, ... of its 256 columns, then 8-way atomics
+    const long i = (long)bx * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = by;
+    for (; r + 24 < nrows; r += 32) {
+        s0 += part[(size_t)r * n + i];
+        s1 += part[(size_t)(r + 8) * n + i];
+        s2 += part[(size_t)(r + 16) * n + i];
+        s3 += part[(size_t)(r + 24) * n + i];
     }
-    if (sub > 0) red[sub - 1][lane] = s0;
-    __syncthreads();
-    if (sub == 0 && in) {
-        add(s0, red[0][lane]); add(s0, red[1][lane]); add(s0, red[2][lane]);
-        if (s0.x != 0.f) atomicAdd(G + i, s0.x);
-        if (s0.y != 0.f) atomicAdd(G + i + 1, s0.y);
-        if (s0.z != 0.f) atomicAdd(G + i + 2, s0.z);
-        if (s0.w != 0.f) atomicAdd(G + i + 3, s0.w);
-    }
+    for (; r < nrows; r += 8) s0 += part[(size_t)r * n + i];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (v != 0.f) atomicAdd(G + i, v);
 }
 
 // the two independent tails of the convolutional backward pass in ONE launch (as launches of their own they are two
