@@ -721,17 +721,20 @@ static int hl_backward_impl(const hlvae_plan* p, const hlvae_ws* ws, const float
         HL_CHECK(hipEventRecord(p->ev[3], s0));
         // (large batches, metrics behind side 0's chain and the input stage alone on side 1: its 16-workgroup statistics kernel
         //  starves beside the streaming launches -- 110 us instead of 12 -- and the step does not move, 0.490 vs 0.483 ms)
-        if ((p->pend_flags & HL_PEND_DEFERRED) && p->defer_join == 2) {
-            // the caller does not wait for anything else at the end of this step (GP prior with a deferred state update: its chains
-            // are the step's critical path and share the hardware queues with side 1 -- the next batch's input stage sat 250 us
-            // behind them, and the next step's encoder behind it): metrics and input stage in line, beside y_layer's launch
-            if ((rc = hl_flush_deferred(p, st, true, HL_PEND_DEFERRED, false, true))) return rc;
+        const bool inline_deferred = (p->pend_flags & HL_PEND_DEFERRED) && p->defer_join == 2;
+        if (inline_deferred) {
         } else if (p->pend_flags & HL_PEND_DEFERRED) {
             HL_CHECK(hipStreamWaitEvent(s1, p->ev[0], 0));   // forked at the head kernel like side 0: with the fork behind
             // dU_splitk the graph executor put both side chains on ONE hardware queue, y_layer's launch last (0.166 vs 0.144 ms/step)
             if ((rc = hl_flush_deferred(p, s1, true, HL_PEND_DEFERRED, false, small_batch))) return rc;
         }
         HL_CHECK(hipStreamWaitEvent(st, p->ev[3], 0));
+        // the caller does not wait for anything else at the end of this step (GP prior with a deferred state update: its chains are
+        // the step's critical path and share the hardware queues with side 1 -- the next batch's input stage sat 250 us behind
+        // them, and the next step's encoder behind it): metrics and input stage in line, BEHIND both streaming launches (beside
+        // y_layer's the pack kernel took 93 us instead of 24)
+        if (inline_deferred)
+            if ((rc = hl_flush_deferred(p, st, true, HL_PEND_DEFERRED, false, true))) return rc;
         return p->defer_join ? 0 : hlvae_join(p, s);
     }
     // d W1 below is the LAST encoder Linear's gradient; its input is Xn or the output of the layers before it
