@@ -480,7 +480,9 @@ class GPPriorHIP:
                 x = labels if rows is None else labels.index_select(0, rows.long())
                 x, Kxz = x.contiguous(), None
             idx = groups if groups is not None else self._group(x)
-            side = None if (self._serial or self._defer_capture) else self._streams(dev)[1]
+            # (not under data parallelism: replaying a captured chain with the RCCL all-reduce of the sums on chain A's stream and this
+            #  extra fork segfaulted in hipGraphLaunch on ROCm 7.2 -- tests/test_gpu_parity.py, single-rank RCCL case)
+            side = None if (self._serial or self._defer_capture or self.dp is not None) else self._streams(dev)[1]
             st_ = self._prepare_state(x, idx.shape[0], idx.shape[1], x.shape[0], dev, Kxz=Kxz, side=side)
         self._prep = (x, idx) + st_
         return x
