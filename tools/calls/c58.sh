@@ -1,10 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_configs.py tests/test_trajectory_gpu.py tests/test_gpu_parity.py -x -q -m gpu -k "gp or config5 or GP or traj" > gpurun_out/c58_tests.log 2>&1
-echo "exit $?" >> gpurun_out/c58_tests.log
-tail -3 gpurun_out/c58_tests.log
-grep -q "exit 0" gpurun_out/c58_tests.log || exit 1
-run() {
   env "$@" timeout -k 10 300 python bench.py --workload d4 --rows 50000 --batch 1024 --kl gp --no-cpu-baseline --no-also --no-in-step > gpurun_out/c58_out.log 2> gpurun_out/c58_err.log
   echo "$* rc $? $(python -c "import json; d=json.loads(open('gpurun_out/c58_out.log').read().strip().splitlines()[-1]); print(round(d['ms_per_step'],4), d['config'].get('final_nll_sum'))" 2>/dev/null)"
 }
