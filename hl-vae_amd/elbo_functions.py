@@ -334,8 +334,6 @@ class GPPriorHIP:
         # fork 0.610).  Inside a capture with the deferred state update only the second form survives hipStreamEndCapture.
         self._fork_direct = _os.environ.get("HL_GP_FORK_DIRECT", "1") != "0"
         self._defer_capture = False
-        self._split_prep = _os.environ.get("HL_GP_SPLIT_PREP", "1") != "0"  # H iK, iK - iK H iK on chain C's stream (prepare)
-        self._prep_split = False
         self._a_first = _os.environ.get("HL_GP_A_FIRST", "0") != "0"       # chain A queued before chain C (kl_and_grads)
         self._early = _os.environ.get("HL_GP_EARLY", "1") != "0"          # per-subject kernel forked behind the ENCODER (kl_and_grads(after=...))
         self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
@@ -480,10 +478,7 @@ class GPPriorHIP:
                 x = labels if rows is None else labels.index_select(0, rows.long())
                 x, Kxz = x.contiguous(), None
             idx = groups if groups is not None else self._group(x)
-            # (not under data parallelism: replaying a captured chain with the RCCL all-reduce of the sums on chain A's stream and this
-            #  extra fork segfaulted in hipGraphLaunch on ROCm 7.2 -- tests/test_gpu_parity.py, single-rank RCCL case)
-            side = None if (self._serial or self._defer_capture or self.dp is not None) else self._streams(dev)[1]
-            st_ = self._prepare_state(x, idx.shape[0], idx.shape[1], x.shape[0], dev, Kxz=Kxz, side=side)
+            st_ = self._prepare_state(x, idx.shape[0], idx.shape[1], x.shape[0], dev, Kxz=Kxz)
         self._prep = (x, idx) + st_
         return x
 
@@ -523,7 +518,7 @@ class GPPriorHIP:
         self._transform()
         self.compute_ahead(labels, rows)
 
-    def _prepare_state(self, x, S, T, B, dev, Kxz=None, side=None):
+    def _prepare_state(self, x, S, T, B, dev, Kxz=None):
         """the state-only launches (current stream); returns (buf, hyp, Kxz, iKm, HiK, N1).  Kxz given: computed ahead, behind the
         transform of the last optimiser step (the planes in self._hyp are current)"""
         L, M = self.L, self.M
@@ -543,19 +538,11 @@ class GPPriorHIP:
             self._spd_inv(self.H, self._iHb, self._ldH)
         iK = self._iK
         iKm = self._bmv(iK, self.m, mm["iKm"])                               # [L,M,1]
+        HiK = self._bmm_into(self.H, iK, mm["HiK"])
+        N1 = self._bmm_into(iK, HiK, mm["N1"], D=iK, alpha=-1.0, beta=1.0)   # iK - iK H iK
         if self._fuse_sums:
             LMM, LM = L * M * M, L * M
             self._xchg[:LMM + 2 * LM].zero_()                                # W (hlvae_gp_gemm_acc), P1, u (the per-subject kernel) accumulate
-        # the per-subject kernel needs iK m and the cleared accumulators; H iK and iK - iK H iK are first read by the two chains BEHIND
-        # it.  side (prepare(): chain C's stream, idle here): the two M x M products run there, beside the per-subject kernel --
-        # 33 us off the state update -> prepare -> per-subject kernel chain, the step's critical path (late round-3 trace)
-        self._prep_split = side is not None and self._split_prep
-        ctx = torch.cuda.stream(side) if self._prep_split else contextlib.nullcontext()
-        if self._prep_split:
-            side.wait_stream(torch.cuda.current_stream(dev))
-        with ctx:
-            HiK = self._bmm_into(self.H, iK, mm["HiK"])
-            N1 = self._bmm_into(iK, HiK, mm["N1"], D=iK, alpha=-1.0, beta=1.0)   # iK - iK H iK
         return buf, hyp, Kxz, iKm, HiK, N1
 
     def kl_and_grads(self, mu, log_v, train_x, P_total, P_batch, groups=None, join=True, after=None):
@@ -649,9 +636,6 @@ class GPPriorHIP:
         else:
             sA.wait_stream(main)
             sC.wait_stream(main)
-        if self._prep_split:         # H iK / iK - iK H iK were queued on chain C's stream by prepare(): chain A reads H iK
-            sA.wait_stream(sC)
-            self._prep_split = False
         world = 1 if self.dp is None else self.dp.world
         gprm, gz = self.prm.grad, self.zt_list.grad                          # zero here: the Adam kernel cleans them
         balance = self._balance if (self._chain and M % 4 == 0) else 0
