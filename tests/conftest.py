@@ -18,3 +18,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_state(request):
+    """GPU tests build models, trainers and captured HIP graphs whose buffers (graph-private pools included) outlive the test until
+    the collector runs.  Eighty-odd tests in one process accumulated enough of them that replaying a captured chain with RCCL nodes
+    segfaulted inside hipGraphLaunch (ROCm 7.2; order-dependent: any ten tests fewer in front of it and it passed).  Collect and
+    hand the cached blocks back after every GPU test."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+        gc.collect()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+        except Exception:
+            pass
