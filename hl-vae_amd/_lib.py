@@ -127,7 +127,6 @@ _SIGS = {
     "hlvae_gp_gemm_acc": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, C.c_int64, _vp, C.c_int, C.c_int64, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_double, _vp]),
     "hlvae_gp_bmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
-    "hlvae_gp_bmv_clear": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp, C.c_int64, _vp]),
     "hlvae_gp_resid": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "hlvae_gp_gemv_t_f32": (C.c_int, [_vp, _vp, C.c_long, C.c_long, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "hlvae_gp_natgrad": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

@@ -1125,11 +1125,7 @@ __global__ __launch_bounds__(256) void k_gp_gemm(const double* __restrict__ A, i
 // out[l] = alpha A[l] x[l] + beta y[l]      (A: [batch][N][N] row-major, x, y, out: [batch][N]; y may be null or alias out)
 // eight lanes per row, one workgroup per matrix: the matrix-vector products of the natural gradient (iK m, Bm m, iK P1, H tmp)
 __global__ __launch_bounds__(1024) void k_gp_bmv(const double* __restrict__ A, const double* __restrict__ x, const double* y,
-                                                 double* out, int N, double alpha, double beta, double* zero_ptr, long zero_n2) {
-    // (optional: clears zero_n2 pairs of doubles, 16-byte aligned, on the way -- the accumulators of the GP step, whose fill kernel
-    //  was a launch of its own on the prepare chain)
-    for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < zero_n2; i += (long)gridDim.x * 1024)
-        reinterpret_cast<double2*>(zero_ptr)[i] = make_double2(0.0, 0.0);
+                                                 double* out, int N, double alpha, double beta) {
     const int l = blockIdx.x, sub = threadIdx.x & 7;
     const double* Al = A + (size_t)l * N * N;
     const double* xl = x + (size_t)l * N;
@@ -2017,18 +2013,7 @@ int hlvae_gp_bmv(const double* A, const double* x, const double* y, double* out,
                  hlvae_stream s) {
     HL_REQUIRE(A && x && out && N >= 1 && N <= GP_MMAX && batch >= 1, HLVAE_EINVAL, "gp_bmv: N=%d batch=%d", N, batch);
     HL_PROF("gp_bmv", (hipStream_t)s);
-    k_gp_bmv<<<batch, 1024, 0, (hipStream_t)s>>>(A, x, y, out, N, alpha, beta, nullptr, 0);
-    HL_LAUNCH_CHECK();
-    return 0;
-}
-
-// hlvae_gp_bmv that also clears n doubles at zero_ptr (16-byte aligned, n even; disjoint from the operands)
-int hlvae_gp_bmv_clear(const double* A, const double* x, const double* y, double* out, int N, int batch, double alpha, double beta,
-                       double* zero_ptr, int64_t n, hlvae_stream s) {
-    HL_REQUIRE(A && x && out && N >= 1 && N <= GP_MMAX && batch >= 1, HLVAE_EINVAL, "gp_bmv_clear: N=%d batch=%d", N, batch);
-    HL_REQUIRE(zero_ptr && n >= 0 && n % 2 == 0 && ((uintptr_t)zero_ptr & 15) == 0, HLVAE_ESHAPE, "gp_bmv_clear: the range to clear must be 16-byte aligned, even");
-    HL_PROF("gp_bmv", (hipStream_t)s);
-    k_gp_bmv<<<batch, 1024, 0, (hipStream_t)s>>>(A, x, y, out, N, alpha, beta, zero_ptr, (long)(n / 2));
+    k_gp_bmv<<<batch, 1024, 0, (hipStream_t)s>>>(A, x, y, out, N, alpha, beta);
     HL_LAUNCH_CHECK();
     return 0;
 }

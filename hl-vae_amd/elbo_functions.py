@@ -334,7 +334,6 @@ class GPPriorHIP:
         # fork 0.610).  Inside a capture with the deferred state update only the second form survives hipStreamEndCapture.
         self._fork_direct = _os.environ.get("HL_GP_FORK_DIRECT", "1") != "0"
         self._defer_capture = False
-        self._fold_clear = _os.environ.get("HL_GP_FOLD_CLEAR", "1") != "0"   # accumulators cleared inside the iK m launch (prepare)
         self._a_first = _os.environ.get("HL_GP_A_FIRST", "0") != "0"       # chain A queued before chain C (kl_and_grads)
         self._early = _os.environ.get("HL_GP_EARLY", "1") != "0"          # per-subject kernel forked behind the ENCODER (kl_and_grads(after=...))
         self._chain = int(_os.environ.get("HL_GP_CHAIN", "2"))            # the M x M algebra behind W: 0 separate launches, 1 k_gp_chain, 2 k_gp_chain_rb
@@ -538,17 +537,10 @@ class GPPriorHIP:
             self._spd_inv(self._KH[:L], self._iK, self._ldK)
             self._spd_inv(self.H, self._iHb, self._ldH)
         iK = self._iK
-        fold_clear = self._fuse_sums and self._fold_clear and (L * M * M + 2 * L * M) % 2 == 0
-        if fold_clear:      # iK m, and the cleared accumulators W / P1 / u on the way (no fill launch on this chain)
-            LMM, LM = L * M * M, L * M
-            _lib.check(_lib.load().hlvae_gp_bmv_clear(_lib.ptr(iK), _lib.ptr(self.m), None, _lib.ptr(mm["iKm"]), M, L, _C.c_double(1.0),
-                                                      _C.c_double(0.0), _lib.ptr(self._xchg), LMM + 2 * LM, self._stream()), "gp_bmv_clear")
-            iKm = mm["iKm"]
-        else:
-            iKm = self._bmv(iK, self.m, mm["iKm"])                           # [L,M,1]
+        iKm = self._bmv(iK, self.m, mm["iKm"])                               # [L,M,1]
         HiK = self._bmm_into(self.H, iK, mm["HiK"])
         N1 = self._bmm_into(iK, HiK, mm["N1"], D=iK, alpha=-1.0, beta=1.0)   # iK - iK H iK
-        if self._fuse_sums and not fold_clear:
+        if self._fuse_sums:
             LMM, LM = L * M * M, L * M
             self._xchg[:LMM + 2 * LM].zero_()                                # W (hlvae_gp_gemm_acc), P1, u (the per-subject kernel) accumulate
         return buf, hyp, Kxz, iKm, HiK, N1

@@ -406,10 +406,6 @@ int hlvae_gp_gemm_acc(const double* A, int lda, int64_t strideA, int transA, con
 /* out[l] = alpha A[l] x[l] + beta y[l]  (A [batch][N][N] row-major; x, y, out [batch][N]; y may be NULL or alias out) */
 int hlvae_gp_bmv(const double* A, const double* x, const double* y, double* out, int N, int batch, double alpha, double beta,
                  hlvae_stream s);
-/* hlvae_gp_bmv that also clears n doubles at zero_ptr (16-byte aligned, n even, disjoint from the operands): the accumulators of the
- * GP step (W, P1, u) without a fill launch of their own on the prepare chain */
-int hlvae_gp_bmv_clear(const double* A, const double* x, const double* y, double* out, int N, int batch, double alpha, double beta,
-                       double* zero_ptr, int64_t n, hlvae_stream s);
 /* resid[l][b] = sum_m Kxz[l][b][m] w[l][m] - mu[b][l]  (A_part of elbo_functions.py:230; mu fp32 [B][L] = the VAE's encoder means) */
 int hlvae_gp_resid(const double* Kxz, const double* w, const float* mu, int L, int B, int M, double* out, hlvae_stream s);
 /* hlvae_gp_gemv_t with an fp32 vector operand (V^T mu straight from the VAE's fp32 means) */
