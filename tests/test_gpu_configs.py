@@ -742,17 +742,18 @@ def test_fused_optimiser_epilogue_matches_separate_launches():
 
 
 @pytest.mark.gpu
-def test_gp_captured_chain_matches_eager_steps():
+@pytest.mark.parametrize("hid", [[500], []], ids=["hidden500", "nohid"])
+def test_gp_captured_chain_matches_eager_steps(hid):
     """GP prior + fused optimiser inside a captured chain of two pipelined steps (y_layer's shadows double-buffered, the prior's
     chains on streams of their own) against the same six steps launched eagerly: VAE parameters, GP hyper-parameters, inducing
-    points, m and H."""
+    points, m and H.  Also for a model without hidden layers (the general optimiser path inside the captured chain)."""
     from hlvae_amd.HLVAE import HLVAE
     from hlvae_amd.training import ELBOTrainer
     from hlvae_amd.datafeed import CompactDataset, subject_index
     from hlvae_amd.elbo_functions import GPPriorHIP
     dev = _dev()
     src = synthetic.make_d4(n_subjects=40, T=20, seed=21)
-    dims = [src.cov_dim_ext, [500], 32, [500], 5]
+    dims = [src.cov_dim_ext, hid, 32, hid, 5]
     ds = CompactDataset.from_expanded(src.data, src.mask, src.labels, src.types_info, src.id_covariate).to(dev)
     win = [np.arange(0, 256), np.arange(300, 556)]
     R = [torch.tensor(w.astype(np.int32), device=dev) for w in win]
@@ -781,7 +782,7 @@ def test_gp_captured_chain_matches_eager_steps():
     a, b = run(False), run(True)
     errs = {k: rel_err(a[k], b[k]) for k in ("arena", "theta", "m", "H")}
     errs["kld"] = abs(a["kld"] - b["kld"]) / abs(a["kld"])
-    _report("gp_chain_vs_eager", **errs)
+    _report("gp_chain_vs_eager" + ("" if hid else "_nohid"), **errs)
     # fp32 / fp64 atomics (head gradients, the prior's per-subject sums) reorder between runs, and Adam turns a sign flip of a tiny
     # gradient into a +-lr step: measured kld 7e-6, parameters 2.7e-4 of the largest one, m 3e-6, H 5e-8, hyper-parameters 1e-9
     assert errs["kld"] < 1e-4 and errs["arena"] < 2e-3 and errs["theta"] < 1e-6 and errs["m"] < 1e-4 and errs["H"] < 1e-5, errs
