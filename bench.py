@@ -458,17 +458,20 @@ def main():
     if rank == 0 and world == 1 and default_run and not a.no_also:
         # BASELINE configs[4] -- the reference's actual training mode (elbo_functions.py:196-285 + training.py:130-137: GP-prior KL and
         # natural gradient beside the decoder) -- measured in the same run by a child process (never exec from a GPU process)
+        # ... and the configuration the reference SHIPS (config/hlvae_config_file.txt:22, 51: convolutional encoder / decoder + GP prior)
         import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "d4", "--rows", "50000", "--batch", "1024", "--kl", "gp",
-               "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-also"]
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-            j = json.loads(r.stdout.strip().splitlines()[-1])
-            also = {"configs[4]": {k: j[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")} |
-                    {"workload": j["config"]["workload"], "kl": j["config"]["kl"], "final_nll_sum": j["config"]["final_nll_sum"],
-                     "command": "bench.py " + " ".join(cmd[2:])}}
-        except Exception as e:     # noqa: BLE001 -- the headline line must not be lost to the extra leg
-            also = {"configs[4]": {"error": f"{type(e).__name__}: {e}"}}
+        also = {}
+        for key, flags in (("configs[4]", ["--workload", "d4", "--rows", "50000", "--batch", "1024", "--kl", "gp"]),
+                           ("shipped_conv_gp", ["--conv", "--kl", "gp"])):
+            cmd = [sys.executable, os.path.abspath(__file__)] + flags + ["--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-also"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                also[key] = ({k: j[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline")} |
+                             {"workload": j["config"]["workload"], "kl": j["config"]["kl"], "final_nll_sum": j["config"]["final_nll_sum"],
+                              "command": "bench.py " + " ".join(cmd[2:])})
+            except Exception as e:     # noqa: BLE001 -- the headline line must not be lost to the extra leg
+                also[key] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         T = T_SUBJECT[a.workload]

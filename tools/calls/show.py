@@ -15,3 +15,5 @@ if tl:
 if "also" in j:
     a = j["also"].get("configs[4]", {})
     print("   also configs[4]:", a.get("ms_per_step"), a.get("error"))
+    b = j["also"].get("shipped_conv_gp") or {}
+    print("   also shipped conv+gp:", b.get("ms_per_step"), b.get("error"))
